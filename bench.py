@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the FWI hot path (forward modelling -> misfit -> adjoint -> model gradient).
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+A "step" is one full gradient evaluation over the rank's shots.  value = interior
+cells x time steps x shots (all ranks) / wall second, in Mcells*steps/s (BASELINE.json metric).
+Shots are independent => weak scaling: every rank runs the workload's per-GPU shot count and
+the only collective is one all-reduce of the model gradient (RCCL) inside the timed step.
+Inputs are synthetic and resident in HBM before timing starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def synth_vp(nz, nx, seed, water_rows=26):
+    """1500 + 2500 z/nz + Gaussian-smoothed (sigma=5) N(0,150^2), clipped to
+    [1500,4500], water layer on top."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    z = np.arange(nz, dtype=np.float64)[:, None] / nz
+    vp = 1500.0 + 2500.0 * z + gaussian_filter(rng.normal(0.0, 150.0, (nz, nx)), 5.0) * 5.0
+    vp = np.clip(vp, 1500.0, 4500.0)
+    vp[:water_rows, :] = 1500.0
+    return vp.astype(np.float32)
+
+
+class AcousticMarmousi:
+    """BASELINE.json configs[1]: 2-D acoustic Marmousi-like 174x500, 29 shots, 2000 steps,
+    deepwave-shaped call protocol + the L1 trace-normalised misfit of networks.py:5467-5476."""
+    name = "acoustic_marmousi_174x500_29shots_2000steps"
+    nz, nx, h, dt, nt, freq = 174, 500, 10.0, 0.001, 2000, 8.0
+    shots_per_gpu = 29
+    pml = 20
+    fwd_bytes, adj_bytes = 16.0, 20.0          # SURVEY.md 8d algorithmic B / cell-step
+
+    def __init__(self, dev, rank, world, nt=None, shots=None):
+        import torch
+        import physicsbasedfwi2_amd.compat.deepwave as deepwave
+        self.torch, self.deepwave, self.dev = torch, deepwave, dev
+        if nt:
+            self.nt = nt
+        ns = shots or self.shots_per_gpu
+        self.ns = ns
+        total = ns * world
+        xs_all = np.linspace(0.0, (self.nx - 1) * self.h, total)
+        xs = xs_all[rank * ns:(rank + 1) * ns]
+        self.x_s = torch.zeros(ns, 1, 2)
+        self.x_s[:, 0, 1] = torch.tensor(xs, dtype=torch.float32)
+        self.x_r = torch.zeros(ns, self.nx, 2)
+        self.x_r[:, :, 1] = (torch.arange(self.nx).float() * self.h)[None, :]
+        self.x_s, self.x_r = self.x_s.to(dev), self.x_r.to(dev)
+        self.wav = deepwave.wavelets.ricker(self.freq, self.nt, self.dt, 1.0 / self.freq) \
+            .reshape(-1, 1, 1).repeat(1, ns, 1).to(dev)
+        self.vp = torch.tensor(synth_vp(self.nz, self.nx, 0), device=dev, requires_grad=True)
+        vp_true = torch.tensor(synth_vp(self.nz, self.nx, 1), device=dev)
+        with torch.no_grad():
+            obs = deepwave.scalar.Propagator({"vp": vp_true}, self.h, pml_width=self.pml)(
+                self.wav, self.x_s, self.x_r, self.dt)
+            omax, _ = obs.abs().max(dim=0, keepdim=True)
+            self.obs = obs / (omax + 1e-10)
+        self.t_fwd = self.t_bwd = 0.0
+        self.n_timed = 0
+
+    # cells one kernel launch updates (computational grid incl. absorbing layer, all shots)
+    @property
+    def cells_per_launch(self):
+        return (self.nz + 2 * self.pml) * (self.nx + 2 * self.pml) * self.ns
+
+    @property
+    def units_per_step(self):
+        return self.nz * self.nx * self.nt * self.ns
+
+    def step(self, timed=False):
+        torch = self.torch
+        self.vp.grad = None
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        prop = self.deepwave.scalar.Propagator({"vp": self.vp}, self.h, pml_width=self.pml)
+        ev[0].record()
+        rec = prop(self.wav, self.x_s, self.x_r, self.dt)
+        ev[1].record()
+        pmax, _ = rec.abs().max(dim=0, keepdim=True)
+        loss = torch.nn.functional.l1_loss(rec / (pmax + 1e-10), self.obs)
+        (grec,) = torch.autograd.grad(loss, rec, retain_graph=True)
+        ev[2].record()
+        rec.backward(grec)
+        ev[3].record()
+        if timed:
+            self._ev = getattr(self, "_ev", []) + [ev]
+        return self.vp.grad, loss
+
+    def kernel_times(self):
+        """avg per-launch duration (s) of the forward(+save) and adjoint(+imaging) kernels from
+        the HIP events recorded on the launch stream around the two time loops."""
+        tf = np.mean([e[0].elapsed_time(e[1]) for e in self._ev]) * 1e-3
+        tb = np.mean([e[2].elapsed_time(e[3]) for e in self._ev]) * 1e-3
+        return tf / self.nt, tb / max(1, self.nt - 1)
+
+    def cpu_baseline(self, budget_s=20.0):
+        """The C oracle (scalar port, OpenMP over shots) on a bounded sample of this workload."""
+        import oracle
+        from oracle import helpers as H
+        o = oracle.load("f32")
+        cores = os.cpu_count() or 1
+        P, h, dt = self.pml, self.h, self.dt
+        vp = np.pad(synth_vp(self.nz, self.nx, 0), P, mode="edge").astype(np.float64)
+        r = (vp * dt / h) ** 2
+        N0, N1 = r.shape
+        q0 = H.damp_profile_1d(N0, P, h) * h * h / (2 * dt)
+        q1 = H.damp_profile_1d(N1, P, h) * h * h / (2 * dt)
+        ns = min(self.ns, cores)
+        nt = 200
+        f = np.zeros((nt, ns, 1), dtype=np.float32)
+        f[:, :, 0] = (H.ricker_deepwave(self.freq, nt, dt, 1.0 / self.freq) * h * h)[:, None]
+        sc, sw = H.cell_taps(np.full((ns, 1), P), (np.linspace(0, self.nx - 1, ns)[:, None]
+                                                   .astype(int) + P), N1)
+        rc, rw = H.cell_taps(np.full((ns, self.nx), P), np.arange(self.nx)[None, :]
+                             .repeat(ns, 0) + P, N1)
+        t0 = time.time()
+        rec, G = o.acoustic_forward(r, q0, q1, f, sc, sw, rc, rw, save=True)
+        o.acoustic_backward(r, q0, q1, sc, sw, rc, rw, rec, G)
+        el = time.time() - t0
+        return {"value": self.nz * self.nx * nt * ns / el / 1e6, "unit": "Mcells*steps/s",
+                "cores": cores, "kind": "port",
+                "sample": "%d shots x %d steps of this workload, forward+adjoint, C oracle "
+                          "(oracle/acoustic.c, OpenMP over shots), %.1f s" % (ns, nt, el)}
+
+
+WORKLOADS = {"acoustic_marmousi": AcousticMarmousi}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="acoustic_marmousi", choices=sorted(WORKLOADS))
+    ap.add_argument("--nt", type=int, default=0, help="override time steps (debug only)")
+    ap.add_argument("--shots", type=int, default=0, help="override shots per GPU (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = WORKLOADS[args.workload](dev, rank, world, nt=args.nt or None, shots=args.shots or None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(timed):
+        grad, loss = wl.step(timed)
+        if world > 1:
+            from physicsbasedfwi2_amd import dist as mdist
+            mdist.all_reduce_gradient([grad], loss)
+        return grad, loss
+
+    for _ in range(args.warmup):
+        one_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        value = wl.units_per_step * world * args.steps / el / 1e6
+        t_f, t_b = wl.kernel_times()
+        cells = wl.cells_per_launch
+        kern = {
+            "forward+save": {"avg_launch_s": t_f, "alg_bytes_per_cell_step": wl.fwd_bytes,
+                             "achieved_GBs": wl.fwd_bytes * cells / t_f / 1e9},
+            "adjoint+imaging": {"avg_launch_s": t_b, "alg_bytes_per_cell_step": wl.adj_bytes,
+                                "achieved_GBs": wl.adj_bytes * cells / t_b / 1e9},
+        }
+        dom = "adjoint+imaging" if t_b >= t_f else "forward+save"
+        out = {
+            "metric": "grid-cells*timesteps/sec (forward+adjoint gradient pass)",
+            "value": value, "unit": "Mcells*steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl.name, "shots_per_gpu": wl.ns, "nt": wl.nt,
+                       "grid": [wl.nz, wl.nx], "parallelism": "shots x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": dom,
+                         "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS,
+                         "traffic": None},
+            "kernels": kern,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = wl.cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+/*
+ * mifwi.h -- C-ABI of the MI355X-native 2-D finite-difference wave propagator
+ * (libmifwi.so, hand-written HIP for gfx950).
+ *
+ * The reference (ADharaUTEXAS123007/PhysicsBasedFWI2) has no C interface of its own: its
+ * hot path is reached through three third-party Python call protocols.  Every entry point
+ * below names the reference call site(s) it replaces (paths relative to the reference
+ * tree); INTEGRATION.md shows the binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MIFWI_E* code otherwise; no C++
+ *     exception crosses the boundary; mifwi_last_error() gives the message (thread-local).
+ *   - all array arguments are DEVICE pointers owned by the caller (the Python host passes
+ *     torch tensors' data_ptr()); the library allocates no device memory and keeps no
+ *     global state; `stream` is a hipStream_t (0 = default stream).
+ *   - arithmetic is fp32; indices are int32; cells are linear indices i0*n1+i1 into the
+ *     computational grid (axis 1 fastest), -1 = inactive tap.
+ *   - there is NO CPU fallback: without a visible gfx950 device every compute call fails
+ *     with MIFWI_ENODEVICE.
+ */
+#ifndef MIFWI_H
+#define MIFWI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIFWI_VERSION_MAJOR 0
+#define MIFWI_VERSION_MINOR 1
+
+enum {
+    MIFWI_OK = 0,
+    MIFWI_EINVAL = -1,     /* bad argument / shape mismatch                     */
+    MIFWI_ENODEVICE = -2,  /* no HIP device / wrong architecture                */
+    MIFWI_EHIP = -3,       /* a HIP runtime call failed                          */
+    MIFWI_ECFL = -4,       /* stability limit violated                           */
+    MIFWI_ENOMEM = -5      /* caller-provided workspace too small                */
+};
+
+const char *mifwi_last_error(void);
+int mifwi_version(void);                 /* major*1000 + minor                  */
+int mifwi_device_count(void);            /* number of visible HIP devices, >=0  */
+
+/* ======================================================================================
+ * 2-D constant-density ACOUSTIC propagator (forward + exact discrete adjoint)
+ *
+ * Replaces:
+ *   deepwave.scalar.Propagator({'vp': m}, dx)(src, x_s, x_r, dt) and its autograd
+ *   backward                                   models/networks.py:5408-5411, 5449, 5464, 5491
+ *   Devito Forward/Gradient operators          seisgan/fwi/pde/seismic/acoustic/operators.py:54-89,
+ *                                              127-165 ; wavesolver.py:72-107, 143-172
+ *
+ * Scheme:  r = vp^2 dt^2/h^2 = s^2/(m h^2);  q = q0[i0]+q1[i1]
+ *   u+ = (2u - (1-q r) u- + r L4(u)) / (1+q r) + sum_taps w f[n] r[cell]
+ *   rec[n] = sum_taps w u^n[cell]            (time loop n = 0..nt-1)
+ * ==================================================================================== */
+typedef struct {
+    int32_t n0, n1;        /* computational grid (caller has already padded the model)      */
+    int32_t nt;            /* time steps                                                    */
+    int32_t nshot;         /* shots propagated together (independent wavefields)            */
+    int32_t nsrc, nrec;    /* sources / receivers per shot                                  */
+    int32_t ntap;          /* taps per point: 1 = nearest cell, 4 = bilinear                */
+    float c0, c1;          /* (h/h0)^2, (h/h1)^2 with h = min(h0,h1)                        */
+    int32_t shots_per_group; /* shots marched by one thread (gradient RMW amortisation); 0 = auto */
+    int32_t reserved;
+} mifwi_acoustic_desc;
+
+typedef struct mifwi_acoustic_plan mifwi_acoustic_plan;
+
+int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
+                               const mifwi_acoustic_desc *desc);
+int mifwi_acoustic_plan_destroy(mifwi_acoustic_plan *plan);
+
+/* Buffer layout the caller needs for allocation (all counts in floats):
+ *   wavefields      [nshot][n0+4][pitch]   (2 halo rows top/bottom, interior column 0 at +4)
+ *   coefficient r, every snapshot slice, gradients, accumulators   [n0][gp]
+ *   gp = n1 rounded up to a multiple of 4; cells i1 >= n1 of r must be 0.                   */
+typedef struct {
+    int32_t gp, pitch, ngroups, shots_per_group;
+    int64_t field_elems;          /* one wavefield set                                       */
+    int64_t coef_elems;           /* n0*gp                                                   */
+    int64_t work_forward_elems;   /* size of `work` for mifwi_acoustic_forward               */
+    int64_t work_backward_elems;  /* size of `work` for mifwi_acoustic_backward              */
+} mifwi_acoustic_layout;
+
+int mifwi_acoustic_plan_layout(const mifwi_acoustic_plan *plan, mifwi_acoustic_layout *out);
+
+/* flags for the time-range calls */
+#define MIFWI_ZERO_STATE 1   /* zero the wavefield state (and accumulators) in `work` first   */
+#define MIFWI_FINALIZE   2   /* backward: reduce accumulators into grad_r, emit grad_f[k_lo-1] */
+
+/* Forward modelling of steps n = n_begin .. n_end-1 (a full run is [0, nt) with
+ * MIFWI_ZERO_STATE).  The wavefield state (u^n, u^{n-1}) lives in the first
+ * 2*field_elems floats of `work`; buffer parity is absolute in n, so a run can be split
+ * into ranges and the state copied out/in by the caller (time checkpointing).
+ *   r [n0][gp], q0 [n0], q1 [gp]
+ *   f [nt][nshot][nsrc]; src_cell/src_w [nshot][nsrc][ntap]; rec_cell/rec_w [nshot][nrec][ntap]
+ *   rec_out [nt][nshot][nrec] or NULL (no sampling)
+ *   snap : NULL, or [n_end-n_begin][nshot][n0][gp] receiving G^n = d u^{n+1}/d r
+ *   work : layout.work_forward_elems floats                                                 */
+int mifwi_acoustic_forward(mifwi_acoustic_plan *plan, const float *r, const float *q0,
+                           const float *q1, const float *f, const int32_t *src_cell,
+                           const float *src_w, const int32_t *rec_cell, const float *rec_w,
+                           float *rec_out, float *snap, float *work, int32_t n_begin,
+                           int32_t n_end, int32_t flags, void *stream);
+
+/* Exact discrete adjoint + imaging for k = k_hi down to k_lo (a full run is k_hi = nt-1,
+ * k_lo = 1 with MIFWI_ZERO_STATE | MIFWI_FINALIZE).  Step k needs snapshot G^{k-1}, found at
+ * snap + (k-1-snap_first)*nshot*n0*gp.
+ *   grad_rec [nt][nshot][nrec] = dJ/d rec
+ *   grad_r [n0][gp]  (written when MIFWI_FINALIZE; sum over the plan's shots)
+ *   grad_f NULL or [nt][nshot][nsrc]
+ *   work : layout.work_backward_elems floats (adjoint state + accumulators)                 */
+int mifwi_acoustic_backward(mifwi_acoustic_plan *plan, const float *r, const float *q0,
+                            const float *q1, const int32_t *src_cell, const float *src_w,
+                            const int32_t *rec_cell, const float *rec_w, const float *grad_rec,
+                            const float *snap, int32_t snap_first, float *grad_r, float *grad_f,
+                            float *work, int32_t k_hi, int32_t k_lo, int32_t flags,
+                            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIFWI_H */

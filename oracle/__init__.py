@@ -1,0 +1,112 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+CPU restatement (plain C + numpy) of the reference's wave-propagation hot path.
+Importable only from ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg; the product package never imports it.
+
+PARITY STATUS: pinned against the reference's own numpy helpers
+(tests/golden/seisgan_helpers.npz), the analytical Green's function of
+accuracy.ipynb and the Taylor-gradient criterion of gradient_example.py.  Parity
+with deepwave / DENISE / Devito binaries is UNPINNED (none is present).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def build(force=False):
+    """Compile the C oracle (gcc).  Building the checker is not using it."""
+    want = [os.path.join(_HERE, "liboracle_f32.so"), os.path.join(_HERE, "liboracle_f64.so")]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    stale = force or any(
+        (not os.path.exists(w)) or any(os.path.getmtime(s) > os.path.getmtime(w) for s in srcs)
+        for w in want)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
+    return want
+
+
+def _cfg_struct(real):
+    class Cfg(ctypes.Structure):
+        _fields_ = [("n0", ctypes.c_int), ("n1", ctypes.c_int), ("nt", ctypes.c_int),
+                    ("nshot", ctypes.c_int), ("nsrc", ctypes.c_int), ("nrec", ctypes.c_int),
+                    ("ntap", ctypes.c_int), ("c0", real), ("c1", real)]
+    return Cfg
+
+
+class Oracle:
+    """ctypes view of liboracle_{f32,f64}.so."""
+
+    def __init__(self, precision="f32"):
+        build()
+        self.precision = precision
+        self.dtype = np.float32 if precision == "f32" else np.float64
+        self.creal = ctypes.c_float if precision == "f32" else ctypes.c_double
+        self.lib = ctypes.CDLL(os.path.join(_HERE, "liboracle_%s.so" % precision))
+        assert self.lib.oracle_real_bytes() == np.dtype(self.dtype).itemsize
+        self.AcCfg = _cfg_struct(self.creal)
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _r(self, a):
+        return np.ascontiguousarray(a, dtype=self.dtype)
+
+    @staticmethod
+    def _i(a):
+        return np.ascontiguousarray(a, dtype=np.int32)
+
+    @staticmethod
+    def _p(a):
+        return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+    # -- acoustic ------------------------------------------------------------------------------
+    def acoustic_forward(self, r, q0, q1, f, src_cell, src_w, rec_cell, rec_w,
+                         c0=1.0, c1=1.0, save=False):
+        """f [nt,ns,nsrc]; src_cell/src_w [ns,nsrc,ntap]; rec_* [ns,nrec,ntap].
+        Returns rec [nt,ns,nrec] (and G [nt,ns,n0,n1] when save)."""
+        r = self._r(r); q0 = self._r(q0); q1 = self._r(q1); f = self._r(f)
+        src_cell = self._i(src_cell); rec_cell = self._i(rec_cell)
+        src_w = self._r(src_w); rec_w = self._r(rec_w)
+        n0, n1 = r.shape
+        nt, ns, nsrc = f.shape
+        nrec, ntap = rec_cell.shape[1], rec_cell.shape[2]
+        assert src_cell.shape == (ns, nsrc, ntap) and rec_cell.shape == (ns, nrec, ntap)
+        cfg = self.AcCfg(n0, n1, nt, ns, nsrc, nrec, ntap, c0, c1)
+        rec = np.zeros((nt, ns, nrec), dtype=self.dtype)
+        G = np.zeros((nt, ns, n0, n1), dtype=self.dtype) if save else None
+        st = self.lib.oracle_acoustic_forward(ctypes.byref(cfg), self._p(r), self._p(q0),
+                                              self._p(q1), self._p(f), self._p(src_cell),
+                                              self._p(src_w), self._p(rec_cell), self._p(rec_w),
+                                              self._p(rec), self._p(G))
+        if st != 0:
+            raise MemoryError("oracle_acoustic_forward failed")
+        return (rec, G) if save else rec
+
+    def acoustic_backward(self, r, q0, q1, src_cell, src_w, rec_cell, rec_w, g, G,
+                          c0=1.0, c1=1.0, want_grad_f=True):
+        r = self._r(r); q0 = self._r(q0); q1 = self._r(q1); g = self._r(g); G = self._r(G)
+        src_cell = self._i(src_cell); rec_cell = self._i(rec_cell)
+        src_w = self._r(src_w); rec_w = self._r(rec_w)
+        n0, n1 = r.shape
+        nt, ns, nrec = g.shape
+        nsrc, ntap = src_cell.shape[1], src_cell.shape[2]
+        cfg = self.AcCfg(n0, n1, nt, ns, nsrc, nrec, ntap, c0, c1)
+        grad_r = np.zeros((n0, n1), dtype=self.dtype)
+        grad_f = np.zeros((nt, ns, nsrc), dtype=self.dtype) if want_grad_f else None
+        st = self.lib.oracle_acoustic_backward(ctypes.byref(cfg), self._p(r), self._p(q0),
+                                               self._p(q1), self._p(src_cell), self._p(src_w),
+                                               self._p(rec_cell), self._p(rec_w), self._p(g),
+                                               self._p(G), self._p(grad_r), self._p(grad_f))
+        if st != 0:
+            raise MemoryError("oracle_acoustic_backward failed")
+        return grad_r, grad_f
+
+
+def load(precision="f32"):
+    if precision not in _LIBS:
+        _LIBS[precision] = Oracle(precision)
+    return _LIBS[precision]

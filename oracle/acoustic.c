@@ -1,0 +1,233 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the shipped product path.
+ *
+ * Plain-C CPU restatement of the 2-D constant-density acoustic propagator the
+ * reference reaches through Devito (seisgan/fwi) and deepwave.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * shared object; the product (physicsbasedfwi2_amd/) never does.
+ *
+ * Scheme followed (reference file:line, paths relative to /root/reference):
+ *   - PDE  m*u_tt - lap(u) + damp*u_t = q, centred dt / dt2, solved for u+ :
+ *       seisgan/fwi/pde/seismic/acoustic/operators.py:24-51 (iso_stencil)
+ *   - 4th-order (5 points per axis) Laplacian, space_order=4:
+ *       operators.py:8-21 (laplacian), seisgan/fwi/layers.py:102
+ *   - source term  u+[x] += w * src[t] * s^2/m[x]        : operators.py:81-82
+ *   - receiver     rec[t] = sum_taps w * u[t][x]          : operators.py:85
+ *   - adjoint time stepping with the damping sign flipped : operators.py:41-47,113
+ *   - imaging condition (model gradient)                  : operators.py:152-153
+ *     -- restated here as the EXACT discrete adjoint of the forward recursion
+ *        (Devito's `grad -= u.dt2*v` is its one-step-shifted approximation).
+ *
+ * Parity status: the third-party arithmetic (Devito ~3.x / deepwave <=0.0.9) is
+ * absent from /root/reference and from this image, so PARITY WITH THOSE PACKAGES
+ * IS UNPINNED.  What is pinned: the numpy helpers of seisgan (damping profile,
+ * Ricker, critical_dt, TimeAxis: tests/golden/seisgan_helpers.npz), the
+ * analytical 2-D Green's function (accuracy.ipynb cell 9) and the Taylor
+ * gradient criterion (gradient_example.py:143-146).
+ *
+ * Parametrisation (one kernel serves the seisgan- and the deepwave-shaped API):
+ *   r[i0][i1] = s^2 / (m h^2) = vp^2 dt^2 / h^2      (h = reference spacing)
+ *   q = q0[i0] + q1[i1] = damp * h^2 / (2 s)         (separable: model.py:6-29
+ *                                                     adds the profile per side)
+ *   a/m = 1 + q r,  inv = 1/(1+q r)
+ *   u+ = inv * (2u - (1-q r) u- + r * L(u)) + sum_taps w f[n] r[cell]
+ *   L(u) = c0 * D2_0(u) + c1 * D2_1(u),  D2 = (-5/2, 4/3, -1/12) unit spacing,
+ *          c_k = (h/h_k)^2
+ * Time loop n = 0..nt-1:  rec[n] = R u^n ; u^{n+1} = step(u^n, u^{n-1}) + inj(f[n]).
+ *
+ * The arithmetic is written as an explicit fmaf chain and must be compiled with
+ * -ffp-contract=off so that the HIP kernels (same chain) can be compared bitwise.
+ *
+ * Build:  make -C oracle      (f32 -> liboracle_f32.so, f64 -> liboracle_f64.so)
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef ORACLE_DOUBLE
+typedef double real;
+#define FMA(a, b, c) fma((a), (b), (c))
+#else
+typedef float real;
+#define FMA(a, b, c) fmaf((a), (b), (c))
+#endif
+
+#define K0 ((real)-2.5)
+#define K1 ((real)(4.0 / 3.0))
+#define K2 ((real)(-1.0 / 12.0))
+#define HALO 2
+
+typedef struct {
+    int n0, n1;        /* computational grid (already padded by the caller)   */
+    int nt;            /* user time steps                                      */
+    int nshot;
+    int nsrc, nrec;    /* points per shot                                      */
+    int ntap;          /* taps per point: 1 (cell) or 4 (bilinear)             */
+    real c0, c1;       /* (h/h0)^2, (h/h1)^2                                   */
+} oracle_acoustic_cfg;
+
+/* padded scratch field: (n0+4) x (n1+4), zero halo */
+static inline size_t pidx(const oracle_acoustic_cfg *c, int i0, int i1)
+{
+    return (size_t)(i0 + HALO) * (size_t)(c->n1 + 2 * HALO) + (size_t)(i1 + HALO);
+}
+
+/* one time step for one shot:  un overwrites up (in place leapfrog).
+ * If G != NULL, stores the gradient kernel  G = d u^{n+1} / d r  (explicit part,
+ * source term added by the caller).                                            */
+static void step_shot(const oracle_acoustic_cfg *c, const real *r, const real *q0,
+                      const real *q1, const real *u, real *up, real *G)
+{
+    const int n0 = c->n0, n1 = c->n1;
+    const size_t p = (size_t)(n1 + 2 * HALO);
+    for (int i0 = 0; i0 < n0; ++i0) {
+        for (int i1 = 0; i1 < n1; ++i1) {
+            const size_t k = pidx(c, i0, i1);
+            const real uc = u[k];
+            const real s01 = u[k - p] + u[k + p];
+            const real s02 = u[k - 2 * p] + u[k + 2 * p];
+            const real s11 = u[k - 1] + u[k + 1];
+            const real s12 = u[k - 2] + u[k + 2];
+            const real l0 = FMA(K1, s01, FMA(K2, s02, K0 * uc));
+            const real l1 = FMA(K1, s11, FMA(K2, s12, K0 * uc));
+            const real lap = FMA(c->c0, l0, c->c1 * l1);
+            const real rr = r[(size_t)i0 * n1 + i1];
+            const real q = q0[i0] + q1[i1];
+            const real qr = q * rr;
+            const real inv = (real)1 / ((real)1 + qr);
+            const real upv = up[k];
+            const real num = FMA(rr, lap, FMA(-((real)1 - qr), upv, (real)2 * uc));
+            const real un = inv * num;
+            if (G) G[(size_t)i0 * n1 + i1] = inv * (FMA(q, upv, lap) - q * un);
+            up[k] = un;
+        }
+    }
+}
+
+/* rec_out [nt][nshot][nrec];  f [nt][nshot][nsrc];  cells are linear i0*n1+i1
+ * (negative = inactive tap);  G [nt][nshot][n0][n1] or NULL.                   */
+int oracle_acoustic_forward(const oracle_acoustic_cfg *c, const real *r, const real *q0,
+                            const real *q1, const real *f, const int *src_cell,
+                            const real *src_w, const int *rec_cell, const real *rec_w,
+                            real *rec_out, real *G)
+{
+    const int n0 = c->n0, n1 = c->n1, ns = c->nshot;
+    const size_t ncell = (size_t)n0 * n1;
+    const size_t npad = (size_t)(n0 + 2 * HALO) * (n1 + 2 * HALO);
+    int status = 0;
+#pragma omp parallel for schedule(dynamic)
+    for (int s = 0; s < ns; ++s) {
+        real *ua = (real *)calloc(npad, sizeof(real));
+        real *ub = (real *)calloc(npad, sizeof(real));
+        if (!ua || !ub) { status = 1; free(ua); free(ub); continue; }
+        real *ucur = ua, *uprev = ub;
+        for (int n = 0; n < c->nt; ++n) {
+            /* receivers read u^n */
+            for (int ir = 0; ir < c->nrec; ++ir) {
+                real acc = 0;
+                for (int t = 0; t < c->ntap; ++t) {
+                    const size_t e = ((size_t)s * c->nrec + ir) * c->ntap + t;
+                    const int cell = rec_cell[e];
+                    if (cell >= 0) acc = FMA(rec_w[e], ucur[pidx(c, cell / n1, cell % n1)], acc);
+                }
+                rec_out[((size_t)n * ns + s) * c->nrec + ir] = acc;
+            }
+            real *Gn = G ? G + ((size_t)n * ns + s) * ncell : NULL;
+            step_shot(c, r, q0, q1, ucur, uprev, Gn);
+            /* source injection into u^{n+1} (now in uprev) */
+            for (int is = 0; is < c->nsrc; ++is) {
+                const real amp = f[((size_t)n * ns + s) * c->nsrc + is];
+                for (int t = 0; t < c->ntap; ++t) {
+                    const size_t e = ((size_t)s * c->nsrc + is) * c->ntap + t;
+                    const int cell = src_cell[e];
+                    if (cell < 0) continue;
+                    const real wf = src_w[e] * amp;
+                    uprev[pidx(c, cell / n1, cell % n1)] += wf * r[cell];
+                    if (Gn) Gn[cell] += wf;
+                }
+            }
+            real *tmp = ucur; ucur = uprev; uprev = tmp;
+        }
+        free(ua); free(ub);
+    }
+    return status;
+}
+
+/* Exact discrete adjoint.  g [nt][nshot][nrec] = dJ/d rec.
+ * State z^n = r*inv*lambda^n obeys the forward recursion run backwards:
+ *   z^n = inv*(2 z^{n+1} - (1-q r) z^{n+2} + r L z^{n+1}) + r*inv*R^T g^n
+ * grad_r = (1+q r)/r * sum_n z^{n+1} G^n ;  grad_f[n] = sum_taps w (1+q r) z^{n+1}.
+ * grad_r [n0][n1] is OVERWRITTEN with the sum over shots (shot order 0..ns-1).  */
+int oracle_acoustic_backward(const oracle_acoustic_cfg *c, const real *r, const real *q0,
+                             const real *q1, const int *src_cell, const real *src_w,
+                             const int *rec_cell, const real *rec_w, const real *g,
+                             const real *G, real *grad_r, real *grad_f)
+{
+    const int n0 = c->n0, n1 = c->n1, ns = c->nshot;
+    const size_t ncell = (size_t)n0 * n1;
+    const size_t npad = (size_t)(n0 + 2 * HALO) * (n1 + 2 * HALO);
+    real *acc_all = (real *)calloc(ncell * ns, sizeof(real));
+    if (!acc_all) return 1;
+    int status = 0;
+#pragma omp parallel for schedule(dynamic)
+    for (int s = 0; s < ns; ++s) {
+        real *za = (real *)calloc(npad, sizeof(real));
+        real *zb = (real *)calloc(npad, sizeof(real));
+        if (!za || !zb) { status = 1; free(za); free(zb); continue; }
+        real *zcur = za, *zprev = zb;   /* zcur = z^{k+1}, zprev = z^{k+2} */
+        real *acc = acc_all + (size_t)s * ncell;
+        for (int k = c->nt - 1; k >= 1; --k) {
+            step_shot(c, r, q0, q1, zcur, zprev, NULL);      /* zprev <- z^k (no injection yet) */
+            for (int ir = 0; ir < c->nrec; ++ir) {
+                const real gv = g[((size_t)k * ns + s) * c->nrec + ir];
+                for (int t = 0; t < c->ntap; ++t) {
+                    const size_t e = ((size_t)s * c->nrec + ir) * c->ntap + t;
+                    const int cell = rec_cell[e];
+                    if (cell < 0) continue;
+                    const int i0 = cell / n1, i1 = cell % n1;
+                    const real rr = r[cell];
+                    const real q = q0[i0] + q1[i1];
+                    const real inv = (real)1 / ((real)1 + q * rr);
+                    zprev[pidx(c, i0, i1)] += (rec_w[e] * gv) * (rr * inv);
+                }
+            }
+            real *tmp = zcur; zcur = zprev; zprev = tmp;       /* zcur = z^k */
+            const real *Gk = G + ((size_t)(k - 1) * ns + s) * ncell;
+            for (int i0 = 0; i0 < n0; ++i0)
+                for (int i1 = 0; i1 < n1; ++i1) {
+                    const size_t cidx = (size_t)i0 * n1 + i1;
+                    acc[cidx] = FMA(zcur[pidx(c, i0, i1)], Gk[cidx], acc[cidx]);
+                }
+            if (grad_f) {
+                for (int is = 0; is < c->nsrc; ++is) {
+                    real a = 0;
+                    for (int t = 0; t < c->ntap; ++t) {
+                        const size_t e = ((size_t)s * c->nsrc + is) * c->ntap + t;
+                        const int cell = src_cell[e];
+                        if (cell < 0) continue;
+                        const int i0 = cell / n1, i1 = cell % n1;
+                        const real q = q0[i0] + q1[i1];
+                        a = FMA(src_w[e] * ((real)1 + q * r[cell]), zcur[pidx(c, i0, i1)], a);
+                    }
+                    grad_f[((size_t)(k - 1) * ns + s) * c->nsrc + is] = a;
+                }
+            }
+        }
+        if (grad_f)
+            for (int is = 0; is < c->nsrc; ++is)
+                grad_f[((size_t)(c->nt - 1) * ns + s) * c->nsrc + is] = 0;
+        free(za); free(zb);
+    }
+    for (int i0 = 0; i0 < n0; ++i0)
+        for (int i1 = 0; i1 < n1; ++i1) {
+            const size_t cidx = (size_t)i0 * n1 + i1;
+            real a = 0;
+            for (int s = 0; s < ns; ++s) a += acc_all[(size_t)s * ncell + cidx];
+            const real q = q0[i0] + q1[i1];
+            grad_r[cidx] = a * (((real)1 + q * r[cidx]) / r[cidx]);
+        }
+    free(acc_all);
+    return status;
+}
+
+int oracle_real_bytes(void) { return (int)sizeof(real); }

@@ -1,0 +1,132 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY (numpy restatements of the reference's host helpers).
+
+Nothing under ``physicsbasedfwi2_amd/`` may import this module; only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do.
+
+Each function cites the reference file:line it restates (paths relative to
+/root/reference).  Pinned by ``tests/golden/seisgan_helpers.npz`` (minted by
+``tests/golden/make_golden.py`` from the reference's own numpy code).
+"""
+import numpy as np
+
+
+# --- seisgan/fwi/pde/seismic/model.py:6-29 (damp_boundary) -------------------------------
+def damp_profile_1d(n, nbpml, h):
+    """1-D contribution of one axis to the seisgan damping field.
+
+    model.py:13-20: for i in range(nbpml): pos = |(nbpml-i+1)/nbpml|,
+    val = 1.5*ln(1000)/40 * (pos - sin(2 pi pos)/(2 pi)); added to rows i and -(i+1),
+    divided by that axis' spacing.  The 2-D field is the sum of both axes' profiles.
+    """
+    d = np.zeros(n, dtype=np.float64)
+    coeff = 1.5 * np.log(1.0 / 0.001) / 40.0
+    for i in range(nbpml):
+        pos = abs((nbpml - i + 1) / float(nbpml))
+        val = coeff * (pos - np.sin(2 * np.pi * pos) / (2 * np.pi))
+        d[i] += val / h
+        d[-(i + 1)] += val / h
+    return d
+
+
+def damp_field(shape_pml, nbpml, spacing):
+    """Full 2-D damping field (model.py:6-29), axis order as given."""
+    d0 = damp_profile_1d(shape_pml[0], nbpml, spacing[0])
+    d1 = damp_profile_1d(shape_pml[1], nbpml, spacing[1])
+    return d0[:, None] + d1[None, :]
+
+
+# --- model.py:160-168 (critical_dt) ----------------------------------------------------------
+def critical_dt(spacing, vp_max, ndim=2):
+    coeff = 0.38 if ndim == 3 else 0.42
+    return coeff * min(spacing) / vp_max
+
+
+# --- model.py:194-200 (pad) ----------------------------------------------------------------------
+def pad_edge(a, nbpml):
+    return np.pad(a, [(nbpml, nbpml)] * a.ndim, "edge")
+
+
+# --- seisgan/fwi/pde/seismic/source.py:36-58 (TimeAxis, the `num is None` branch) ----------
+def time_axis_num(start, stop, step):
+    num = int(np.ceil((stop - start + step) / step))
+    return num, step * (num - 1) + start
+
+
+# --- source.py:224-231 (RickerSource.wavelet): peak at 2/f0 -------------------------------------
+def ricker_seisgan(f0, t):
+    r = np.pi * f0 * (t - 2.0 / f0)
+    return (1 - 2.0 * r ** 2) * np.exp(-r ** 2)
+
+
+# --- deepwave.wavelets.ricker as called at models/networks.py:5357 ------------------------------
+def ricker_deepwave(freq, nt, dt, peak_time):
+    t = np.arange(nt, dtype=np.float64) * dt - peak_time
+    a = (np.pi * freq * t) ** 2
+    return (1 - 2 * a) * np.exp(-a)
+
+
+# --- sparse points -------------------------------------------------------------------------------
+def cell_taps(idx0, idx1, n1):
+    """Integer-cell placement (deepwave / DENISE conventions): one tap, weight 1."""
+    idx0 = np.asarray(idx0, dtype=np.int64)
+    idx1 = np.asarray(idx1, dtype=np.int64)
+    cells = (idx0 * n1 + idx1).astype(np.int32)[..., None]
+    return cells, np.ones(cells.shape, dtype=np.float64)
+
+
+def bilinear_taps(coords, spacing, nbpml, shape_pml):
+    """Devito (bi)linear sparse operator (operators.py:81-85 with offset=nbpml).
+
+    coords [..., 2] in metres relative to the un-padded origin; returns cells [...,4]
+    (linear index in the padded array, axis-0 major) and weights [...,4].
+    """
+    coords = np.asarray(coords, dtype=np.float64)
+    p0 = coords[..., 0] / spacing[0]
+    p1 = coords[..., 1] / spacing[1]
+    i0 = np.floor(p0).astype(np.int64)
+    i1 = np.floor(p1).astype(np.int64)
+    f0 = p0 - i0
+    f1 = p1 - i1
+    n1 = shape_pml[1]
+    cells = np.stack([
+        (i0 + nbpml) * n1 + (i1 + nbpml),
+        (i0 + nbpml) * n1 + (i1 + 1 + nbpml),
+        (i0 + 1 + nbpml) * n1 + (i1 + nbpml),
+        (i0 + 1 + nbpml) * n1 + (i1 + 1 + nbpml)], axis=-1)
+    w = np.stack([(1 - f0) * (1 - f1), (1 - f0) * f1, f0 * (1 - f1), f0 * f1], axis=-1)
+    # taps with zero weight may fall outside the grid: deactivate them
+    inside = (cells >= 0) & (cells < shape_pml[0] * shape_pml[1])
+    cells = np.where((w != 0) & inside, cells, -1)
+    w = np.where(cells >= 0, w, 0.0)
+    return cells.astype(np.int32), w
+
+
+# --- analytical 2-D Green's function (acoustic/accuracy.ipynb cells 9-10) ------------------------
+def analytical_2d(f0, c0, dist, nt, dt_fine, t_peak, amp=1.0):
+    """u(r,t) for a Ricker source time function; units follow the notebook
+    (ms, kHz, km/s, m).  Returns the trace sampled at dt_fine for nt samples."""
+    from scipy.special import hankel2
+    T = (nt - 1) * dt_fine
+    t = np.linspace(-t_peak, T - t_peak, int(T / dt_fine))
+    tt = (np.pi ** 2) * (f0 ** 2) * (t ** 2)
+    rick = amp * (1.0 - 2.0 * tt) * np.exp(-tt)
+    nf = int(nt / 2 + 1)
+    df = 1.0 / T
+    faxis = df * np.arange(nf)
+    R = np.fft.fft(rick / (c0 ** 2))[0:nf]
+    U = np.zeros(nf, dtype=complex)
+    for a in range(1, nf - 1):
+        k = 2 * np.pi * faxis[a] / c0
+        U[a] = -1j * np.pi * hankel2(0.0, k * dist) * R[a]
+    return np.real(1.0 / (2.0 * np.pi) * np.real(np.fft.ifft(U, nt)))
+
+
+# --- scheme coefficients shared by the acoustic tests -------------------------------------------
+def acoustic_coeffs(m_pad, damp0, damp1, s, spacing):
+    """r, q0, q1, c0, c1 of oracle/acoustic.c from square slowness m (padded), the two
+    1-D damping profiles, time step s and spacing (h0, h1)."""
+    h = min(spacing)
+    r = s * s / (m_pad * h * h)
+    q0 = damp0 * h * h / (2 * s)
+    q1 = damp1 * h * h / (2 * s)
+    return r, q0, q1, (h / spacing[0]) ** 2, (h / spacing[1]) ** 2

@@ -1,0 +1,90 @@
+"""ctypes binding of libmifwi.so (the C-ABI declared in include/mifwi.h).
+
+There is no CPU fallback: if the shared object is missing or no HIP device is visible the
+compute entry points raise ``MifwiError``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmifwi.so")
+
+MIFWI_OK = 0
+ZERO_STATE = 1
+FINALIZE = 2
+_ERR_NAMES = {-1: "EINVAL", -2: "ENODEVICE", -3: "EHIP", -4: "ECFL", -5: "ENOMEM"}
+
+
+class MifwiError(RuntimeError):
+    pass
+
+
+class AcousticDesc(ctypes.Structure):
+    _fields_ = [("n0", ctypes.c_int32), ("n1", ctypes.c_int32), ("nt", ctypes.c_int32),
+                ("nshot", ctypes.c_int32), ("nsrc", ctypes.c_int32), ("nrec", ctypes.c_int32),
+                ("ntap", ctypes.c_int32), ("c0", ctypes.c_float), ("c1", ctypes.c_float),
+                ("shots_per_group", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class AcousticLayout(ctypes.Structure):
+    _fields_ = [("gp", ctypes.c_int32), ("pitch", ctypes.c_int32), ("ngroups", ctypes.c_int32),
+                ("shots_per_group", ctypes.c_int32), ("field_elems", ctypes.c_int64),
+                ("coef_elems", ctypes.c_int64), ("work_forward_elems", ctypes.c_int64),
+                ("work_backward_elems", ctypes.c_int64)]
+
+
+_P = ctypes.c_void_p
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against
+# include/mifwi.h so that header and binding cannot drift apart.
+SIGNATURES = {
+    "mifwi_last_error": (ctypes.c_char_p, []),
+    "mifwi_version": (ctypes.c_int, []),
+    "mifwi_device_count": (ctypes.c_int, []),
+    "mifwi_acoustic_plan_create": (ctypes.c_int, [ctypes.POINTER(_P), ctypes.c_int,
+                                                  ctypes.POINTER(AcousticDesc)]),
+    "mifwi_acoustic_plan_destroy": (ctypes.c_int, [_P]),
+    "mifwi_acoustic_plan_layout": (ctypes.c_int, [_P, ctypes.POINTER(AcousticLayout)]),
+    "mifwi_acoustic_forward": (ctypes.c_int, [_P] * 12 + [ctypes.c_int32] * 3 + [_P]),
+    "mifwi_acoustic_backward": (ctypes.c_int, [_P] * 10 + [ctypes.c_int32] + [_P] * 3 +
+                                [ctypes.c_int32] * 3 + [_P]),
+}
+
+_lib = None
+
+
+def load():
+    """Return the loaded library, building it in-tree with hipcc if it is not there yet."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch bundles its own HIP runtime (same soname as /opt/rocm's): it must be the one the
+    # process loads first, or torch later finds no device.
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+        try:
+            _build.build()
+        except Exception as exc:  # noqa: BLE001
+            raise MifwiError(
+                "libmifwi.so is missing and could not be built with hipcc (%s); "
+                "run `python -m physicsbasedfwi2_amd.build`. There is no CPU fallback." % exc)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != MIFWI_OK:
+        msg = load().mifwi_last_error()
+        raise MifwiError("libmifwi %s: %s" % (_ERR_NAMES.get(rc, rc),
+                                                msg.decode() if msg else "unknown error"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,218 @@
+"""Host side of the acoustic propagator: plan handling, buffer allocation (torch = device
+memory + stream plumbing only) and the ``torch.autograd.Function`` through which the model
+gradient reaches the caller, as deepwave's autograd backward does at
+models/networks.py:5464/5491 and ``FWILoss`` does at seisgan/fwi/layers.py:158-197.
+
+All arithmetic happens in libmifwi.so (HIP); there is no CPU path here.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MifwiError
+
+# snapshots kept resident between forward and backward; above this the time axis is cut
+# into checkpointed segments that are re-propagated during the adjoint (exact, ~1 extra forward)
+DEFAULT_SNAPSHOT_BUDGET = 96 << 30
+
+
+class AcousticPlan:
+    """RAII wrapper of ``mifwi_acoustic_plan`` (include/mifwi.h)."""
+
+    def __init__(self, n0, n1, nt, nshot, nsrc, nrec, ntap, c0, c1, device_index,
+                 shots_per_group=0):
+        self._lib = _lib.load()
+        self.desc = _lib.AcousticDesc(n0, n1, nt, nshot, nsrc, nrec, ntap, c0, c1,
+                                      shots_per_group, 0)
+        self._h = ctypes.c_void_p()
+        _lib.check(self._lib.mifwi_acoustic_plan_create(ctypes.byref(self._h), device_index,
+                                                        ctypes.byref(self.desc)))
+        self.layout = _lib.AcousticLayout()
+        _lib.check(self._lib.mifwi_acoustic_plan_layout(self._h, ctypes.byref(self.layout)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            self._lib.mifwi_acoustic_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise MifwiError("%s must live on a HIP device (got %s): libmifwi has no CPU fallback"
+                         % (name, t.device))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Geometry:
+    """Device-resident sparse-point description shared by forward and backward."""
+
+    def __init__(self, src_cell, src_w, rec_cell, rec_w, device):
+        self.src_cell = src_cell.to(device=device, dtype=torch.int32).contiguous()
+        self.src_w = src_w.to(device=device, dtype=torch.float32).contiguous()
+        self.rec_cell = rec_cell.to(device=device, dtype=torch.int32).contiguous()
+        self.rec_w = rec_w.to(device=device, dtype=torch.float32).contiguous()
+        if self.src_cell.dim() != 3 or self.rec_cell.dim() != 3:
+            raise MifwiError("src_cell/rec_cell must be [nshot, npoint, ntap]")
+        if self.src_cell.shape != self.src_w.shape or self.rec_cell.shape != self.rec_w.shape:
+            raise MifwiError("cell/weight shape mismatch")
+        if self.src_cell.shape[0] != self.rec_cell.shape[0]:
+            raise MifwiError("source and receiver shot counts differ")
+        if self.src_cell.shape[2] != self.rec_cell.shape[2]:
+            raise MifwiError("sources and receivers must use the same number of taps")
+
+
+class _AcousticFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r, f, q0, q1, geom, c0, c1, shots_per_group, snapshot_budget):
+        _require_cuda(r, "r")
+        dev = r.device
+        lib = _lib.load()
+        n0, n1 = r.shape
+        nt, ns, nsrc = f.shape
+        if geom.src_cell.shape[:2] != (ns, nsrc):
+            raise MifwiError("f is [nt,%d,%d] but src_cell is %s" % (ns, nsrc,
+                                                                      tuple(geom.src_cell.shape)))
+        nrec, ntap = geom.rec_cell.shape[1], geom.rec_cell.shape[2]
+        ncell = n0 * n1
+        for name, c in (("src_cell", geom.src_cell), ("rec_cell", geom.rec_cell)):
+            if c.numel() and (int(c.max()) >= ncell):
+                raise MifwiError("%s holds a cell outside the %dx%d grid" % (name, n0, n1))
+        with torch.cuda.device(dev):
+            plan = AcousticPlan(n0, n1, nt, ns, nsrc, nrec, ntap, c0, c1, dev.index,
+                                shots_per_group)
+            lay = plan.layout
+            gp = lay.gp
+            r_p = torch.zeros((n0, gp), device=dev, dtype=torch.float32)
+            r_p[:, :n1] = r.detach()
+            q0_d = q0.to(device=dev, dtype=torch.float32).contiguous()
+            q1_p = torch.zeros(gp, device=dev, dtype=torch.float32)
+            q1_p[:n1] = q1.to(device=dev, dtype=torch.float32)
+            f_d = f.detach().to(dtype=torch.float32).contiguous()
+            rec = torch.empty((nt, ns, nrec), device=dev, dtype=torch.float32)
+            work = torch.empty(lay.work_forward_elems, device=dev, dtype=torch.float32)
+            need_grad = r.requires_grad or f.requires_grad
+            step_bytes = 4 * ns * lay.coef_elems
+            seg = nt
+            snap = None
+            ckpt = None
+            if need_grad:
+                if nt * step_bytes > snapshot_budget:
+                    seg = max(1, int(snapshot_budget // (2 * step_bytes)))
+                if seg >= nt:
+                    seg = nt
+                    snap = torch.empty((nt, ns, n0, gp), device=dev, dtype=torch.float32)
+            args = (plan.handle, _lib.ptr(r_p), _lib.ptr(q0_d), _lib.ptr(q1_p), _lib.ptr(f_d),
+                    _lib.ptr(geom.src_cell), _lib.ptr(geom.src_w), _lib.ptr(geom.rec_cell),
+                    _lib.ptr(geom.rec_w), _lib.ptr(rec))
+            if not need_grad or seg == nt:
+                _lib.check(lib.mifwi_acoustic_forward(*args, _lib.ptr(snap), _lib.ptr(work), 0, nt,
+                                                      _lib.ZERO_STATE, _stream()))
+            else:
+                # checkpoint the two-level state at every segment start, no snapshots yet
+                ckpt = []
+                state_elems = 2 * lay.field_elems
+                for b in range(0, nt, seg):
+                    flags = _lib.ZERO_STATE if b == 0 else 0
+                    if b > 0:
+                        ckpt.append(work[:state_elems].clone())
+                    _lib.check(lib.mifwi_acoustic_forward(*args, None, _lib.ptr(work), b,
+                                                          min(b + seg, nt), flags, _stream()))
+            if need_grad:
+                ctx.plan = plan
+                ctx.geom = geom
+                ctx.seg = seg
+                ctx.ckpt = ckpt
+                ctx.snap = snap
+                ctx.dims = (n0, n1, nt, ns, nsrc, nrec)
+                ctx.need_f = f.requires_grad
+                ctx.save_for_backward(r_p, q0_d, q1_p, f_d)
+            else:
+                plan.close()
+        return rec
+
+    @staticmethod
+    def backward(ctx, grad_rec):
+        lib = _lib.load()
+        r_p, q0_d, q1_p, f_d = ctx.saved_tensors
+        plan, geom = ctx.plan, ctx.geom
+        lay = plan.layout
+        n0, n1, nt, ns, nsrc, nrec = ctx.dims
+        dev = r_p.device
+        with torch.cuda.device(dev):
+            g = grad_rec.to(dtype=torch.float32).contiguous()
+            grad_r = torch.empty((n0, lay.gp), device=dev, dtype=torch.float32)
+            grad_f = (torch.zeros((nt, ns, nsrc), device=dev, dtype=torch.float32)
+                      if ctx.need_f else None)
+            work = torch.empty(lay.work_backward_elems, device=dev, dtype=torch.float32)
+            common = (plan.handle, _lib.ptr(r_p), _lib.ptr(q0_d), _lib.ptr(q1_p),
+                      _lib.ptr(geom.src_cell), _lib.ptr(geom.src_w), _lib.ptr(geom.rec_cell),
+                      _lib.ptr(geom.rec_w), _lib.ptr(g))
+            if nt < 2:
+                grad_r.zero_()
+            elif ctx.snap is not None:
+                _lib.check(lib.mifwi_acoustic_backward(
+                    *common, _lib.ptr(ctx.snap), 0, _lib.ptr(grad_r), _lib.ptr(grad_f),
+                    _lib.ptr(work), nt - 1, 1, _lib.ZERO_STATE | _lib.FINALIZE, _stream()))
+            else:
+                seg = ctx.seg
+                fwork = torch.empty(lay.work_forward_elems, device=dev, dtype=torch.float32)
+                snap = torch.empty((seg, ns, n0, lay.gp), device=dev, dtype=torch.float32)
+                state_elems = 2 * lay.field_elems
+                starts = list(range(0, nt, seg))
+                first = True
+                for si in reversed(range(len(starts))):
+                    b, e = starts[si], min(starts[si] + seg, nt)
+                    # snapshots G^b..G^{e-1} serve adjoint steps k = e .. b+1
+                    k_hi, k_lo = min(e, nt - 1), b + 1
+                    if k_hi < k_lo:
+                        continue
+                    if b == 0:
+                        fflags = _lib.ZERO_STATE
+                    else:
+                        fwork[:state_elems].copy_(ctx.ckpt[si - 1])
+                        fflags = 0
+                    _lib.check(lib.mifwi_acoustic_forward(
+                        plan.handle, _lib.ptr(r_p), _lib.ptr(q0_d), _lib.ptr(q1_p), _lib.ptr(f_d),
+                        _lib.ptr(geom.src_cell), _lib.ptr(geom.src_w), _lib.ptr(geom.rec_cell),
+                        _lib.ptr(geom.rec_w), None, _lib.ptr(snap), _lib.ptr(fwork), b, e, fflags,
+                        _stream()))
+                    flags = (_lib.ZERO_STATE if first else 0) | (_lib.FINALIZE if b == 0 else 0)
+                    first = False
+                    _lib.check(lib.mifwi_acoustic_backward(
+                        *common, _lib.ptr(snap), b, _lib.ptr(grad_r), _lib.ptr(grad_f),
+                        _lib.ptr(work), k_hi, k_lo, flags, _stream()))
+            plan.close()
+            ctx.snap = None
+            ctx.ckpt = None
+        return (grad_r[:, :n1].contiguous(), grad_f, None, None, None, None, None, None, None)
+
+
+def propagate(r, f, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
+              shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET):
+    """Run the acoustic propagator (differentiable w.r.t. ``r`` and ``f``).
+
+    r   [n0,n1]  = vp^2 dt^2 / h^2 on the computational (already padded) grid
+    f   [nt,nshot,nsrc] source amplitudes (the injected term is  w * f[n] * r[cell])
+    q0  [n0], q1 [n1]  separable damping,  q = damp h^2 / (2 dt)
+    src_cell/src_w [nshot,nsrc,ntap], rec_cell/rec_w [nshot,nrec,ntap]  (cell = i0*n1+i1)
+    returns rec [nt,nshot,nrec] with rec[n] sampled from u^n.
+    """
+    _require_cuda(r, "r")
+    geom = _Geometry(src_cell, src_w, rec_cell, rec_w, r.device)
+    f = f.to(device=r.device)
+    return _AcousticFn.apply(r, f, q0, q1, geom, float(c0), float(c1), int(shots_per_group),
+                             int(snapshot_budget))

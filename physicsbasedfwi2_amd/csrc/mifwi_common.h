@@ -1,0 +1,49 @@
+// Shared host-side plumbing of libmifwi (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/mifwi.h"
+
+namespace mifwi {
+
+inline char *err_buf()
+{
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+inline int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define MIFWI_HIP_TRY(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return ::mifwi::fail(MIFWI_EHIP, "%s failed: %s (%s:%d)", #expr,             \
+                                 hipGetErrorString(e__), __FILE__, __LINE__);            \
+    } while (0)
+
+inline int check_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MIFWI_ENODEVICE, "no HIP device visible (libmifwi has no CPU fallback)");
+    if (device < 0 || device >= n)
+        return fail(MIFWI_ENODEVICE, "device %d out of range (0..%d)", device, n - 1);
+    return MIFWI_OK;
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace mifwi

@@ -1,0 +1,39 @@
+"""Shot-parallel layer: one process per GPU, shots partitioned across ranks, ONE collective per
+gradient evaluation (all-reduce of the concatenated model gradient + scalar loss over
+RCCL/xGMI; ``gloo`` in the CPU tests).
+
+Shots are independent in every ``prop()`` of the reference (they are looped / batched and their
+gradients summed: seisgan/fwi/layers.py:169-183, models/networks.py:5454-5464; DENISE sums over
+shots internally), so there is no halo exchange and no domain decomposition.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def shot_partition(nshots, rank, world):
+    """Contiguous block of the (already shuffled) shot list owned by `rank`:
+    shots[r*ceil(S/R) : (r+1)*ceil(S/R)].  Trailing ranks may own fewer (or no) shots."""
+    per = int(math.ceil(nshots / float(world)))
+    lo = min(rank * per, nshots)
+    hi = min(lo + per, nshots)
+    return lo, hi
+
+
+def all_reduce_gradient(grads, loss=None, group=None):
+    """Sum per-rank partial gradients (list of tensors, any shapes) and the partial loss with a
+    single all_reduce(SUM) on one flat fp32 buffer [sum(numel) + 1].  In place; returns
+    (grads, loss)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return grads, loss
+    dev = grads[0].device
+    loss_t = torch.as_tensor(0.0 if loss is None else loss, dtype=torch.float32, device=dev)
+    flat = torch.cat([g.reshape(-1).float() for g in grads] + [loss_t.reshape(1)])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+    return grads, flat[off]

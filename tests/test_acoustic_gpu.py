@@ -1,0 +1,168 @@
+"""HIP acoustic propagator vs the CPU oracle (fp32) on identical seeded inputs.
+
+Tolerances (fp32): receiver traces and snapshots use the same fmaf chain as the oracle and
+are expected to agree to rounding of the last bit (asserted: rel-L2 <= 1e-6); gradients sum
+products over time and shots in a different order: rel-L2 <= 2e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from cases import acoustic_case, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_TRACE = 1e-6
+TOL_GRAD = 2e-5
+
+
+def _run_hip(case, gs=0, budget=None, need_f=True):
+    from physicsbasedfwi2_amd import acoustic
+    dev = torch.device("cuda:0")
+    r = torch.tensor(case["r"], dtype=torch.float32, device=dev, requires_grad=True)
+    f = torch.tensor(case["f"], dtype=torch.float32, device=dev, requires_grad=need_f)
+    kw = {} if budget is None else {"snapshot_budget": budget}
+    rec = acoustic.propagate(r, f, torch.tensor(case["q0"]), torch.tensor(case["q1"]),
+                             torch.tensor(case["sc"]), torch.tensor(case["sw"]),
+                             torch.tensor(case["rc"]), torch.tensor(case["rw"]),
+                             case["c0"], case["c1"], shots_per_group=gs, **kw)
+    return r, f, rec
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                             # n1 multiple of 4 after padding? (66) no
+    dict(n0=33, n1=47, nb=5, ns=3, nrec=11),            # ragged sizes, tail groups
+    dict(n0=70, n1=300, nb=10, ns=2, nrec=40, nt=60),   # several tiles in x and z (LX=64)
+    dict(ntap=4, ns=2, nsrc=2, nrec=9),                 # bilinear taps, two sources per shot
+    dict(h=(10.0, 15.0), ntap=4),                       # anisotropic spacing
+])
+def test_forward_backward_parity(oracle32, kw):
+    case = acoustic_case(seed=3, **kw)
+    o = oracle32
+    rec_o, G_o = o.acoustic_forward(case["r"], case["q0"], case["q1"], case["f"], case["sc"],
+                                    case["sw"], case["rc"], case["rw"], case["c0"], case["c1"],
+                                    save=True)
+    r, f, rec = _run_hip(case)
+    rec_h = rec.detach().cpu().numpy()
+    assert np.isfinite(rec_h).all()
+    assert np.abs(rec_o).max() > 0
+    assert rel_l2(rec_h, rec_o) <= TOL_TRACE
+    rng = np.random.default_rng(11)
+    g = (rng.standard_normal(rec_o.shape) * np.abs(rec_o).max()).astype(np.float32)
+    rec.backward(torch.tensor(g, device=rec.device))
+    gr_o, gf_o = o.acoustic_backward(case["r"], case["q0"], case["q1"], case["sc"], case["sw"],
+                                     case["rc"], case["rw"], g, G_o, case["c0"], case["c1"])
+    assert rel_l2(r.grad.cpu().numpy(), gr_o) <= TOL_GRAD
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= TOL_GRAD
+
+
+def test_bitwise_traces(oracle32):
+    """Same fmaf chain on both sides: report (and require) exact equality of the traces for the
+    single-tap case."""
+    case = acoustic_case(seed=5, n0=48, n1=64, nb=6, nt=120)
+    rec_o = oracle32.acoustic_forward(case["r"], case["q0"], case["q1"], case["f"], case["sc"],
+                                      case["sw"], case["rc"], case["rw"], case["c0"], case["c1"])
+    _, _, rec = _run_hip(case, need_f=False)
+    diff = np.abs(rec.detach().cpu().numpy() - rec_o).max()
+    print("max |hip - oracle| on traces:", diff)
+    assert diff == 0.0
+
+
+@pytest.mark.parametrize("gs", [2, 3])
+def test_shot_groups(oracle32, gs):
+    case = acoustic_case(seed=7, ns=5, nt=70)
+    o = oracle32
+    rec_o, G_o = o.acoustic_forward(case["r"], case["q0"], case["q1"], case["f"], case["sc"],
+                                    case["sw"], case["rc"], case["rw"], save=True)
+    r, f, rec = _run_hip(case, gs=gs)
+    assert rel_l2(rec.detach().cpu().numpy(), rec_o) <= TOL_TRACE
+    g = np.sign(rec_o).astype(np.float32)
+    rec.backward(torch.tensor(g, device=rec.device))
+    gr_o, gf_o = o.acoustic_backward(case["r"], case["q0"], case["q1"], case["sc"], case["sw"],
+                                     case["rc"], case["rw"], g, G_o)
+    assert rel_l2(r.grad.cpu().numpy(), gr_o) <= TOL_GRAD
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= TOL_GRAD
+
+
+def test_time_checkpointing_matches_resident_snapshots(oracle32):
+    """Tiny snapshot budget forces checkpointed segments + re-propagation; the gradient must
+    not change (same arithmetic, same order)."""
+    case = acoustic_case(seed=9, nt=101, ns=2)
+    r1, f1, rec1 = _run_hip(case)
+    g = torch.sign(rec1.detach())
+    rec1.backward(g)
+    N0, N1 = case["shape"]
+    step_bytes = 4 * 2 * N0 * ((N1 + 3) // 4 * 4)
+    r2, f2, rec2 = _run_hip(case, budget=step_bytes * 2 * 13)     # 13-step segments
+    rec2.backward(g)
+    assert torch.equal(rec1, rec2)
+    assert torch.equal(r1.grad, r2.grad)
+    assert torch.equal(f1.grad, f2.grad)
+
+
+def test_determinism():
+    case = acoustic_case(seed=13, ns=3)
+    outs = []
+    for _ in range(2):
+        r, f, rec = _run_hip(case)
+        rec.backward(torch.ones_like(rec))
+        outs.append((rec.detach().clone(), r.grad.clone(), f.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_zero_residual_zero_gradient():
+    case = acoustic_case(seed=15)
+    r, f, rec = _run_hip(case)
+    rec.backward(torch.zeros_like(rec))
+    assert float(r.grad.abs().max()) == 0.0
+    assert float(f.grad.abs().max()) == 0.0
+
+
+def test_deepwave_shim_matches_oracle(oracle32):
+    """End-to-end through the deepwave-shaped API (metres, seconds, m/s), including the
+    replicate-pad, the vp -> r chain rule and the L1 trace-normalised misfit of
+    models/networks.py:5467-5476."""
+    import physicsbasedfwi2_amd.compat.deepwave as deepwave
+    from oracle import helpers as H
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(21)
+    nz, nx, dx, dt, nt, P = 31, 52, 10.0, 0.001, 150, 12
+    vp_np = (1500.0 + 2000.0 * rng.random((nz, nx))).astype(np.float32)
+    ns, nr = 3, 20
+    x_s = torch.zeros(ns, 1, 2)
+    x_s[:, 0, 1] = torch.linspace(0, (nx - 1) * dx, ns)
+    x_r = torch.zeros(ns, nr, 2)
+    x_r[:, :, 1] = (torch.arange(nr).float() * 25.0)[None, :]
+    wav = deepwave.wavelets.ricker(12.0, nt, dt, 1 / 12.0).reshape(-1, 1, 1).repeat(1, ns, 1)
+    vp = torch.tensor(vp_np, device=dev, requires_grad=True)
+    prop = deepwave.scalar.Propagator({"vp": vp}, dx, pml_width=P)
+    rec = prop(wav.to(dev), x_s.to(dev), x_r.to(dev), dt)
+    obs = torch.tensor(rng.standard_normal((nt, ns, nr)).astype(np.float32), device=dev)
+    pmax, _ = rec.abs().max(dim=0, keepdim=True)
+    loss = torch.nn.L1Loss()(rec / (pmax + 1e-10), obs)
+    loss.backward()
+    # oracle composition in numpy/torch-CPU
+    vpt = torch.tensor(vp_np, requires_grad=True)
+    vpp = torch.nn.functional.pad(vpt[None, None], (P, P, P, P), mode="replicate")[0, 0]
+    r_t = (vpp * (dt / dx)) ** 2
+    N0, N1 = r_t.shape
+    q0 = H.damp_profile_1d(N0, P, dx) * dx * dx / (2 * dt)
+    q1 = H.damp_profile_1d(N1, P, dx) * dx * dx / (2 * dt)
+    sc, sw = H.cell_taps(np.trunc(x_s[..., 0].numpy() / dx).astype(int) + P,
+                         np.trunc(x_s[..., 1].numpy() / dx).astype(int) + P, N1)
+    rc, rw = H.cell_taps(np.trunc(x_r[..., 0].numpy() / dx).astype(int) + P,
+                         np.trunc(x_r[..., 1].numpy() / dx).astype(int) + P, N1)
+    f_np = (wav.numpy() * dx * dx).astype(np.float32)
+    r_np = r_t.detach().numpy()
+    rec_o, G_o = oracle32.acoustic_forward(r_np, q0, q1, f_np, sc, sw, rc, rw, save=True)
+    assert rel_l2(rec.detach().cpu().numpy(), rec_o) <= 1e-5
+    rec_ot = torch.tensor(rec_o, requires_grad=True)
+    pm, _ = rec_ot.abs().max(dim=0, keepdim=True)
+    loss_o = torch.nn.L1Loss()(rec_ot / (pm + 1e-10), obs.cpu())
+    loss_o.backward()
+    gr_o, _ = oracle32.acoustic_backward(r_np, q0, q1, sc, sw, rc, rw, rec_ot.grad.numpy(), G_o,
+                                         want_grad_f=False)
+    r_t.backward(torch.tensor(gr_o))
+    assert abs(float(loss) - float(loss_o)) <= 1e-5 * abs(float(loss_o))
+    assert rel_l2(vp.grad.cpu().numpy(), vpt.grad.numpy()) <= 1e-4
