@@ -21,10 +21,11 @@
 // -ffp-contract=off) so wavefields can be compared bitwise.
 #include "mifwi_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int RZ = 4;            // rows marched per thread
 constexpr float K0 = -2.5f;
 constexpr float K1 = (float)(4.0 / 3.0);
 constexpr float K2 = (float)(-1.0 / 12.0);
@@ -88,7 +89,7 @@ __device__ void sample_points(const AcParams &p)
     }
 }
 
-template <int LX, bool SAVE, bool IMAGE>
+template <int LX, int RZ, bool SAVE, bool IMAGE>
 __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
 {
     constexpr int LZ = kThreads / LX;
@@ -300,29 +301,46 @@ __global__ void ac_finalize(const float *acc, int ngroups, int n0, int n1, int g
 struct mifwi_acoustic_plan {
     mifwi_acoustic_desc d;
     int device;
-    int ng, gp, pitch, lx, gs, ngroups;
+    int ng, gp, pitch, lx, rz, gs, ngroups;
     long long shot_stride, field_elems, coef_elems;
 };
 
 namespace {
+
+template <int LX, bool SAVE, bool IMAGE>
+void launch_rz(const mifwi_acoustic_plan *pl, dim3 grid, const AcParams &q, hipStream_t st)
+{
+    dim3 block(kThreads);
+    switch (pl->rz) {
+        case 8: hipLaunchKernelGGL((ac_step<LX, 8, SAVE, IMAGE>), grid, block, 0, st, q); break;
+        case 2: hipLaunchKernelGGL((ac_step<LX, 2, SAVE, IMAGE>), grid, block, 0, st, q); break;
+        default: hipLaunchKernelGGL((ac_step<LX, 4, SAVE, IMAGE>), grid, block, 0, st, q); break;
+    }
+}
 
 template <bool SAVE, bool IMAGE>
 void launch_step(const mifwi_acoustic_plan *pl, const AcParams &p, hipStream_t st)
 {
     const int lz = kThreads / pl->lx;
     const int tiles_x = mifwi::ceil_div(pl->ng, pl->lx);
-    const int tiles_z = mifwi::ceil_div(pl->d.n0, lz * RZ);
+    const int tiles_z = mifwi::ceil_div(pl->d.n0, lz * pl->rz);
     AcParams q = p;
     q.tiles_z = tiles_z;
     int extra = 0;
     if (p.smp_out != nullptr && p.nsmp > 0)
         extra = mifwi::ceil_div(mifwi::ceil_div(pl->gs * p.nsmp, kThreads), tiles_x);
-    dim3 grid(tiles_x, tiles_z + extra, pl->ngroups), block(kThreads);
+    dim3 grid(tiles_x, tiles_z + extra, pl->ngroups);
     switch (pl->lx) {
-        case 64: hipLaunchKernelGGL((ac_step<64, SAVE, IMAGE>), grid, block, 0, st, q); break;
-        case 32: hipLaunchKernelGGL((ac_step<32, SAVE, IMAGE>), grid, block, 0, st, q); break;
-        default: hipLaunchKernelGGL((ac_step<16, SAVE, IMAGE>), grid, block, 0, st, q); break;
+        case 64: launch_rz<64, SAVE, IMAGE>(pl, grid, q, st); break;
+        case 32: launch_rz<32, SAVE, IMAGE>(pl, grid, q, st); break;
+        default: launch_rz<16, SAVE, IMAGE>(pl, grid, q, st); break;
     }
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
 }
 
 AcParams base_params(const mifwi_acoustic_plan *pl, const float *r, const float *q0,
@@ -373,10 +391,15 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
     pl->lx = 16;
     for (int cand : {64, 32}) {
         const int padded = mifwi::ceil_div(pl->ng, cand) * cand;
-        if (padded * 10 <= pl->ng * 11) { pl->lx = cand; break; }
+        if (padded * 10 <= pl->ng * 12) { pl->lx = cand; break; }
     }
+    pl->rz = 2;
+    // tuning overrides (benchmarks only)
+    { const int v = env_int("MIFWI_AC_LX", 0); if (v == 16 || v == 32 || v == 64) pl->lx = v; }
+    { const int v = env_int("MIFWI_AC_RZ", 0); if (v == 2 || v == 4 || v == 8) pl->rz = v; }
     int gs = d->shots_per_group;
-    if (gs <= 0) gs = 1;
+    if (gs <= 0) gs = env_int("MIFWI_AC_GS", 2);
+    if (gs <= 0) gs = 2;
     if (gs > d->nshot) gs = d->nshot;
     pl->gs = gs;
     pl->ngroups = mifwi::ceil_div(d->nshot, gs);
@@ -513,7 +536,7 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
             const int extra =
                 mifwi::ceil_div(mifwi::ceil_div(pl->gs * s.nsmp, kThreads), tiles_x);
             dim3 grid(tiles_x, extra, pl->ngroups), block(kThreads);
-            hipLaunchKernelGGL((ac_step<16, false, false>), grid, block, 0, st, s);
+            hipLaunchKernelGGL((ac_step<16, 4, false, false>), grid, block, 0, st, s);
         }
         const long long ncoef = pl->coef_elems;
         hipLaunchKernelGGL(ac_finalize, dim3((unsigned)((ncoef + 255) / 256)), dim3(256), 0, st,
