@@ -121,6 +121,68 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *plan, const float *r, const flo
                             float *work, int32_t k_hi, int32_t k_lo, int32_t flags,
                             void *stream);
 
+/* ======================================================================================
+ * 2-D P-SV ELASTIC velocity-stress propagator (forward + exact discrete adjoint)
+ *
+ * Replaces the DENISE-Black-Edition runs behind pyapi_denise:
+ *   d.forward(model, src, rec) / d.grad(model, src, rec)   models/networks.py:7787, 9853-9877
+ *   (parameter block 7698-7731 / 9790-9833; gradient read-back 7799-7802)
+ *
+ * Scheme: standard staggered grid, 4th-order space, leapfrog time,
+ * C-PML memory variables on every derivative (layer inside the grid, pml_width nodes),
+ * explosive source into sxx/szz, receivers sample vx/vz after the velocity update.
+ *   mat [5][nz][gp] = lambda dt/h, (lambda+2mu) dt/h, mu_xz dt/h, dt/(h rho_x), dt/(h rho_z)
+ *                     (staggered averages are formed by the host; columns >= nx must be 0)
+ *   pz [6][nz], px [6][gp] : C-PML a, b, 1/kappa at integer then at half nodes
+ *                     (a = b = 0, 1/kappa = 1 outside the layer and in columns >= nx)
+ * ==================================================================================== */
+typedef struct {
+    int32_t nz, nx;          /* grid, z = depth is the slow axis                              */
+    int32_t nt, nshot, nsrc, nrec, ntap;
+    int32_t pml_width;       /* C-PML nodes per side (0 = none); profiles may still be zero
+                                on a side (e.g. free surface)                                 */
+    int32_t free_surface;    /* reserved, must be 0                                           */
+    int32_t shots_per_group; /* adjoint: shots sharing one gradient accumulator; 0 = auto     */
+} mifwi_elastic_desc;
+
+typedef struct {
+    int32_t gp, pitch, ngroups, shots_per_group;
+    int64_t coef_elems;           /* nz*gp: one material / snapshot / gradient plane           */
+    int64_t state_elems;          /* forward state (5 fields + memory variables) at the start
+                                     of `work`: what a time checkpoint copies                  */
+    int64_t work_forward_elems;
+    int64_t work_backward_elems;
+} mifwi_elastic_layout;
+
+typedef struct mifwi_elastic_plan mifwi_elastic_plan;
+
+int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device,
+                              const mifwi_elastic_desc *desc);
+int mifwi_elastic_plan_destroy(mifwi_elastic_plan *plan);
+int mifwi_elastic_plan_layout(const mifwi_elastic_plan *plan, mifwi_elastic_layout *out);
+
+/* Steps n = n_begin .. n_end-1.
+ *   f [nt][nshot][nsrc] (added to sxx and szz, pre-scaled by the host)
+ *   rec_vx, rec_vz [nt][nshot][nrec] or both NULL
+ *   snap NULL or [n_end-n_begin][nshot][5][nz][gp]: the five PML-filtered derivative sums the
+ *        material gradient needs (exx', ezz', exz', and the two force terms)                 */
+int mifwi_elastic_forward(mifwi_elastic_plan *plan, const float *mat, const float *pz,
+                          const float *px, const float *f, const int32_t *src_cell,
+                          const float *src_w, const int32_t *rec_cell, const float *rec_w,
+                          float *rec_vx, float *rec_vz, float *snap, float *work, int32_t n_begin,
+                          int32_t n_end, int32_t flags, void *stream);
+
+/* Adjoint steps n = n_hi down to n_lo (full run: nt-1 .. 0, ZERO_STATE|FINALIZE).
+ *   g_vx, g_vz [nt][nshot][nrec] = dJ/d rec;  snapshot of step n at snap+(n-snap_first)*5*nshot*nz*gp
+ *   grad_mat [5][nz][gp] (on FINALIZE): dJ/d mat summed over the plan's shots
+ *   grad_f NULL or [nt][nshot][nsrc]                                                        */
+int mifwi_elastic_backward(mifwi_elastic_plan *plan, const float *mat, const float *pz,
+                           const float *px, const int32_t *src_cell, const float *src_w,
+                           const int32_t *rec_cell, const float *rec_w, const float *g_vx,
+                           const float *g_vz, const float *snap, int32_t snap_first,
+                           float *grad_mat, float *grad_f, float *work, int32_t n_hi, int32_t n_lo,
+                           int32_t flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,3 +130,65 @@ def acoustic_coeffs(m_pad, damp0, damp1, s, spacing):
     q0 = damp0 * h * h / (2 * s)
     q1 = damp1 * h * h / (2 * s)
     return r, q0, q1, (h / spacing[0]) ** 2, (h / spacing[1]) ** 2
+
+
+# ================================================================================================
+# Elastic (DENISE-shaped) helpers.  DENISE is not in the reference tree; the formulas are the
+# published ones (Komatitsch & Martin 2007 C-PML; Levander 1988 staggered grid), restated.
+# ================================================================================================
+def cpml_profiles(n, fw, h, dt, vpml, fpml, npower=4.0, kmax=1.0, lo=True, hi=True,
+                  rcoef=0.0008):
+    """1-D C-PML tables [6][n]: a, b, 1/kappa at integer nodes x=i*h, then at half nodes
+    x=(i+1/2)*h.  The layer is INSIDE the grid (DENISE convention), `fw` nodes wide:
+    low side  abscissa = (fw - x/h) h   for x/h < fw,
+    high side abscissa = (x/h - (n-1-fw)) h for x/h > n-1-fw.
+    d = d0 (abscissa/L)^N, d0 = -(N+1) vpml ln(rcoef) / (2L), L = fw*h;
+    kappa = 1 + (kmax-1)(abscissa/L)^N; alpha = pi*fpml*(1 - abscissa/L);
+    b = exp(-(d/kappa + alpha) dt); a = d (b-1) / (kappa (d + kappa alpha))."""
+    out = np.zeros((6, n), dtype=np.float64)
+    out[2] = 1.0
+    out[5] = 1.0
+    if fw <= 0:
+        return out
+    L = fw * h
+    d0 = -(npower + 1.0) * vpml * np.log(rcoef) / (2.0 * L)
+    amax = np.pi * fpml
+    for half in (0, 1):
+        pos = np.arange(n, dtype=np.float64) + 0.5 * half
+        absc = np.zeros(n)
+        if lo:
+            absc = np.maximum(absc, (fw - pos) * h)
+        if hi:
+            absc = np.maximum(absc, (pos - (n - 1 - fw)) * h)
+        norm = np.clip(absc / L, 0.0, None)
+        inside = norm > 0
+        d = d0 * norm ** npower
+        kappa = 1.0 + (kmax - 1.0) * norm ** npower
+        alpha = amax * (1.0 - np.minimum(norm, 1.0))
+        b = np.exp(-(d / kappa + alpha) * dt)
+        den = kappa * (d + kappa * alpha)
+        a = np.where(den > 1e-30, d * (b - 1.0) / np.where(den > 1e-30, den, 1.0), 0.0)
+        out[3 * half + 0] = np.where(inside, a, 0.0)
+        out[3 * half + 1] = np.where(inside, b, 0.0)
+        out[3 * half + 2] = np.where(inside, 1.0 / kappa, 1.0)
+    return out
+
+
+def elastic_materials(vp, vs, rho, dt, h):
+    """Staggered, dt/h-scaled material arrays [5][nz][nx] = Ls, Ms, mus, bxs, bzs (numpy)."""
+    vp, vs, rho = (np.asarray(a, dtype=np.float64) for a in (vp, vs, rho))
+    mu = rho * vs ** 2
+    lam = rho * vp ** 2 - 2.0 * mu
+    s = dt / h
+
+    def sh(a, dz, dx):   # value at (j+dz, i+dx), edge replicated
+        return np.pad(a, ((0, dz), (0, dx)), "edge")[dz:, dx:]
+    rx = 0.5 * (rho + sh(rho, 0, 1))
+    rz = 0.5 * (rho + sh(rho, 1, 0))
+    m4 = [mu, sh(mu, 0, 1), sh(mu, 1, 0), sh(mu, 1, 1)]
+    anyzero = np.zeros(mu.shape, dtype=bool)
+    for m in m4:
+        anyzero |= (m == 0)
+    with np.errstate(divide="ignore"):
+        muxz = np.where(anyzero, 0.0, 4.0 / sum(1.0 / np.where(m == 0, 1.0, m) for m in m4))
+    return np.stack([lam * s, (lam + 2 * mu) * s, muxz * s, s / rx, s / rz])

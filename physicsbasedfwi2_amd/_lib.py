@@ -33,6 +33,20 @@ class AcousticLayout(ctypes.Structure):
                 ("work_backward_elems", ctypes.c_int64)]
 
 
+class ElasticDesc(ctypes.Structure):
+    _fields_ = [("nz", ctypes.c_int32), ("nx", ctypes.c_int32), ("nt", ctypes.c_int32),
+                ("nshot", ctypes.c_int32), ("nsrc", ctypes.c_int32), ("nrec", ctypes.c_int32),
+                ("ntap", ctypes.c_int32), ("pml_width", ctypes.c_int32),
+                ("free_surface", ctypes.c_int32), ("shots_per_group", ctypes.c_int32)]
+
+
+class ElasticLayout(ctypes.Structure):
+    _fields_ = [("gp", ctypes.c_int32), ("pitch", ctypes.c_int32), ("ngroups", ctypes.c_int32),
+                ("shots_per_group", ctypes.c_int32), ("coef_elems", ctypes.c_int64),
+                ("state_elems", ctypes.c_int64), ("work_forward_elems", ctypes.c_int64),
+                ("work_backward_elems", ctypes.c_int64)]
+
+
 _P = ctypes.c_void_p
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against
@@ -48,6 +62,13 @@ SIGNATURES = {
     "mifwi_acoustic_forward": (ctypes.c_int, [_P] * 12 + [ctypes.c_int32] * 3 + [_P]),
     "mifwi_acoustic_backward": (ctypes.c_int, [_P] * 10 + [ctypes.c_int32] + [_P] * 3 +
                                 [ctypes.c_int32] * 3 + [_P]),
+    "mifwi_elastic_plan_create": (ctypes.c_int, [ctypes.POINTER(_P), ctypes.c_int,
+                                                 ctypes.POINTER(ElasticDesc)]),
+    "mifwi_elastic_plan_destroy": (ctypes.c_int, [_P]),
+    "mifwi_elastic_plan_layout": (ctypes.c_int, [_P, ctypes.POINTER(ElasticLayout)]),
+    "mifwi_elastic_forward": (ctypes.c_int, [_P] * 13 + [ctypes.c_int32] * 3 + [_P]),
+    "mifwi_elastic_backward": (ctypes.c_int, [_P] * 11 + [ctypes.c_int32] + [_P] * 3 +
+                               [ctypes.c_int32] * 3 + [_P]),
 }
 
 _lib = None

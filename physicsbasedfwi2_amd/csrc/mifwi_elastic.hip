@@ -1,0 +1,961 @@
+// 2-D P-SV elastic velocity-stress propagator for gfx950 (MI355X): forward, snapshot save and
+// the exact discrete adjoint with material-gradient accumulation.  Memory-bound staggered-grid
+// stencil (4th order space, leapfrog time, C-PML memory variables); MFMA unused.
+//
+// Replaces (reference tree): the DENISE-Black-Edition runs behind pyapi_denise's
+// `d.forward(...)` / `d.grad(...)` as called at models/networks.py:7787, 9853-9877 (mpirun of 30
+// MPI ranks + files on disk in the reference).
+//
+// Forward: two launches per time step (V: velocities from stresses, S: stresses from the new
+// velocities).  A thread owns 4 consecutive cells (16-B lane accesses) and marches RZ rows with
+// the z windows in registers; x neighbours come from 8-B halo loads that hit the lines the
+// neighbouring lanes fetch.  C-PML memory variables live in compact strips (group-aligned in x,
+// row-aligned in z) so that interior tiles never touch them.  Source injection (LDS image of
+// the tile, only where the shot's bounding box intersects it) and receiver sampling (extra
+// workgroups) ride in the S launch.
+// Adjoint: two launches per step (S^T then V^T).  The transposed C-PML acts on the
+// material-scaled adjoint fields BEFORE the spatial derivative, so each workgroup first
+// evaluates those four per-cell quantities on its tile + 2-cell halo into LDS, then applies the
+// stencils from LDS.  All five material-gradient accumulators are updated in the S^T launch and
+// stay in registers across the shots of a group (one read-modify-write per group, not per shot).
+// Arithmetic = the explicit fmaf chain of oracle/elastic.c (build with -ffp-contract=off).
+#include "mifwi_common.h"
+
+#include <cstdlib>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr float C1 = (float)(9.0 / 8.0);
+constexpr float C2 = (float)(-1.0 / 24.0);
+
+enum { F_VX = 0, F_VZ = 1, F_SXX = 2, F_SZZ = 3, F_SXZ = 4 };
+enum { M_L = 0, M_M = 1, M_MU = 2, M_BX = 3, M_BZ = 4 };
+enum { PA = 0, PB = 1, PK = 2, PAH = 3, PBH = 4, PKH = 5 };
+// psi index: x strips hold (0: d1 sxx_x @half, 1: d3 sxz_x @int, 2: e1 vx_x @int, 3: e4 vz_x @half)
+//            z strips hold (0: d2 sxz_z @int, 1: d4 szz_z @half, 2: e2 vz_z @int, 3: e3 vx_z @half)
+
+struct ElParams {
+    int nz, nx, ng, gp, pitch;
+    unsigned field_stride;       // (nz+4)*pitch
+    long long shot_stride;       // 5*field_stride
+    int nshot, gs;
+    int W, wl, xr0, wx;          // C-PML strip geometry; W = 0 disables the layer
+    long long psix_shot, psiz_shot;   // floats per shot: 4*nz*wx, 4*2W*gp
+    const float *mat, *pz, *px;
+    float *fields;
+    float *psix, *psiz;          // forward: updated in place; adjoint: read side
+    float *psix_out, *psiz_out;  // adjoint: write side (ping-pong)
+    float *S;                    // snapshot slice of this step [nshot][5][nz][gp]
+    float *acc;                  // [ngroups][5][nz][gp]
+    // injection (S launch: sxx,szz += a ; S^T launch: vx += ax, vz += az)
+    int ninj, ntap_inj;
+    const int *inj_cell;
+    const float *inj_w;
+    const float *inj_amp0, *inj_amp1;     // [nshot][ninj] of this step (amp1 only in S^T)
+    const int *inj_bbox;
+    // sampling (S launch: vx, vz ; S^T launch: sxx+szz)
+    int nsmp, ntap_smp;
+    const int *smp_cell;
+    const float *smp_w;
+    float *smp_out0, *smp_out1;
+    int tiles_z;
+};
+
+__device__ __forceinline__ float comp(const float4 &v, int c)
+{
+    return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
+}
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+__device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float dfw(float fm1, float f0, float f1, float f2)   // Dp at "0"
+{
+    return fmaf(C1, f1 - f0, C2 * (f2 - fm1));
+}
+__device__ __forceinline__ float dbw(float fm2, float fm1, float f0, float f1)  // Dm at "0"
+{
+    return fmaf(C1, f0 - fm1, C2 * (f1 - fm2));
+}
+// forward C-PML: psi <- b psi + a d ; returns d*ik + psi
+__device__ __forceinline__ float pml(float &psi, float a, float b, float ik, float d)
+{
+    psi = fmaf(b, psi, a * d);
+    return fmaf(d, ik, psi);
+}
+// transposed C-PML: P = psib + db ; returns ik*db + a*P ; psib <- b*P
+__device__ __forceinline__ float pmlT(float psib, float a, float b, float ik, float db,
+                                      float &psib_new)
+{
+    const float P = psib + db;
+    psib_new = b * P;
+    return fmaf(ik, db, a * P);
+}
+
+// x-strip column offset of group g (or -1)
+__device__ __forceinline__ int xstrip(const ElParams &p, int g)
+{
+    if (p.W == 0) return -1;
+    const int c0 = 4 * g;
+    if (c0 < p.wl) return c0;
+    if (c0 >= p.xr0) return p.wl + (c0 - p.xr0);
+    return -1;
+}
+// z-strip row index of row j (or -1)
+__device__ __forceinline__ int zstrip(const ElParams &p, int j)
+{
+    if (p.W == 0) return -1;
+    if (j < p.W) return j;
+    if (j >= p.nz - p.W) return j - (p.nz - 2 * p.W);
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampling workgroups.  mode 0: out0 = sum w vx, out1 = sum w vz ; mode 1: out0 = sum w (sxx+szz)
+template <int MODE>
+__device__ void sample_points(const ElParams &p)
+{
+    if (p.smp_out0 == nullptr) return;
+    const int nrb = (int)(gridDim.y - p.tiles_z) * (int)gridDim.x;
+    const int rb = ((int)blockIdx.y - p.tiles_z) * (int)gridDim.x + (int)blockIdx.x;
+    const int total = p.gs * p.nsmp;
+    for (int e = rb * kThreads + (int)threadIdx.x; e < total; e += nrb * kThreads) {
+        const int si = e / p.nsmp, ip = e - si * p.nsmp;
+        const int s = (int)blockIdx.z * p.gs + si;
+        if (s >= p.nshot) continue;
+        const float *fl = p.fields + (long long)s * p.shot_stride;
+        float a0 = 0.f, a1 = 0.f;
+        for (int t = 0; t < p.ntap_smp; ++t) {
+            const long long ee = ((long long)s * p.nsmp + ip) * p.ntap_smp + t;
+            const int cell = p.smp_cell[ee];
+            if (cell < 0) continue;
+            const int j = cell / p.nx, i = cell - j * p.nx;
+            const unsigned off = (unsigned)(j + 2) * p.pitch + 4 + i;
+            const float w = p.smp_w[ee];
+            if (MODE == 0) {
+                a0 = fmaf(w, fl[F_VX * p.field_stride + off], a0);
+                a1 = fmaf(w, fl[F_VZ * p.field_stride + off], a1);
+            } else {
+                a0 = fmaf(w, fl[F_SXX * p.field_stride + off] + fl[F_SZZ * p.field_stride + off], a0);
+            }
+        }
+        p.smp_out0[(long long)s * p.nsmp + ip] = a0;
+        if (MODE == 0) p.smp_out1[(long long)s * p.nsmp + ip] = a1;
+    }
+}
+
+// stage the shot's injection amplitudes that fall into this tile (block-uniform decision)
+template <int TZ, int TX, int NCOMP>
+__device__ bool stage_injection(const ElParams &p, int s, int tile_j, int tile_i, float *inj)
+{
+    if (p.ninj <= 0) return false;
+    const int b0 = p.inj_bbox[4 * s + 0], b1 = p.inj_bbox[4 * s + 1];
+    const int b2 = p.inj_bbox[4 * s + 2], b3 = p.inj_bbox[4 * s + 3];
+    const bool has = (b0 < tile_j + TZ) && (b1 >= tile_j) && (b2 < tile_i + TX) && (b3 >= tile_i);
+    if (!has) return false;
+    for (int e = (int)threadIdx.x; e < NCOMP * TZ * TX; e += kThreads) inj[e] = 0.f;
+    __syncthreads();
+    const int total = p.ninj * p.ntap_inj;
+    for (int e = (int)threadIdx.x; e < total; e += kThreads) {
+        const long long ee = (long long)s * total + e;
+        const int cell = p.inj_cell[ee];
+        if (cell < 0) continue;
+        const int j = cell / p.nx, i = cell - j * p.nx;
+        const int tj = j - tile_j, ti = i - tile_i;
+        if (tj >= 0 && tj < TZ && ti >= 0 && ti < TX) {
+            const long long ai = (long long)s * p.ninj + e / p.ntap_inj;
+            const float w = p.inj_w[ee];
+            atomicAdd(&inj[tj * TX + ti], w * p.inj_amp0[ai]);
+            if (NCOMP == 2) atomicAdd(&inj[TZ * TX + tj * TX + ti], w * p.inj_amp1[ai]);
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+// ================================================================================================
+// forward V launch:  vx += bxs (Dp_x sxx' + Dm_z sxz'),  vz += bzs (Dm_x sxz' + Dp_z szz')
+// ================================================================================================
+template <int LX, int RZ, bool SAVE>
+__global__ __launch_bounds__(kThreads) void el_step_v(const ElParams p)
+{
+    constexpr int LZ = kThreads / LX;
+    const int lx = (int)threadIdx.x % LX, lz = (int)threadIdx.x / LX;
+    const int g = (int)blockIdx.x * LX + lx;
+    const int j0 = ((int)blockIdx.y * LZ + lz) * RZ;
+    if (g >= p.ng || j0 >= p.nz) return;
+    const int s = (int)blockIdx.z;
+    const unsigned fs = p.field_stride;
+    float *fl = p.fields + (long long)s * p.shot_stride;
+    const float *sxx = fl + F_SXX * fs, *szz = fl + F_SZZ * fs, *sxz = fl + F_SXZ * fs;
+    float *vx = fl + F_VX * fs, *vz = fl + F_VZ * fs;
+    const unsigned col = 4 + 4 * g;
+    const unsigned ncell = (unsigned)p.nz * p.gp;
+    const int xs_off = xstrip(p, g);
+    float4 pxa, pxb, pxk, pxah, pxbh, pxkh;
+    if (xs_off >= 0) {
+        pxa = ld4(p.px + PA * p.gp + 4 * g); pxb = ld4(p.px + PB * p.gp + 4 * g);
+        pxk = ld4(p.px + PK * p.gp + 4 * g); pxah = ld4(p.px + PAH * p.gp + 4 * g);
+        pxbh = ld4(p.px + PBH * p.gp + 4 * g); pxkh = ld4(p.px + PKH * p.gp + 4 * g);
+    }
+    // windows: sxz rows j-2..j+1 (a0..a3), szz rows j-1..j+2 (b0..b3)
+    float4 a0, a1, a2, a3, b0, b1, b2, b3;
+    {
+        const unsigned o = (unsigned)(j0 + 2) * p.pitch + col;     // row j0
+        a0 = ld4(sxz + o - 2 * p.pitch); a1 = ld4(sxz + o - p.pitch); a2 = ld4(sxz + o);
+        b0 = ld4(szz + o - p.pitch); b1 = ld4(szz + o); b2 = ld4(szz + o + p.pitch);
+    }
+#pragma unroll
+    for (int rz = 0; rz < RZ; ++rz) {
+        const int j = j0 + rz;
+        if (j < p.nz) {
+            const unsigned o = (unsigned)(j + 2) * p.pitch + col;
+            const unsigned cc = (unsigned)j * p.gp + 4 * g;
+            a3 = ld4(sxz + o + p.pitch);
+            b3 = ld4(szz + o + 2 * p.pitch);
+            const float4 cxx = ld4(sxx + o);
+            const float2 Lxx = ld2(sxx + o - 2), Rxx = ld2(sxx + o + 4);
+            const float2 Lxz = ld2(sxz + o - 2), Rxz = ld2(sxz + o + 4);
+            float4 vxv = ld4(vx + o), vzv = ld4(vz + o);
+            const float4 bxs = ld4(p.mat + M_BX * ncell + cc), bzs = ld4(p.mat + M_BZ * ncell + cc);
+            const float xx[8] = {Lxx.x, Lxx.y, cxx.x, cxx.y, cxx.z, cxx.w, Rxx.x, Rxx.y};
+            const float xz[8] = {Lxz.x, Lxz.y, a2.x, a2.y, a2.z, a2.w, Rxz.x, Rxz.y};
+            float d1[4], d2[4], d3[4], d4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                d1[c] = dfw(xx[c + 1], xx[c + 2], xx[c + 3], xx[c + 4]);
+                d2[c] = dbw(comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
+                d3[c] = dbw(xz[c], xz[c + 1], xz[c + 2], xz[c + 3]);
+                d4[c] = dfw(comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
+            }
+            if (xs_off >= 0) {
+                float *q1 = p.psix + (long long)s * p.psix_shot + ((long long)0 * p.nz + j) * p.wx + xs_off;
+                float *q3 = p.psix + (long long)s * p.psix_shot + ((long long)1 * p.nz + j) * p.wx + xs_off;
+                float4 s1 = ld4(q1), s3 = ld4(q3);
+                float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t3[4] = {s3.x, s3.y, s3.z, s3.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    d1[c] = pml(t1[c], comp(pxah, c), comp(pxbh, c), comp(pxkh, c), d1[c]);
+                    d3[c] = pml(t3[c], comp(pxa, c), comp(pxb, c), comp(pxk, c), d3[c]);
+                }
+                st4(q1, make_float4(t1[0], t1[1], t1[2], t1[3]));
+                st4(q3, make_float4(t3[0], t3[1], t3[2], t3[3]));
+            }
+            const int zs = zstrip(p, j);
+            if (zs >= 0) {
+                const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
+                const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
+                float *q2 = p.psiz + (long long)s * p.psiz_shot + ((long long)0 * 2 * p.W + zs) * p.gp + 4 * g;
+                float *q4 = p.psiz + (long long)s * p.psiz_shot + ((long long)1 * 2 * p.W + zs) * p.gp + 4 * g;
+                float4 s2 = ld4(q2), s4 = ld4(q4);
+                float t2[4] = {s2.x, s2.y, s2.z, s2.w}, t4[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    d2[c] = pml(t2[c], za, zb, zk, d2[c]);
+                    d4[c] = pml(t4[c], zah, zbh, zkh, d4[c]);
+                }
+                st4(q2, make_float4(t2[0], t2[1], t2[2], t2[3]));
+                st4(q4, make_float4(t4[0], t4[1], t4[2], t4[3]));
+            }
+            float s4v[4], s5v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { s4v[c] = d1[c] + d2[c]; s5v[c] = d3[c] + d4[c]; }
+            vxv.x = fmaf(bxs.x, s4v[0], vxv.x); vxv.y = fmaf(bxs.y, s4v[1], vxv.y);
+            vxv.z = fmaf(bxs.z, s4v[2], vxv.z); vxv.w = fmaf(bxs.w, s4v[3], vxv.w);
+            vzv.x = fmaf(bzs.x, s5v[0], vzv.x); vzv.y = fmaf(bzs.y, s5v[1], vzv.y);
+            vzv.z = fmaf(bzs.z, s5v[2], vzv.z); vzv.w = fmaf(bzs.w, s5v[3], vzv.w);
+            st4(vx + o, vxv);
+            st4(vz + o, vzv);
+            if (SAVE) {
+                float *Sp = p.S + (long long)s * 5 * ncell + cc;
+                st4(Sp + 3 * (long long)ncell, make_float4(s4v[0], s4v[1], s4v[2], s4v[3]));
+                st4(Sp + 4 * (long long)ncell, make_float4(s5v[0], s5v[1], s5v[2], s5v[3]));
+            }
+            a0 = a1; a1 = a2; a2 = a3;
+            b0 = b1; b1 = b2; b2 = b3;
+        }
+    }
+}
+
+// ================================================================================================
+// forward S launch: stresses from the new velocities + source injection + receiver sampling
+// ================================================================================================
+template <int LX, int RZ, bool SAVE>
+__global__ __launch_bounds__(kThreads) void el_step_s(const ElParams p)
+{
+    constexpr int LZ = kThreads / LX;
+    constexpr int TZ = LZ * RZ, TX = LX * 4;
+    if ((int)blockIdx.y >= p.tiles_z) {
+        sample_points<0>(p);
+        return;
+    }
+    __shared__ float inj[TZ * TX];
+    const int lx = (int)threadIdx.x % LX, lz = (int)threadIdx.x / LX;
+    const int g = (int)blockIdx.x * LX + lx;
+    const int tile_j = (int)blockIdx.y * TZ, tile_i = (int)blockIdx.x * TX;
+    const int j0 = tile_j + lz * RZ;
+    const bool active = (g < p.ng) && (j0 < p.nz);
+    const unsigned fs = p.field_stride;
+    const unsigned col = 4 + 4 * g;
+    const unsigned ncell = (unsigned)p.nz * p.gp;
+    const int xs_off = active ? xstrip(p, g) : -1;
+    float4 pxa, pxb, pxk, pxah, pxbh, pxkh;
+    if (xs_off >= 0) {
+        pxa = ld4(p.px + PA * p.gp + 4 * g); pxb = ld4(p.px + PB * p.gp + 4 * g);
+        pxk = ld4(p.px + PK * p.gp + 4 * g); pxah = ld4(p.px + PAH * p.gp + 4 * g);
+        pxbh = ld4(p.px + PBH * p.gp + 4 * g); pxkh = ld4(p.px + PKH * p.gp + 4 * g);
+    }
+    for (int si = 0; si < p.gs; ++si) {
+        const int s = (int)blockIdx.z * p.gs + si;
+        if (s >= p.nshot) break;
+        const bool has_inj = stage_injection<TZ, TX, 1>(p, s, tile_j, tile_i, inj);
+        if (active) {
+            float *fl = p.fields + (long long)s * p.shot_stride;
+            const float *vx = fl + F_VX * fs, *vz = fl + F_VZ * fs;
+            float *sxx = fl + F_SXX * fs, *szz = fl + F_SZZ * fs, *sxz = fl + F_SXZ * fs;
+            // windows: vz rows j-2..j+1 (a0..a3), vx rows j-1..j+2 (b0..b3)
+            float4 a0, a1, a2, a3, b0, b1, b2, b3;
+            {
+                const unsigned o = (unsigned)(j0 + 2) * p.pitch + col;
+                a0 = ld4(vz + o - 2 * p.pitch); a1 = ld4(vz + o - p.pitch); a2 = ld4(vz + o);
+                b0 = ld4(vx + o - p.pitch); b1 = ld4(vx + o); b2 = ld4(vx + o + p.pitch);
+            }
+#pragma unroll
+            for (int rz = 0; rz < RZ; ++rz) {
+                const int j = j0 + rz;
+                if (j < p.nz) {
+                    const unsigned o = (unsigned)(j + 2) * p.pitch + col;
+                    const unsigned cc = (unsigned)j * p.gp + 4 * g;
+                    a3 = ld4(vz + o + p.pitch);
+                    b3 = ld4(vx + o + 2 * p.pitch);
+                    const float2 Lvx = ld2(vx + o - 2), Rvx = ld2(vx + o + 4);
+                    const float2 Lvz = ld2(vz + o - 2), Rvz = ld2(vz + o + 4);
+                    float4 vxx = ld4(sxx + o), vzz = ld4(szz + o), vxz = ld4(sxz + o);
+                    const float4 Ls = ld4(p.mat + M_L * ncell + cc), Ms = ld4(p.mat + M_M * ncell + cc);
+                    const float4 mus = ld4(p.mat + M_MU * ncell + cc);
+                    const float xv[8] = {Lvx.x, Lvx.y, b1.x, b1.y, b1.z, b1.w, Rvx.x, Rvx.y};
+                    const float zv[8] = {Lvz.x, Lvz.y, a2.x, a2.y, a2.z, a2.w, Rvz.x, Rvz.y};
+                    float e1[4], e2[4], e3[4], e4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        e1[c] = dbw(xv[c], xv[c + 1], xv[c + 2], xv[c + 3]);
+                        e2[c] = dbw(comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
+                        e3[c] = dfw(comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
+                        e4[c] = dfw(zv[c + 1], zv[c + 2], zv[c + 3], zv[c + 4]);
+                    }
+                    if (xs_off >= 0) {
+                        float *q5 = p.psix + (long long)s * p.psix_shot + ((long long)2 * p.nz + j) * p.wx + xs_off;
+                        float *q8 = p.psix + (long long)s * p.psix_shot + ((long long)3 * p.nz + j) * p.wx + xs_off;
+                        float4 s5 = ld4(q5), s8 = ld4(q8);
+                        float t5[4] = {s5.x, s5.y, s5.z, s5.w}, t8[4] = {s8.x, s8.y, s8.z, s8.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            e1[c] = pml(t5[c], comp(pxa, c), comp(pxb, c), comp(pxk, c), e1[c]);
+                            e4[c] = pml(t8[c], comp(pxah, c), comp(pxbh, c), comp(pxkh, c), e4[c]);
+                        }
+                        st4(q5, make_float4(t5[0], t5[1], t5[2], t5[3]));
+                        st4(q8, make_float4(t8[0], t8[1], t8[2], t8[3]));
+                    }
+                    const int zs = zstrip(p, j);
+                    if (zs >= 0) {
+                        const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
+                        const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
+                        float *q6 = p.psiz + (long long)s * p.psiz_shot + ((long long)2 * 2 * p.W + zs) * p.gp + 4 * g;
+                        float *q7 = p.psiz + (long long)s * p.psiz_shot + ((long long)3 * 2 * p.W + zs) * p.gp + 4 * g;
+                        float4 s6 = ld4(q6), s7 = ld4(q7);
+                        float t6[4] = {s6.x, s6.y, s6.z, s6.w}, t7[4] = {s7.x, s7.y, s7.z, s7.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            e2[c] = pml(t6[c], za, zb, zk, e2[c]);
+                            e3[c] = pml(t7[c], zah, zbh, zkh, e3[c]);
+                        }
+                        st4(q6, make_float4(t6[0], t6[1], t6[2], t6[3]));
+                        st4(q7, make_float4(t7[0], t7[1], t7[2], t7[3]));
+                    }
+                    float nxx[4], nzz[4], nxz[4], s3v[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        s3v[c] = e3[c] + e4[c];
+                        nxx[c] = fmaf(comp(Ms, c), e1[c], fmaf(comp(Ls, c), e2[c], comp(vxx, c)));
+                        nzz[c] = fmaf(comp(Ls, c), e1[c], fmaf(comp(Ms, c), e2[c], comp(vzz, c)));
+                        nxz[c] = fmaf(comp(mus, c), s3v[c], comp(vxz, c));
+                        if (has_inj) {
+                            const float a = inj[(j - tile_j) * TX + 4 * lx + c];
+                            nxx[c] += a;
+                            nzz[c] += a;
+                        }
+                    }
+                    st4(sxx + o, make_float4(nxx[0], nxx[1], nxx[2], nxx[3]));
+                    st4(szz + o, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
+                    st4(sxz + o, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
+                    if (SAVE) {
+                        float *Sp = p.S + (long long)s * 5 * ncell + cc;
+                        st4(Sp, make_float4(e1[0], e1[1], e1[2], e1[3]));
+                        st4(Sp + (long long)ncell, make_float4(e2[0], e2[1], e2[2], e2[3]));
+                        st4(Sp + 2 * (long long)ncell, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
+                    }
+                    a0 = a1; a1 = a2; a2 = a3;
+                    b0 = b1; b1 = b2; b2 = b3;
+                }
+            }
+        }
+        if (has_inj) __syncthreads();
+    }
+}
+
+// ================================================================================================
+// adjoint launches.  Tile = TZ x (4*GXO) owned cells, staged on (TZ+4) x 4*(GXO+2) in LDS.
+// ================================================================================================
+constexpr int ATZ = 16;          // owned rows
+constexpr int AGX = 16;          // staged groups per row (14 owned + 1 halo group each side)
+constexpr int AGO = AGX - 2;     // owned groups per row
+constexpr int ASZ = ATZ + 4;     // staged rows
+constexpr int ASX = 4 * AGX;     // staged columns
+
+// S^T:  E = C^T sigma_bar through the transposed C-PML;  v_bar -= stencils(E);  v_bar += R^T g;
+//       all five material-gradient accumulators.
+__global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
+{
+    if ((int)blockIdx.y >= p.tiles_z) {
+        sample_points<1>(p);
+        return;
+    }
+    __shared__ float E[4][ASZ][ASX];
+    __shared__ float inj[2 * ATZ * 4 * AGO];
+    const int tile_j = (int)blockIdx.y * ATZ;
+    const int tile_g = (int)blockIdx.x * AGO;           // first owned group
+    const unsigned fs = p.field_stride;
+    const unsigned ncell = (unsigned)p.nz * p.gp;
+    // stencil-phase ownership: thread t -> (row t / AGO, group t % AGO) for t < ATZ*AGO
+    const int t = (int)threadIdx.x;
+    const bool owner = t < ATZ * AGO;
+    const int orow = t / AGO, ogrp = t % AGO;
+    const int oj = tile_j + orow, og = tile_g + ogrp;
+    const bool own_ok = owner && oj < p.nz && og < p.ng;
+    const unsigned occ = (unsigned)oj * p.gp + 4 * og;
+    float4 acc[5];
+    if (own_ok) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            acc[k] = ld4(p.acc + ((long long)blockIdx.z * 5 + k) * ncell + occ);
+    }
+    for (int si = 0; si < p.gs; ++si) {
+        const int s = (int)blockIdx.z * p.gs + si;
+        if (s >= p.nshot) break;
+        float *fl = p.fields + (long long)s * p.shot_stride;
+        const bool has_inj = stage_injection<ATZ, 4 * AGO, 2>(p, s, tile_j, 4 * tile_g, inj);
+        // ---- stage E1..E4 on the tile + halo -------------------------------------------------
+        for (int e = t; e < ASZ * AGX; e += kThreads) {
+            const int sr = e / AGX, sg = e - sr * AGX;
+            const int j = tile_j - 2 + sr, g = tile_g - 1 + sg;
+            float4 E1 = make_float4(0.f, 0.f, 0.f, 0.f), E2 = E1, E3 = E1, E4 = E1;
+            if (j >= 0 && j < p.nz && g >= 0 && g < p.ng) {
+                const unsigned o = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
+                const unsigned cc = (unsigned)j * p.gp + 4 * g;
+                const float4 bxx = ld4(fl + F_SXX * fs + o), bzz = ld4(fl + F_SZZ * fs + o);
+                const float4 bxz = ld4(fl + F_SXZ * fs + o);
+                const float4 Ls = ld4(p.mat + M_L * ncell + cc), Ms = ld4(p.mat + M_M * ncell + cc);
+                const float4 mus = ld4(p.mat + M_MU * ncell + cc);
+                float e1[4], e2[4], e3[4], e4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    e1[c] = fmaf(comp(Ms, c), comp(bxx, c), comp(Ls, c) * comp(bzz, c));
+                    e2[c] = fmaf(comp(Ls, c), comp(bxx, c), comp(Ms, c) * comp(bzz, c));
+                    e3[c] = comp(mus, c) * comp(bxz, c);
+                    e4[c] = e3[c];
+                }
+                const bool mine = (sr >= 2 && sr < 2 + ATZ && sg >= 1 && sg <= AGO);
+                const int xs_off = xstrip(p, g);
+                if (xs_off >= 0) {
+                    const float4 pxa = ld4(p.px + PA * p.gp + 4 * g), pxb = ld4(p.px + PB * p.gp + 4 * g);
+                    const float4 pxk = ld4(p.px + PK * p.gp + 4 * g), pxah = ld4(p.px + PAH * p.gp + 4 * g);
+                    const float4 pxbh = ld4(p.px + PBH * p.gp + 4 * g), pxkh = ld4(p.px + PKH * p.gp + 4 * g);
+                    const long long q5 = (long long)s * p.psix_shot + ((long long)2 * p.nz + j) * p.wx + xs_off;
+                    const long long q8 = (long long)s * p.psix_shot + ((long long)3 * p.nz + j) * p.wx + xs_off;
+                    const float4 s5 = ld4(p.psix + q5), s8 = ld4(p.psix + q8);
+                    float n5[4], n8[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        e1[c] = pmlT(comp(s5, c), comp(pxa, c), comp(pxb, c), comp(pxk, c), e1[c], n5[c]);
+                        e4[c] = pmlT(comp(s8, c), comp(pxah, c), comp(pxbh, c), comp(pxkh, c), e4[c], n8[c]);
+                    }
+                    if (mine) {
+                        st4(p.psix_out + q5, make_float4(n5[0], n5[1], n5[2], n5[3]));
+                        st4(p.psix_out + q8, make_float4(n8[0], n8[1], n8[2], n8[3]));
+                    }
+                }
+                const int zs = zstrip(p, j);
+                if (zs >= 0) {
+                    const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
+                    const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
+                    const long long q6 = (long long)s * p.psiz_shot + ((long long)2 * 2 * p.W + zs) * p.gp + 4 * g;
+                    const long long q7 = (long long)s * p.psiz_shot + ((long long)3 * 2 * p.W + zs) * p.gp + 4 * g;
+                    const float4 s6 = ld4(p.psiz + q6), s7 = ld4(p.psiz + q7);
+                    float n6[4], n7[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        e2[c] = pmlT(comp(s6, c), za, zb, zk, e2[c], n6[c]);
+                        e3[c] = pmlT(comp(s7, c), zah, zbh, zkh, e3[c], n7[c]);
+                    }
+                    if (mine) {
+                        st4(p.psiz_out + q6, make_float4(n6[0], n6[1], n6[2], n6[3]));
+                        st4(p.psiz_out + q7, make_float4(n7[0], n7[1], n7[2], n7[3]));
+                    }
+                }
+                E1 = make_float4(e1[0], e1[1], e1[2], e1[3]); E2 = make_float4(e2[0], e2[1], e2[2], e2[3]);
+                E3 = make_float4(e3[0], e3[1], e3[2], e3[3]); E4 = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            }
+            st4(&E[0][sr][4 * sg], E1); st4(&E[1][sr][4 * sg], E2);
+            st4(&E[2][sr][4 * sg], E3); st4(&E[3][sr][4 * sg], E4);
+        }
+        __syncthreads();
+        // ---- stencils from LDS + injection + gradient accumulation ---------------------------
+        if (own_ok) {
+            const unsigned o = (unsigned)(oj + 2) * p.pitch + 4 + 4 * og;
+            const int r = orow + 2, cb = 4 * (ogrp + 1);
+            float4 vxb = ld4(fl + F_VX * fs + o), vzb = ld4(fl + F_VZ * fs + o);
+            const float4 bxx = ld4(fl + F_SXX * fs + o), bzz = ld4(fl + F_SZZ * fs + o);
+            const float4 bxz = ld4(fl + F_SXZ * fs + o);
+            const float *Sp = p.S + (long long)s * 5 * ncell + occ;
+            const float4 S1 = ld4(Sp), S2 = ld4(Sp + (long long)ncell), S3 = ld4(Sp + 2 * (long long)ncell);
+            const float4 S4 = ld4(Sp + 3 * (long long)ncell), S5 = ld4(Sp + 4 * (long long)ncell);
+            float nvx[4], nvz[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int x = cb + c;
+                const float dx1 = dfw(E[0][r][x - 1], E[0][r][x], E[0][r][x + 1], E[0][r][x + 2]);
+                const float dz3 = dbw(E[2][r - 2][x], E[2][r - 1][x], E[2][r][x], E[2][r + 1][x]);
+                const float dz2 = dfw(E[1][r - 1][x], E[1][r][x], E[1][r + 1][x], E[1][r + 2][x]);
+                const float dx4 = dbw(E[3][r][x - 2], E[3][r][x - 1], E[3][r][x], E[3][r][x + 1]);
+                float ax = comp(vxb, c) - (dx1 + dz3);
+                float az = comp(vzb, c) - (dz2 + dx4);
+                if (has_inj) {
+                    ax += inj[orow * 4 * AGO + 4 * ogrp + c];
+                    az += inj[ATZ * 4 * AGO + orow * 4 * AGO + 4 * ogrp + c];
+                }
+                if (4 * og + c >= p.nx) { ax = 0.f; az = 0.f; }
+                nvx[c] = ax; nvz[c] = az;
+            }
+            st4(fl + F_VX * fs + o, make_float4(nvx[0], nvx[1], nvx[2], nvx[3]));
+            st4(fl + F_VZ * fs + o, make_float4(nvz[0], nvz[1], nvz[2], nvz[3]));
+            // gradients (oracle order): Ms, Ls, mus from sigma_bar; bxs, bzs from the new v_bar
+#define ACC3(dst, a, b, c_, d) dst = fmaf(a, b, fmaf(c_, d, dst))
+            ACC3(acc[M_M].x, S1.x, bxx.x, S2.x, bzz.x); ACC3(acc[M_M].y, S1.y, bxx.y, S2.y, bzz.y);
+            ACC3(acc[M_M].z, S1.z, bxx.z, S2.z, bzz.z); ACC3(acc[M_M].w, S1.w, bxx.w, S2.w, bzz.w);
+            ACC3(acc[M_L].x, S2.x, bxx.x, S1.x, bzz.x); ACC3(acc[M_L].y, S2.y, bxx.y, S1.y, bzz.y);
+            ACC3(acc[M_L].z, S2.z, bxx.z, S1.z, bzz.z); ACC3(acc[M_L].w, S2.w, bxx.w, S1.w, bzz.w);
+#undef ACC3
+            acc[M_MU].x = fmaf(S3.x, bxz.x, acc[M_MU].x); acc[M_MU].y = fmaf(S3.y, bxz.y, acc[M_MU].y);
+            acc[M_MU].z = fmaf(S3.z, bxz.z, acc[M_MU].z); acc[M_MU].w = fmaf(S3.w, bxz.w, acc[M_MU].w);
+            acc[M_BX].x = fmaf(S4.x, nvx[0], acc[M_BX].x); acc[M_BX].y = fmaf(S4.y, nvx[1], acc[M_BX].y);
+            acc[M_BX].z = fmaf(S4.z, nvx[2], acc[M_BX].z); acc[M_BX].w = fmaf(S4.w, nvx[3], acc[M_BX].w);
+            acc[M_BZ].x = fmaf(S5.x, nvz[0], acc[M_BZ].x); acc[M_BZ].y = fmaf(S5.y, nvz[1], acc[M_BZ].y);
+            acc[M_BZ].z = fmaf(S5.z, nvz[2], acc[M_BZ].z); acc[M_BZ].w = fmaf(S5.w, nvz[3], acc[M_BZ].w);
+        }
+        __syncthreads();          // E and inj are reused by the next shot
+    }
+    if (own_ok) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            st4(p.acc + ((long long)blockIdx.z * 5 + k) * ncell + occ, acc[k]);
+    }
+}
+
+// V^T:  D = B^T v_bar through the transposed C-PML;  sigma_bar -= stencils(D)
+__global__ __launch_bounds__(kThreads) void el_adj_v(const ElParams p)
+{
+    __shared__ float D[4][ASZ][ASX];
+    const int tile_j = (int)blockIdx.y * ATZ;
+    const int tile_g = (int)blockIdx.x * AGO;
+    const int s = (int)blockIdx.z;
+    const unsigned fs = p.field_stride;
+    const unsigned ncell = (unsigned)p.nz * p.gp;
+    const int t = (int)threadIdx.x;
+    float *fl = p.fields + (long long)s * p.shot_stride;
+    for (int e = t; e < ASZ * AGX; e += kThreads) {
+        const int sr = e / AGX, sg = e - sr * AGX;
+        const int j = tile_j - 2 + sr, g = tile_g - 1 + sg;
+        float4 D1 = make_float4(0.f, 0.f, 0.f, 0.f), D2 = D1, D3 = D1, D4 = D1;
+        if (j >= 0 && j < p.nz && g >= 0 && g < p.ng) {
+            const unsigned o = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
+            const unsigned cc = (unsigned)j * p.gp + 4 * g;
+            const float4 vxb = ld4(fl + F_VX * fs + o), vzb = ld4(fl + F_VZ * fs + o);
+            const float4 bxs = ld4(p.mat + M_BX * ncell + cc), bzs = ld4(p.mat + M_BZ * ncell + cc);
+            float d1[4], d2[4], d3[4], d4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                d1[c] = comp(bxs, c) * comp(vxb, c); d2[c] = d1[c];
+                d3[c] = comp(bzs, c) * comp(vzb, c); d4[c] = d3[c];
+            }
+            const bool mine = (sr >= 2 && sr < 2 + ATZ && sg >= 1 && sg <= AGO);
+            const int xs_off = xstrip(p, g);
+            if (xs_off >= 0) {
+                const float4 pxa = ld4(p.px + PA * p.gp + 4 * g), pxb = ld4(p.px + PB * p.gp + 4 * g);
+                const float4 pxk = ld4(p.px + PK * p.gp + 4 * g), pxah = ld4(p.px + PAH * p.gp + 4 * g);
+                const float4 pxbh = ld4(p.px + PBH * p.gp + 4 * g), pxkh = ld4(p.px + PKH * p.gp + 4 * g);
+                const long long q1 = (long long)s * p.psix_shot + ((long long)0 * p.nz + j) * p.wx + xs_off;
+                const long long q3 = (long long)s * p.psix_shot + ((long long)1 * p.nz + j) * p.wx + xs_off;
+                const float4 s1 = ld4(p.psix + q1), s3 = ld4(p.psix + q3);
+                float n1[4], n3[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    d1[c] = pmlT(comp(s1, c), comp(pxah, c), comp(pxbh, c), comp(pxkh, c), d1[c], n1[c]);
+                    d3[c] = pmlT(comp(s3, c), comp(pxa, c), comp(pxb, c), comp(pxk, c), d3[c], n3[c]);
+                }
+                if (mine) {
+                    st4(p.psix_out + q1, make_float4(n1[0], n1[1], n1[2], n1[3]));
+                    st4(p.psix_out + q3, make_float4(n3[0], n3[1], n3[2], n3[3]));
+                }
+            }
+            const int zs = zstrip(p, j);
+            if (zs >= 0) {
+                const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
+                const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
+                const long long q2 = (long long)s * p.psiz_shot + ((long long)0 * 2 * p.W + zs) * p.gp + 4 * g;
+                const long long q4 = (long long)s * p.psiz_shot + ((long long)1 * 2 * p.W + zs) * p.gp + 4 * g;
+                const float4 s2 = ld4(p.psiz + q2), s4 = ld4(p.psiz + q4);
+                float n2[4], n4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    d2[c] = pmlT(comp(s2, c), za, zb, zk, d2[c], n2[c]);
+                    d4[c] = pmlT(comp(s4, c), zah, zbh, zkh, d4[c], n4[c]);
+                }
+                if (mine) {
+                    st4(p.psiz_out + q2, make_float4(n2[0], n2[1], n2[2], n2[3]));
+                    st4(p.psiz_out + q4, make_float4(n4[0], n4[1], n4[2], n4[3]));
+                }
+            }
+            D1 = make_float4(d1[0], d1[1], d1[2], d1[3]); D2 = make_float4(d2[0], d2[1], d2[2], d2[3]);
+            D3 = make_float4(d3[0], d3[1], d3[2], d3[3]); D4 = make_float4(d4[0], d4[1], d4[2], d4[3]);
+        }
+        st4(&D[0][sr][4 * sg], D1); st4(&D[1][sr][4 * sg], D2);
+        st4(&D[2][sr][4 * sg], D3); st4(&D[3][sr][4 * sg], D4);
+    }
+    __syncthreads();
+    if (t < ATZ * AGO) {
+        const int orow = t / AGO, ogrp = t % AGO;
+        const int oj = tile_j + orow, og = tile_g + ogrp;
+        if (oj < p.nz && og < p.ng) {
+            const unsigned o = (unsigned)(oj + 2) * p.pitch + 4 + 4 * og;
+            const int r = orow + 2, cb = 4 * (ogrp + 1);
+            const float4 bxx = ld4(fl + F_SXX * fs + o), bzz = ld4(fl + F_SZZ * fs + o);
+            const float4 bxz = ld4(fl + F_SXZ * fs + o);
+            float nxx[4], nzz[4], nxz[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int x = cb + c;
+                const float dx1 = dbw(D[0][r][x - 2], D[0][r][x - 1], D[0][r][x], D[0][r][x + 1]);
+                const float dz2 = dfw(D[1][r - 1][x], D[1][r][x], D[1][r + 1][x], D[1][r + 2][x]);
+                const float dx3 = dfw(D[2][r][x - 1], D[2][r][x], D[2][r][x + 1], D[2][r][x + 2]);
+                const float dz4 = dbw(D[3][r - 2][x], D[3][r - 1][x], D[3][r][x], D[3][r + 1][x]);
+                nxx[c] = comp(bxx, c) - dx1;
+                nxz[c] = comp(bxz, c) - (dz2 + dx3);
+                nzz[c] = comp(bzz, c) - dz4;
+                if (4 * og + c >= p.nx) { nxx[c] = 0.f; nxz[c] = 0.f; nzz[c] = 0.f; }
+            }
+            st4(fl + F_SXX * fs + o, make_float4(nxx[0], nxx[1], nxx[2], nxx[3]));
+            st4(fl + F_SZZ * fs + o, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
+            st4(fl + F_SXZ * fs + o, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
+        }
+    }
+}
+
+__global__ void el_points_bbox(const int *cell, int npts_per_shot, int n1, int *bbox)
+{
+    __shared__ int red[4][kThreads];
+    const int s = blockIdx.x;
+    int a0 = 0x7fffffff, a1 = -1, b0 = 0x7fffffff, b1 = -1;
+    for (int e = threadIdx.x; e < npts_per_shot; e += kThreads) {
+        const int c = cell[(long long)s * npts_per_shot + e];
+        if (c < 0) continue;
+        const int i0 = c / n1, i1 = c - i0 * n1;
+        a0 = min(a0, i0); a1 = max(a1, i0); b0 = min(b0, i1); b1 = max(b1, i1);
+    }
+    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1;
+    red[2][threadIdx.x] = b0; red[3][threadIdx.x] = b1;
+    __syncthreads();
+    for (int st = kThreads / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            red[0][threadIdx.x] = min(red[0][threadIdx.x], red[0][threadIdx.x + st]);
+            red[1][threadIdx.x] = max(red[1][threadIdx.x], red[1][threadIdx.x + st]);
+            red[2][threadIdx.x] = min(red[2][threadIdx.x], red[2][threadIdx.x + st]);
+            red[3][threadIdx.x] = max(red[3][threadIdx.x], red[3][threadIdx.x + st]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        bbox[4 * s + 0] = red[0][0]; bbox[4 * s + 1] = red[1][0];
+        bbox[4 * s + 2] = red[2][0]; bbox[4 * s + 3] = red[3][0];
+    }
+}
+
+// grad[k][cell] = sum over shot groups of acc[group][k][cell]
+__global__ void el_finalize(const float *acc, int ngroups, long long n5, float *grad)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n5) return;
+    float a = 0.f;
+    for (int gidx = 0; gidx < ngroups; ++gidx) a += acc[(long long)gidx * n5 + idx];
+    grad[idx] = a;
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+// ================================================================================================
+struct mifwi_elastic_plan {
+    mifwi_elastic_desc d;
+    int device;
+    int ng, gp, pitch, lx, rz, gs, ngroups;
+    int W, wl, xr0, wx;
+    long long field_stride, shot_stride, fields_elems, psix_elems, psiz_elems, coef_elems;
+};
+
+namespace {
+
+ElParams el_base(const mifwi_elastic_plan *pl, const float *mat, const float *pz, const float *px)
+{
+    ElParams p;
+    memset(&p, 0, sizeof(p));
+    p.nz = pl->d.nz; p.nx = pl->d.nx; p.ng = pl->ng; p.gp = pl->gp; p.pitch = pl->pitch;
+    p.field_stride = (unsigned)pl->field_stride; p.shot_stride = pl->shot_stride;
+    p.nshot = pl->d.nshot; p.gs = 1;
+    p.W = pl->W; p.wl = pl->wl; p.xr0 = pl->xr0; p.wx = pl->wx;
+    p.psix_shot = 4LL * pl->d.nz * pl->wx; p.psiz_shot = 4LL * 2 * pl->W * pl->gp;
+    p.mat = mat; p.pz = pz; p.px = px;
+    return p;
+}
+
+template <bool SAVE>
+void launch_v(const mifwi_elastic_plan *pl, const ElParams &p, hipStream_t st)
+{
+    const int lz = kThreads / pl->lx;
+    dim3 grid(mifwi::ceil_div(pl->ng, pl->lx), mifwi::ceil_div(pl->d.nz, lz * 2), pl->d.nshot);
+    dim3 block(kThreads);
+    switch (pl->lx) {
+        case 64: hipLaunchKernelGGL((el_step_v<64, 2, SAVE>), grid, block, 0, st, p); break;
+        case 32: hipLaunchKernelGGL((el_step_v<32, 2, SAVE>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((el_step_v<16, 2, SAVE>), grid, block, 0, st, p); break;
+    }
+}
+
+template <bool SAVE>
+void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, hipStream_t st)
+{
+    const int lz = kThreads / pl->lx;
+    const int tiles_x = mifwi::ceil_div(pl->ng, pl->lx);
+    ElParams p = p0;
+    p.tiles_z = mifwi::ceil_div(pl->d.nz, lz * 2);
+    int extra = 0;
+    if (p.smp_out0 != nullptr && p.nsmp > 0)
+        extra = mifwi::ceil_div(mifwi::ceil_div(p.gs * p.nsmp, kThreads), tiles_x);
+    dim3 grid(tiles_x, p.tiles_z + extra, mifwi::ceil_div(pl->d.nshot, p.gs)), block(kThreads);
+    switch (pl->lx) {
+        case 64: hipLaunchKernelGGL((el_step_s<64, 2, SAVE>), grid, block, 0, st, p); break;
+        case 32: hipLaunchKernelGGL((el_step_s<32, 2, SAVE>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((el_step_s<16, 2, SAVE>), grid, block, 0, st, p); break;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi_elastic_desc *d)
+{
+    if (!plan || !d) return mifwi::fail(MIFWI_EINVAL, "null plan/desc");
+    if (d->nz < 1 || d->nx < 1 || d->nt < 1 || d->nshot < 1 || d->nsrc < 0 || d->nrec < 0)
+        return mifwi::fail(MIFWI_EINVAL, "bad sizes nz=%d nx=%d nt=%d nshot=%d", d->nz, d->nx, d->nt,
+                           d->nshot);
+    if (d->ntap != 1 && d->ntap != 4) return mifwi::fail(MIFWI_EINVAL, "ntap must be 1 or 4");
+    if (d->free_surface != 0)
+        return mifwi::fail(MIFWI_EINVAL, "free_surface is not implemented in this build");
+    if (d->pml_width < 0) return mifwi::fail(MIFWI_EINVAL, "pml_width < 0");
+    int rc = mifwi::check_device(device);
+    if (rc) return rc;
+    mifwi_elastic_plan *pl = new mifwi_elastic_plan;
+    pl->d = *d;
+    pl->device = device;
+    pl->ng = mifwi::ceil_div(d->nx, 4);
+    pl->gp = 4 * pl->ng;
+    pl->pitch = (int)mifwi::round_up64(4 * (pl->ng + 3), 32);
+    pl->field_stride = (long long)(d->nz + 4) * pl->pitch;
+    pl->shot_stride = 5 * pl->field_stride;
+    pl->fields_elems = pl->shot_stride * d->nshot;
+    pl->coef_elems = (long long)d->nz * pl->gp;
+    // strip geometry: W = pml_width + 1 nodes per side (half-node profiles reach one node further)
+    pl->W = d->pml_width > 0 ? d->pml_width + 1 : 0;
+    if (pl->W > 0) {
+        pl->wl = (int)mifwi::round_up64(pl->W, 4);
+        pl->xr0 = ((d->nx - pl->W) / 4) * 4;
+        if (pl->xr0 < pl->wl || 2 * pl->W > d->nz) {
+            delete pl;
+            return mifwi::fail(MIFWI_EINVAL, "grid %dx%d too small for a %d-node C-PML", d->nz,
+                               d->nx, d->pml_width);
+        }
+        pl->wx = pl->wl + (pl->gp - pl->xr0);
+    } else {
+        pl->wl = pl->xr0 = pl->wx = 0;
+    }
+    pl->psix_elems = 4LL * d->nz * pl->wx * d->nshot;
+    pl->psiz_elems = 4LL * 2 * pl->W * pl->gp * d->nshot;
+    pl->lx = 16;
+    for (int cand : {64, 32}) {
+        const int padded = mifwi::ceil_div(pl->ng, cand) * cand;
+        if (padded * 10 <= pl->ng * 12) { pl->lx = cand; break; }
+    }
+    { const int v = env_int("MIFWI_EL_LX", 0); if (v == 16 || v == 32 || v == 64) pl->lx = v; }
+    pl->rz = 2;
+    int gs = d->shots_per_group;
+    if (gs <= 0) gs = env_int("MIFWI_EL_GS", 4);
+    if (gs <= 0) gs = 1;
+    if (gs > d->nshot) gs = d->nshot;
+    pl->gs = gs;
+    pl->ngroups = mifwi::ceil_div(d->nshot, gs);
+    *plan = pl;
+    return MIFWI_OK;
+}
+
+int mifwi_elastic_plan_destroy(mifwi_elastic_plan *plan)
+{
+    delete plan;
+    return MIFWI_OK;
+}
+
+int mifwi_elastic_plan_layout(const mifwi_elastic_plan *pl, mifwi_elastic_layout *out)
+{
+    if (!pl || !out) return mifwi::fail(MIFWI_EINVAL, "null plan/layout");
+    out->gp = pl->gp; out->pitch = pl->pitch; out->ngroups = pl->ngroups;
+    out->shots_per_group = pl->gs;
+    out->coef_elems = pl->coef_elems;
+    const long long psi = mifwi::round_up64(pl->psix_elems + pl->psiz_elems, 64);
+    const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
+    out->state_elems = pl->fields_elems + psi;
+    out->work_forward_elems = out->state_elems + bbox;
+    out->work_backward_elems = pl->fields_elems + 2 * psi + 5LL * pl->ngroups * pl->coef_elems + bbox;
+    return MIFWI_OK;
+}
+
+int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float *pz,
+                          const float *px, const float *f, const int32_t *src_cell,
+                          const float *src_w, const int32_t *rec_cell, const float *rec_w,
+                          float *rec_vx, float *rec_vz, float *snap, float *work, int32_t n_begin,
+                          int32_t n_end, int32_t flags, void *stream)
+{
+    if (!pl || !mat || !pz || !px || !work) return mifwi::fail(MIFWI_EINVAL, "null argument");
+    const mifwi_elastic_desc &d = pl->d;
+    if (n_begin < 0 || n_end > d.nt || n_begin > n_end)
+        return mifwi::fail(MIFWI_EINVAL, "bad step range [%d,%d) for nt=%d", n_begin, n_end, d.nt);
+    if (d.nsrc > 0 && (!f || !src_cell || !src_w))
+        return mifwi::fail(MIFWI_EINVAL, "sources declared but f/src_cell/src_w is null");
+    if ((rec_vx || rec_vz) && (!rec_cell || !rec_w || !rec_vx || !rec_vz))
+        return mifwi::fail(MIFWI_EINVAL, "receiver output needs rec_cell, rec_w, rec_vx and rec_vz");
+    int rc = mifwi::check_device(pl->device);
+    if (rc) return rc;
+    MIFWI_HIP_TRY(hipSetDevice(pl->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long long psi = mifwi::round_up64(pl->psix_elems + pl->psiz_elems, 64);
+    float *fields = work, *psix = work + pl->fields_elems, *psiz = psix + pl->psix_elems;
+    int *bbox = reinterpret_cast<int *>(work + pl->fields_elems + psi);
+    if (flags & MIFWI_ZERO_STATE)
+        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (pl->fields_elems + psi), st));
+    if (d.nsrc > 0)
+        hipLaunchKernelGGL(el_points_bbox, dim3(d.nshot), dim3(kThreads), 0, st, src_cell,
+                           d.nsrc * d.ntap, d.nx, bbox);
+    ElParams p = el_base(pl, mat, pz, px);
+    p.fields = fields; p.psix = psix; p.psiz = psiz;
+    ElParams ps = p;
+    ps.ninj = d.nsrc; ps.ntap_inj = d.ntap; ps.inj_cell = src_cell; ps.inj_w = src_w;
+    ps.inj_bbox = bbox;
+    ps.nsmp = rec_vx ? d.nrec : 0; ps.ntap_smp = d.ntap; ps.smp_cell = rec_cell; ps.smp_w = rec_w;
+    const long long snap_step = 5LL * d.nshot * pl->coef_elems;
+    for (int n = n_begin; n < n_end; ++n) {
+        float *Sn = snap ? snap + (long long)(n - n_begin) * snap_step : nullptr;
+        p.S = Sn; ps.S = Sn;
+        ps.inj_amp0 = f ? f + (long long)n * d.nshot * d.nsrc : nullptr;
+        ps.smp_out0 = (rec_vx && d.nrec > 0) ? rec_vx + (long long)n * d.nshot * d.nrec : nullptr;
+        ps.smp_out1 = (rec_vz && d.nrec > 0) ? rec_vz + (long long)n * d.nshot * d.nrec : nullptr;
+        if (snap) { launch_v<true>(pl, p, st); launch_s<true>(pl, ps, st); }
+        else { launch_v<false>(pl, p, st); launch_s<false>(pl, ps, st); }
+    }
+    MIFWI_HIP_TRY(hipGetLastError());
+    return MIFWI_OK;
+}
+
+int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float *pz,
+                           const float *px, const int32_t *src_cell, const float *src_w,
+                           const int32_t *rec_cell, const float *rec_w, const float *g_vx,
+                           const float *g_vz, const float *snap, int32_t snap_first,
+                           float *grad_mat, float *grad_f, float *work, int32_t n_hi, int32_t n_lo,
+                           int32_t flags, void *stream)
+{
+    if (!pl || !mat || !pz || !px || !work || !snap || !g_vx || !g_vz || !rec_cell || !rec_w)
+        return mifwi::fail(MIFWI_EINVAL, "null argument");
+    const mifwi_elastic_desc &d = pl->d;
+    if (n_lo < 0 || n_hi > d.nt - 1 || n_lo > n_hi + 1)
+        return mifwi::fail(MIFWI_EINVAL, "bad adjoint range n=%d..%d for nt=%d", n_hi, n_lo, d.nt);
+    if (snap_first > n_lo)
+        return mifwi::fail(MIFWI_EINVAL, "snapshots start at step %d but step %d is needed",
+                           snap_first, n_lo);
+    if (grad_f && (!src_cell || !src_w))
+        return mifwi::fail(MIFWI_EINVAL, "grad_f requested but src_cell/src_w is null");
+    if ((flags & MIFWI_FINALIZE) && !grad_mat)
+        return mifwi::fail(MIFWI_EINVAL, "finalize requested but grad_mat is null");
+    int rc = mifwi::check_device(pl->device);
+    if (rc) return rc;
+    MIFWI_HIP_TRY(hipSetDevice(pl->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long long psi = mifwi::round_up64(pl->psix_elems + pl->psiz_elems, 64);
+    float *fields = work;
+    float *psiA = work + pl->fields_elems, *psiB = psiA + psi;
+    float *acc = psiB + psi;
+    const long long nacc = 5LL * pl->ngroups * pl->coef_elems;
+    int *bbox = reinterpret_cast<int *>(acc + nacc);
+    if (flags & MIFWI_ZERO_STATE)
+        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (pl->fields_elems + 2 * psi + nacc), st));
+    hipLaunchKernelGGL(el_points_bbox, dim3(d.nshot), dim3(kThreads), 0, st, rec_cell,
+                       d.nrec * d.ntap, d.nx, bbox);
+    ElParams p = el_base(pl, mat, pz, px);
+    p.fields = fields;
+    p.acc = acc;
+    ElParams ps = p;
+    ps.gs = pl->gs;
+    ps.ninj = d.nrec; ps.ntap_inj = d.ntap; ps.inj_cell = rec_cell; ps.inj_w = rec_w;
+    ps.inj_bbox = bbox;
+    const bool want_f = grad_f != nullptr && d.nsrc > 0;
+    ps.nsmp = want_f ? d.nsrc : 0; ps.ntap_smp = d.ntap; ps.smp_cell = src_cell; ps.smp_w = src_w;
+    const long long snap_step = 5LL * d.nshot * pl->coef_elems;
+    const int tiles_x = mifwi::ceil_div(pl->ng, AGO), tiles_z = mifwi::ceil_div(d.nz, ATZ);
+    for (int n = n_hi; n >= n_lo; --n) {
+        // ping-pong of the adjoint memory variables is absolute in n (resumable ranges)
+        const int par = (d.nt - 1 - n) & 1;
+        float *rd = par ? psiB : psiA, *wr = par ? psiA : psiB;
+        ps.psix = rd; ps.psiz = rd + pl->psix_elems;
+        ps.psix_out = wr; ps.psiz_out = wr + pl->psix_elems;
+        ps.S = const_cast<float *>(snap) + (long long)(n - snap_first) * snap_step;
+        ps.inj_amp0 = g_vx + (long long)n * d.nshot * d.nrec;
+        ps.inj_amp1 = g_vz + (long long)n * d.nshot * d.nrec;
+        ps.smp_out0 = want_f ? grad_f + (long long)n * d.nshot * d.nsrc : nullptr;
+        ps.tiles_z = tiles_z;
+        int extra = 0;
+        if (want_f) extra = mifwi::ceil_div(mifwi::ceil_div(ps.gs * ps.nsmp, kThreads), tiles_x);
+        hipLaunchKernelGGL(el_adj_s, dim3(tiles_x, tiles_z + extra, pl->ngroups), dim3(kThreads), 0,
+                           st, ps);
+        p.psix = ps.psix; p.psiz = ps.psiz; p.psix_out = ps.psix_out; p.psiz_out = ps.psiz_out;
+        hipLaunchKernelGGL(el_adj_v, dim3(tiles_x, tiles_z, d.nshot), dim3(kThreads), 0, st, p);
+    }
+    if (flags & MIFWI_FINALIZE) {
+        const long long n5 = 5LL * pl->coef_elems;
+        hipLaunchKernelGGL(el_finalize, dim3((unsigned)((n5 + 255) / 256)), dim3(256), 0, st, acc,
+                           pl->ngroups, n5, grad_mat);
+    }
+    MIFWI_HIP_TRY(hipGetLastError());
+    return MIFWI_OK;
+}
+
+}  // extern "C"

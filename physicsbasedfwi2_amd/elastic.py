@@ -1,0 +1,199 @@
+"""Host side of the elastic (P-SV) propagator: staggered material preparation (differentiable
+torch ops, so the chain rule (vp, vs, rho) -> (lambda, mu, averages) is autograd's), plan and
+buffer handling, and the ``torch.autograd.Function`` around the HIP forward / adjoint.
+
+Stands where ``d.forward`` / ``d.grad`` of pyapi_denise stand in the reference
+(models/networks.py:7752-7802): models in, vx/vz seismograms and Vp/Vs/rho gradients out,
+with no mpirun and no files.  All wave arithmetic is in libmifwi.so; there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MifwiError
+from .acoustic import _Geometry, _require_cuda, _stream
+
+DEFAULT_SNAPSHOT_BUDGET = 96 << 30
+
+
+def staggered_materials(vp, vs, rho, dt, h):
+    """[5, nz, nx] = lambda dt/h, (lambda+2mu) dt/h, mu_xz dt/h, dt/(h rho_x), dt/(h rho_z).
+
+    Arithmetic averaging of density to the vx / vz nodes, harmonic averaging of the shear
+    modulus to the sxz node (0 where any of the four is 0, i.e. in water), edge values
+    replicated.  Plain differentiable torch ops on [nz, nx] tensors."""
+    mu = rho * vs * vs
+    lam = rho * vp * vp - 2.0 * mu
+    s = dt / h
+
+    def sh(a, dz, dx):
+        a = torch.cat([a, a[-1:, :]], 0)[dz:dz + a.shape[0]] if dz else a
+        a = torch.cat([a, a[:, -1:]], 1)[:, dx:dx + a.shape[1]] if dx else a
+        return a
+    rx = 0.5 * (rho + sh(rho, 0, 1))
+    rz = 0.5 * (rho + sh(rho, 1, 0))
+    m4 = [mu, sh(mu, 0, 1), sh(mu, 1, 0), sh(mu, 1, 1)]
+    anyzero = (m4[0] == 0) | (m4[1] == 0) | (m4[2] == 0) | (m4[3] == 0)
+    inv = sum(1.0 / torch.where(m == 0, torch.ones_like(m), m) for m in m4)
+    muxz = torch.where(anyzero, torch.zeros_like(mu), 4.0 / inv)
+    return torch.stack([lam * s, (lam + 2.0 * mu) * s, muxz * s, s / rx, s / rz])
+
+
+class ElasticPlan:
+    def __init__(self, nz, nx, nt, nshot, nsrc, nrec, ntap, pml_width, device_index,
+                 shots_per_group=0, free_surface=0):
+        self._lib = _lib.load()
+        self.desc = _lib.ElasticDesc(nz, nx, nt, nshot, nsrc, nrec, ntap, pml_width,
+                                     free_surface, shots_per_group)
+        self._h = ctypes.c_void_p()
+        _lib.check(self._lib.mifwi_elastic_plan_create(ctypes.byref(self._h), device_index,
+                                                       ctypes.byref(self.desc)))
+        self.layout = _lib.ElasticLayout()
+        _lib.check(self._lib.mifwi_elastic_plan_layout(self._h, ctypes.byref(self.layout)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            self._lib.mifwi_elastic_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class _ElasticFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mat, f, pz, px, geom, pml_width, shots_per_group, snapshot_budget):
+        _require_cuda(mat, "mat")
+        dev = mat.device
+        lib = _lib.load()
+        _, nz, nx = mat.shape
+        nt, ns, nsrc = f.shape
+        if geom.src_cell.shape[:2] != (ns, nsrc):
+            raise MifwiError("f is [nt,%d,%d] but src_cell is %s" % (ns, nsrc,
+                                                                      tuple(geom.src_cell.shape)))
+        nrec, ntap = geom.rec_cell.shape[1], geom.rec_cell.shape[2]
+        for name, c in (("src_cell", geom.src_cell), ("rec_cell", geom.rec_cell)):
+            if c.numel() and int(c.max()) >= nz * nx:
+                raise MifwiError("%s holds a cell outside the %dx%d grid" % (name, nz, nx))
+        with torch.cuda.device(dev):
+            plan = ElasticPlan(nz, nx, nt, ns, nsrc, nrec, ntap, pml_width, dev.index,
+                               shots_per_group)
+            lay = plan.layout
+            gp = lay.gp
+            mat_p = torch.zeros((5, nz, gp), device=dev, dtype=torch.float32)
+            mat_p[:, :, :nx] = mat.detach()
+            pz_d = pz.to(device=dev, dtype=torch.float32).contiguous()
+            px_p = torch.zeros((6, gp), device=dev, dtype=torch.float32)
+            px_p[2] = 1.0
+            px_p[5] = 1.0
+            px_p[:, :nx] = px.to(device=dev, dtype=torch.float32)
+            f_d = f.detach().to(dtype=torch.float32).contiguous()
+            rvx = torch.empty((nt, ns, nrec), device=dev, dtype=torch.float32)
+            rvz = torch.empty((nt, ns, nrec), device=dev, dtype=torch.float32)
+            work = torch.empty(lay.work_forward_elems, device=dev, dtype=torch.float32)
+            need_grad = mat.requires_grad or f.requires_grad
+            step_bytes = 4 * 5 * ns * lay.coef_elems
+            seg, snap, ckpt = nt, None, None
+            if need_grad:
+                if nt * step_bytes > snapshot_budget:
+                    seg = max(1, int(snapshot_budget // (2 * step_bytes)))
+                if seg >= nt:
+                    seg = nt
+                    snap = torch.empty((nt, ns, 5, nz, gp), device=dev, dtype=torch.float32)
+            args = (plan.handle, _lib.ptr(mat_p), _lib.ptr(pz_d), _lib.ptr(px_p), _lib.ptr(f_d),
+                    _lib.ptr(geom.src_cell), _lib.ptr(geom.src_w), _lib.ptr(geom.rec_cell),
+                    _lib.ptr(geom.rec_w), _lib.ptr(rvx), _lib.ptr(rvz))
+            if not need_grad or seg == nt:
+                _lib.check(lib.mifwi_elastic_forward(*args, _lib.ptr(snap), _lib.ptr(work), 0, nt,
+                                                     _lib.ZERO_STATE, _stream()))
+            else:
+                ckpt = []
+                for b in range(0, nt, seg):
+                    if b > 0:
+                        ckpt.append(work[:lay.state_elems].clone())
+                    _lib.check(lib.mifwi_elastic_forward(*args, None, _lib.ptr(work), b,
+                                                         min(b + seg, nt),
+                                                         _lib.ZERO_STATE if b == 0 else 0,
+                                                         _stream()))
+            if need_grad:
+                ctx.plan, ctx.geom, ctx.seg, ctx.ckpt, ctx.snap = plan, geom, seg, ckpt, snap
+                ctx.dims = (nz, nx, nt, ns, nsrc, nrec)
+                ctx.need_f = f.requires_grad
+                ctx.save_for_backward(mat_p, pz_d, px_p, f_d)
+            else:
+                plan.close()
+        return rvx, rvz
+
+    @staticmethod
+    def backward(ctx, g_vx, g_vz):
+        lib = _lib.load()
+        mat_p, pz_d, px_p, f_d = ctx.saved_tensors
+        plan, geom = ctx.plan, ctx.geom
+        lay = plan.layout
+        nz, nx, nt, ns, nsrc, nrec = ctx.dims
+        dev = mat_p.device
+        with torch.cuda.device(dev):
+            gx = (torch.zeros((nt, ns, nrec), device=dev) if g_vx is None
+                  else g_vx.to(dtype=torch.float32).contiguous())
+            gz = (torch.zeros((nt, ns, nrec), device=dev) if g_vz is None
+                  else g_vz.to(dtype=torch.float32).contiguous())
+            grad_mat = torch.empty((5, nz, lay.gp), device=dev, dtype=torch.float32)
+            grad_f = (torch.zeros((nt, ns, nsrc), device=dev, dtype=torch.float32)
+                      if ctx.need_f else None)
+            work = torch.empty(lay.work_backward_elems, device=dev, dtype=torch.float32)
+            common = (plan.handle, _lib.ptr(mat_p), _lib.ptr(pz_d), _lib.ptr(px_p),
+                      _lib.ptr(geom.src_cell), _lib.ptr(geom.src_w), _lib.ptr(geom.rec_cell),
+                      _lib.ptr(geom.rec_w), _lib.ptr(gx), _lib.ptr(gz))
+            if ctx.snap is not None:
+                _lib.check(lib.mifwi_elastic_backward(
+                    *common, _lib.ptr(ctx.snap), 0, _lib.ptr(grad_mat), _lib.ptr(grad_f),
+                    _lib.ptr(work), nt - 1, 0, _lib.ZERO_STATE | _lib.FINALIZE, _stream()))
+            else:
+                seg = ctx.seg
+                fwork = torch.empty(lay.work_forward_elems, device=dev, dtype=torch.float32)
+                snap = torch.empty((seg, ns, 5, nz, lay.gp), device=dev, dtype=torch.float32)
+                starts = list(range(0, nt, seg))
+                first = True
+                for si in reversed(range(len(starts))):
+                    b, e = starts[si], min(starts[si] + seg, nt)
+                    if b == 0:
+                        fflags = _lib.ZERO_STATE
+                    else:
+                        fwork[:lay.state_elems].copy_(ctx.ckpt[si - 1])
+                        fflags = 0
+                    _lib.check(lib.mifwi_elastic_forward(
+                        plan.handle, _lib.ptr(mat_p), _lib.ptr(pz_d), _lib.ptr(px_p),
+                        _lib.ptr(f_d), _lib.ptr(geom.src_cell), _lib.ptr(geom.src_w),
+                        _lib.ptr(geom.rec_cell), _lib.ptr(geom.rec_w), None, None,
+                        _lib.ptr(snap), _lib.ptr(fwork), b, e, fflags, _stream()))
+                    flags = (_lib.ZERO_STATE if first else 0) | (_lib.FINALIZE if b == 0 else 0)
+                    first = False
+                    _lib.check(lib.mifwi_elastic_backward(
+                        *common, _lib.ptr(snap), b, _lib.ptr(grad_mat), _lib.ptr(grad_f),
+                        _lib.ptr(work), e - 1, b, flags, _stream()))
+            plan.close()
+            ctx.snap = None
+            ctx.ckpt = None
+        return (grad_mat[:, :, :nx].contiguous(), grad_f, None, None, None, None, None, None)
+
+
+def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
+              shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET):
+    """Elastic forward modelling, differentiable w.r.t. ``mat`` and ``f``.
+
+    mat [5,nz,nx] from :func:`staggered_materials`;  f [nt,nshot,nsrc] (added to sxx and szz);
+    pz [6,nz], px [6,nx] from :func:`profiles.cpml_tables`;  cells are iz*nx+ix.
+    Returns (rec_vx, rec_vz), each [nt,nshot,nrec], sampled after the velocity update."""
+    _require_cuda(mat, "mat")
+    geom = _Geometry(src_cell, src_w, rec_cell, rec_w, mat.device)
+    f = f.to(device=mat.device)
+    return _ElasticFn.apply(mat, f, pz, px, geom, int(pml_width), int(shots_per_group),
+                            int(snapshot_budget))

@@ -119,3 +119,44 @@ def cells_bilinear(coords, spacing, pad, shape_pad):
     cells = np.where(ok, cells, -1).astype(np.int32)
     w = np.where(ok, w, 0.0)
     return torch.from_numpy(cells), torch.from_numpy(w.astype(np.float32))
+
+
+# ------------------------------------------------------------------------------- C-PML --
+def cpml_tables(n, width, h, dt, vpml, fpml, npower=4.0, kmax=1.0, low=True, high=True,
+                rcoef=0.0008):
+    """1-D convolutional-PML tables [6, n] = a, b, 1/kappa at integer nodes, then the same
+    three at half nodes (x = (i+1/2) h).  DENISE-style layer INSIDE the grid, `width` nodes
+    (pyapi_denise names: FW, DAMPING = vpml, FPML, npower, k_max_PML).
+      abscissa: low side (width - x/h) h, high side (x/h - (n-1-width)) h, clipped at 0
+      d = d0 (abscissa/L)^N,  d0 = -(N+1) vpml ln(rcoef)/(2L),  L = width*h
+      kappa = 1 + (kmax-1)(abscissa/L)^N,  alpha = pi fpml (1 - abscissa/L)
+      b = exp(-(d/kappa + alpha) dt),  a = d (b-1)/(kappa (d + kappa alpha))
+    Outside the layer a = b = 0 and 1/kappa = 1 (the kernels then skip the memory variable)."""
+    out = np.zeros((6, n), dtype=np.float64)
+    out[2] = 1.0
+    out[5] = 1.0
+    if width <= 0 or not (low or high):
+        return out
+    L = width * h
+    d0 = -(npower + 1.0) * vpml * math.log(rcoef) / (2.0 * L)
+    alpha_max = math.pi * fpml
+    for half in (0, 1):
+        pos = np.arange(n, dtype=np.float64) + 0.5 * half
+        absc = np.zeros(n)
+        if low:
+            absc = np.maximum(absc, (width - pos) * h)
+        if high:
+            absc = np.maximum(absc, (pos - (n - 1 - width)) * h)
+        nrm = absc / L
+        d = d0 * nrm ** npower
+        kappa = 1.0 + (kmax - 1.0) * nrm ** npower
+        alpha = alpha_max * (1.0 - np.minimum(nrm, 1.0))
+        b = np.exp(-(d / kappa + alpha) * dt)
+        den = kappa * (d + kappa * alpha)
+        safe = den > 1e-30
+        a = np.where(safe, d * (b - 1.0) / np.where(safe, den, 1.0), 0.0)
+        inside = nrm > 0
+        out[3 * half + 0] = np.where(inside, a, 0.0)
+        out[3 * half + 1] = np.where(inside, b, 0.0)
+        out[3 * half + 2] = np.where(inside, 1.0 / kappa, 1.0)
+    return out

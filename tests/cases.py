@@ -45,3 +45,31 @@ def rel_l2(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = np.linalg.norm(b.ravel())
     return np.linalg.norm((a - b).ravel()) / (den if den > 0 else 1.0)
+
+
+def elastic_case(seed=0, nz=44, nx=60, fw=8, nt=120, ns=2, nsrc=1, nrec=9, h=20.0, dt=0.002,
+                 water=6, freq=8.0):
+    """Random elastic model with a water layer, sources inside the top C-PML."""
+    rng = np.random.default_rng(seed)
+    vp = 1800 + 1500 * rng.random((nz, nx))
+    vs = vp / np.sqrt(3) * (0.8 + 0.4 * rng.random((nz, nx)))
+    rho = 1800 + 600 * rng.random((nz, nx))
+    if water:
+        vs[:water] = 0.0
+        vp[:water] = 1500.0
+        rho[:water] = 1000.0
+    mat = H.elastic_materials(vp, vs, rho, dt, h)
+    pz = H.cpml_profiles(nz, fw, h, dt, 3000.0, 5.0)
+    px = H.cpml_profiles(nx, fw, h, dt, 3000.0, 5.0)
+    f = np.zeros((nt, ns, nsrc))
+    for i in range(nsrc):
+        f[:, :, i] = (H.ricker_deepwave(freq * (1 + 0.2 * i), nt, dt, 1.2 / freq) * 1e6)[:, None]
+    f *= (1.0 + 0.1 * np.arange(ns))[None, :, None]
+    sz = rng.integers(2, 5, (ns, nsrc))
+    sx = rng.integers(4, nx - 4, (ns, nsrc))
+    sc, sw = H.cell_taps(sz, sx, nx)
+    rz_ = np.full((ns, nrec), min(nz - 3, water + 14))
+    rx_ = np.linspace(2, nx - 3, nrec).astype(int)[None, :].repeat(ns, 0)
+    rc, rw = H.cell_taps(rz_, rx_, nx)
+    return dict(mat=mat, pz=pz, px=px, f=f, sc=sc, sw=sw, rc=rc, rw=rw, fw=fw, vp=vp, vs=vs,
+                rho=rho, dt=dt, h=h)
