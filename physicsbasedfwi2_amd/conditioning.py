@@ -1,0 +1,49 @@
+"""The O(data) host expressions that surround the propagator call inside the reference's
+``prop()`` methods: trace normalisation and L1 misfit (models/networks.py:5418-5419,
+5467-5476), shot shuffle / strided mini-batch (5434-5440, 5454-5461), gradient conditioning
+(5329-5332, 5492-5493; 7808-7862).  Plain torch / numpy; the fused HIP misfit lives in misfit.py.
+"""
+import numpy as np
+import torch
+
+
+def trace_normalize(d, eps=1e-10):
+    """d / (max_t |d| + eps) per trace; d is [nt, nshot, nrec] (networks.py:5418-5419)."""
+    dmax, _ = torch.abs(d).max(dim=0, keepdim=True)
+    return d / (dmax.abs() + eps)
+
+
+def l1_trace_normalized(pred, obs_norm, direct=None):
+    """networks.py:5467-5476: subtract the direct wave, normalise per trace, L1 mean."""
+    d = pred if direct is None else pred - direct
+    return torch.nn.functional.l1_loss(trace_normalize(d), obs_norm)
+
+
+def shuffle_and_pick(num_shots, num_batches, it=0, generator=None):
+    """networks.py:5434-5461: idx = randperm(num_shots); batch `it` = idx[it::num_batches].
+    Returns (idx, picked) so that callers can permute x_s, observed data and the direct wave
+    identically (bit-exact given the torch RNG state)."""
+    idx = torch.randperm(num_shots, generator=generator)
+    return idx, idx[it::num_batches]
+
+
+def condition_acoustic_gradient(grad, true_model, water_value=1500.0):
+    """networks.py:5329-5332, 5492-5493: multiply row z by z^2, zero where the true model is
+    water.  grad [nz,nx]; true_model [1,1,nz,nx]."""
+    nz = grad.shape[0]
+    ramp = (torch.arange(nz, device=grad.device, dtype=grad.dtype) ** 2.0)[:, None]
+    out = grad * ramp
+    out[(true_model[0, 0] == water_value).to(out.device)] = 0
+    return out
+
+
+def condition_elastic_gradients(g_vp, g_vs, g_rho, vp, vs, rho, mute_rows=25, rho_factor=0.1):
+    """networks.py:7808-7862: flipud, zero rows 0:mute_rows, scale each by max(model)/max(grad);
+    rho additionally x rho_factor.  numpy in, torch float tensors out (as the reference)."""
+    outs = []
+    for g, m, fac in ((g_vp, vp, 1.0), (g_vs, vs, 1.0), (g_rho, rho, rho_factor)):
+        gg = np.flipud(np.asarray(g)).copy()
+        gg[0:mute_rows, :] = 0.0
+        r = np.max(m) / np.max(gg)
+        outs.append(1.0 * torch.from_numpy(gg.copy()).float() * r * fac)
+    return outs
