@@ -136,35 +136,143 @@ class AcousticMarmousi:
                           "(oracle/acoustic.c, OpenMP over shots), %.1f s" % (ns, nt, el)}
 
 
-WORKLOADS = {"acoustic_marmousi": AcousticMarmousi}
+def synth_elastic(nz, nx, seed, water_rows=26):
+    """Vp as the acoustic case, Vs = Vp/sqrt(3) (0 in water), rho = 310 Vp^0.25
+    (1000 in water)."""
+    vp = synth_vp(nz, nx, seed, water_rows).astype(np.float64)
+    vs = vp / np.sqrt(3.0)
+    rho = 310.0 * vp ** 0.25
+    vs[:water_rows] = 0.0
+    rho[:water_rows] = 1000.0
+    return vp.astype(np.float32), vs.astype(np.float32), rho.astype(np.float32)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="acoustic_marmousi", choices=sorted(WORKLOADS))
-    ap.add_argument("--nt", type=int, default=0, help="override time steps (debug only)")
-    ap.add_argument("--shots", type=int, default=0, help="override shots per GPU (debug only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class ElasticMarmousi:
+    """BASELINE.json configs[2]: 2-D elastic Marmousi-II-like Vp/Vs/rho on the reference's
+    100x300 grid at 20 m (networks.py:7314,7555), 32 shots, 3000 steps of 2 ms, 5 Hz source at
+    40 m depth, 276 receivers at 460 m depth (networks.py:7612-7631), 10-node C-PML, L2 misfit on
+    vx and vz, gradients w.r.t. Vp, Vs and rho."""
+    name = "elastic_marmousi2_100x300_32shots_3000steps"
+    nz, nx, h, dt, nt, freq = 100, 300, 20.0, 0.002, 3000, 5.0
+    shots_per_gpu = 32
+    pml = 10
+    fwd_bytes, adj_bytes = 80.0, 80.0    # SURVEY.md 8d: two-launch forward 80 B, adjoint 80 B
 
+    def __init__(self, dev, rank, world, nt=None, shots=None, grid=None):
+        import torch
+        from physicsbasedfwi2_amd import elastic, profiles
+        self.torch, self.elastic, self.dev = torch, elastic, dev
+        if nt:
+            self.nt = nt
+        if grid:
+            self.nz, self.nx = grid
+            self.name = "elastic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, shots or self.shots_per_gpu, self.nt)
+        ns = shots or self.shots_per_gpu
+        self.ns = ns
+        total = ns * world
+        xs_all = np.linspace(380.0, (self.nx - 1) * self.h - 120.0, total)
+        xs = xs_all[rank * ns:(rank + 1) * ns]
+        _, _, sc = profiles.cells_round(xs, np.full(ns, 40.0), self.h, self.nx)
+        xr = np.arange(380.0, min(5880.0, (self.nx - 2) * self.h) + self.h, 20.0)
+        _, _, rc = profiles.cells_round(xr, np.full(xr.size, 460.0), self.h, self.nx)
+        self.nrec = xr.size
+        self.sc = torch.tensor(sc).view(ns, 1, 1)
+        self.sw = torch.ones(ns, 1, 1)
+        self.rc = torch.tensor(rc).view(1, -1, 1).repeat(ns, 1, 1)
+        self.rw = torch.ones(ns, self.nrec, 1)
+        wav = profiles.ricker(self.freq, self.nt, self.dt, 1.0 / self.freq) * (self.dt / self.h ** 2) * 1e9
+        self.f = wav.reshape(-1, 1, 1).repeat(1, ns, 1).to(dev)
+        vmax = 4500.0
+        assert self.dt <= profiles.elastic_cfl_limit(self.h, vmax)
+        self.pz = torch.tensor(profiles.cpml_tables(self.nz, self.pml, self.h, self.dt, 1500.0, 5.0))
+        self.px = torch.tensor(profiles.cpml_tables(self.nx, self.pml, self.h, self.dt, 1500.0, 5.0))
+        self.prm = [torch.tensor(a, device=dev, requires_grad=True)
+                    for a in synth_elastic(self.nz, self.nx, 0)]
+        with torch.no_grad():
+            true = [torch.tensor(a, device=dev) for a in synth_elastic(self.nz, self.nx, 1)]
+            mat = elastic.staggered_materials(*true, self.dt, self.h)
+            self.ox, self.oz = elastic.propagate(mat, self.f, self.pz, self.px, self.sc, self.sw,
+                                                 self.rc, self.rw, self.pml)
+        self._ev = []
+
+    @property
+    def cells_per_launch(self):
+        return self.nz * self.nx * self.ns
+
+    @property
+    def units_per_step(self):
+        return self.nz * self.nx * self.nt * self.ns
+
+    def step(self, timed=False):
+        torch = self.torch
+        for p in self.prm:
+            p.grad = None
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        mat = self.elastic.staggered_materials(*self.prm, self.dt, self.h)
+        ev[0].record()
+        rvx, rvz = self.elastic.propagate(mat, self.f, self.pz, self.px, self.sc, self.sw, self.rc,
+                                          self.rw, self.pml)
+        ev[1].record()
+        dx, dz = rvx - self.ox, rvz - self.oz
+        loss = 0.5 * (dx * dx).sum() + 0.5 * (dz * dz).sum()
+        gx, gz = torch.autograd.grad(loss, [rvx, rvz], retain_graph=True)
+        ev[2].record()
+        torch.autograd.backward([rvx, rvz], [gx, gz])
+        ev[3].record()
+        if timed:
+            self._ev.append(ev)
+        return torch.stack([p.grad for p in self.prm]), loss
+
+    def kernel_times(self):
+        """avg duration (s) of one forward step (V+S launches) and one adjoint step (S^T+V^T)."""
+        tf = np.mean([e[0].elapsed_time(e[1]) for e in self._ev]) * 1e-3
+        tb = np.mean([e[2].elapsed_time(e[3]) for e in self._ev]) * 1e-3
+        return tf / self.nt, tb / self.nt
+
+    def cpu_baseline(self, budget_s=20.0):
+        import oracle
+        from oracle import helpers as H
+        o = oracle.load("f32")
+        cores = os.cpu_count() or 1
+        vp, vs, rho = synth_elastic(self.nz, self.nx, 0)
+        mat = H.elastic_materials(vp, vs, rho, self.dt, self.h)
+        pz = H.cpml_profiles(self.nz, self.pml, self.h, self.dt, 1500.0, 5.0)
+        px = H.cpml_profiles(self.nx, self.pml, self.h, self.dt, 1500.0, 5.0)
+        ns, nt = min(self.ns, cores), 100
+        f = np.zeros((nt, ns, 1), dtype=np.float32)
+        f[:, :, 0] = (H.ricker_deepwave(self.freq, nt, self.dt, 1.0 / self.freq) * 1e6)[:, None]
+        sc = self.sc.numpy()[:ns]
+        rc = self.rc.numpy()[:ns]
+        t0 = time.time()
+        vx, vz, S = o.elastic_forward(mat, pz, px, f, sc, np.ones(sc.shape), rc, np.ones(rc.shape),
+                                      save=True)
+        o.elastic_backward(mat, pz, px, sc, np.ones(sc.shape), rc, np.ones(rc.shape), vx, vz, S)
+        el = time.time() - t0
+        return {"value": self.nz * self.nx * nt * ns / el / 1e6, "unit": "Mcells*steps/s",
+                "cores": cores, "kind": "port",
+                "sample": "%d shots x %d steps of this workload, forward+adjoint, C oracle "
+                          "(oracle/elastic.c, OpenMP over shots), %.1f s" % (ns, nt, el)}
+
+
+class ElasticSEAM(ElasticMarmousi):
+    """BASELINE.json configs[4] per-GPU share: 1000x3000 Vp/Vs/rho, 16 shots, 5000 steps
+    (h = 30 m, dt = 2.5 ms, networks.py:9638,9810).  Snapshots do not fit: time checkpointing."""
+    name = "elastic_seam_1000x3000_16shots_5000steps"
+    nz, nx, h, dt, nt, freq = 1000, 3000, 30.0, 0.0025, 5000, 5.0
+    shots_per_gpu = 16
+
+
+WORKLOADS = {"acoustic_marmousi": AcousticMarmousi, "elastic_marmousi": ElasticMarmousi,
+             "elastic_seam": ElasticSEAM}
+
+
+def run_workload(name, args, dev, rank, world, want_cpu):
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-
-    wl = WORKLOADS[args.workload](dev, rank, world, nt=args.nt or None, shots=args.shots or None)
+    kw = {}
+    if args.grid and name != "acoustic_marmousi":
+        kw["grid"] = tuple(int(v) for v in args.grid.lower().split("x"))
+    wl = WORKLOADS[name](dev, rank, world, nt=args.nt or None, shots=args.shots or None, **kw)
 
     def barrier():
         if world > 1:
@@ -190,34 +298,78 @@ def main():
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    if rank != 0:
+        return None
+    value = wl.units_per_step * world * args.steps / el / 1e6
+    t_f, t_b = wl.kernel_times()
+    cells = wl.cells_per_launch
+    kern = {
+        "forward+save": {"avg_step_s": t_f, "alg_bytes_per_cell_step": wl.fwd_bytes,
+                         "achieved_GBs": wl.fwd_bytes * cells / t_f / 1e9},
+        "adjoint+imaging": {"avg_step_s": t_b, "alg_bytes_per_cell_step": wl.adj_bytes,
+                            "achieved_GBs": wl.adj_bytes * cells / t_b / 1e9},
+    }
+    dom = "adjoint+imaging" if t_b >= t_f else "forward+save"
+    out = {
+        "metric": "grid-cells*timesteps/sec (forward+adjoint gradient pass)",
+        "value": value, "unit": "Mcells*steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": wl.name, "shots_per_gpu": wl.ns, "nt": wl.nt,
+                   "grid": [wl.nz, wl.nx], "parallelism": "shots x%d" % world},
+        "roofline": {"bound": "hbm", "kernel": dom,
+                     "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS,
+                     "traffic": None},
+        "kernels": kern,
+    }
+    if want_cpu:
+        out["cpu_baseline"] = wl.cpu_baseline()
+    del wl
+    torch.cuda.empty_cache()
+    return out
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--nt", type=int, default=0, help="override time steps (debug only)")
+    ap.add_argument("--shots", type=int, default=0, help="override shots per GPU (debug only)")
+    ap.add_argument("--grid", default="", help="NZxNX override for the elastic workloads")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the secondary (elastic) workload of the default invocation")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    want_cpu = (not args.no_cpu_baseline) and world == 1
+    primary = args.workload or "acoustic_marmousi"
+    out = run_workload(primary, args, dev, rank, world, want_cpu)
+    if args.workload is None and not args.no_also:
+        # the north-star roofline target is stated on the elastic stencil: report it alongside
+        also = run_workload("elastic_marmousi", args, dev, rank, world, want_cpu)
+        if rank == 0:
+            out["also"] = [{k: also[k] for k in ("config", "value", "unit", "ms_per_step",
+                                                 "roofline", "kernels", "cpu_baseline")
+                            if k in also}]
     if rank == 0:
-        value = wl.units_per_step * world * args.steps / el / 1e6
-        t_f, t_b = wl.kernel_times()
-        cells = wl.cells_per_launch
-        kern = {
-            "forward+save": {"avg_launch_s": t_f, "alg_bytes_per_cell_step": wl.fwd_bytes,
-                             "achieved_GBs": wl.fwd_bytes * cells / t_f / 1e9},
-            "adjoint+imaging": {"avg_launch_s": t_b, "alg_bytes_per_cell_step": wl.adj_bytes,
-                                "achieved_GBs": wl.adj_bytes * cells / t_b / 1e9},
-        }
-        dom = "adjoint+imaging" if t_b >= t_f else "forward+save"
-        out = {
-            "metric": "grid-cells*timesteps/sec (forward+adjoint gradient pass)",
-            "value": value, "unit": "Mcells*steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": wl.name, "shots_per_gpu": wl.ns, "nt": wl.nt,
-                       "grid": [wl.nz, wl.nx], "parallelism": "shots x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": dom,
-                         "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS,
-                         "traffic": None},
-            "kernels": kern,
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
