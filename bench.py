@@ -164,6 +164,8 @@ class ElasticMarmousi:
         self.torch, self.elastic, self.dev = torch, elastic, dev
         if nt:
             self.nt = nt
+        if os.environ.get("TUNE_PML"):
+            self.pml = int(os.environ["TUNE_PML"])
         if grid:
             self.nz, self.nx = grid
             self.name = "elastic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, shots or self.shots_per_gpu, self.nt)

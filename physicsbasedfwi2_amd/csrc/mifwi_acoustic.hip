@@ -314,6 +314,7 @@ void launch_rz(const mifwi_acoustic_plan *pl, dim3 grid, const AcParams &q, hipS
     switch (pl->rz) {
         case 8: hipLaunchKernelGGL((ac_step<LX, 8, SAVE, IMAGE>), grid, block, 0, st, q); break;
         case 2: hipLaunchKernelGGL((ac_step<LX, 2, SAVE, IMAGE>), grid, block, 0, st, q); break;
+        case 1: hipLaunchKernelGGL((ac_step<LX, 1, SAVE, IMAGE>), grid, block, 0, st, q); break;
         default: hipLaunchKernelGGL((ac_step<LX, 4, SAVE, IMAGE>), grid, block, 0, st, q); break;
     }
 }
@@ -396,7 +397,7 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
     pl->rz = 2;
     // tuning overrides (benchmarks only)
     { const int v = env_int("MIFWI_AC_LX", 0); if (v == 16 || v == 32 || v == 64) pl->lx = v; }
-    { const int v = env_int("MIFWI_AC_RZ", 0); if (v == 2 || v == 4 || v == 8) pl->rz = v; }
+    { const int v = env_int("MIFWI_AC_RZ", 0); if (v == 1 || v == 2 || v == 4 || v == 8) pl->rz = v; }
     int gs = d->shots_per_group;
     if (gs <= 0) gs = env_int("MIFWI_AC_GS", 2);
     if (gs <= 0) gs = 2;

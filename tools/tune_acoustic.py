@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 
-def run(nt, reps=2):
+def run(nt, reps=3):
     dev = torch.device("cuda:0")
     wl = bench.AcousticMarmousi(dev, 0, 1, nt=nt)
     wl.step(False)
@@ -26,7 +26,7 @@ def run(nt, reps=2):
 
 if __name__ == "__main__":
     nt = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-    combos = list(itertools.product([16, 32, 64], [2, 4, 8], [1, 2, 4]))
+    combos = list(itertools.product([16, 32, 64], [1, 2], [1, 2, 4]))
     print("lx rz gs  fwd+save_us  adj_us")
     for lx, rz, gs in combos:
         os.environ["MIFWI_AC_LX"] = str(lx)
