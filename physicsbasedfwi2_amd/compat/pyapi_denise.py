@@ -1,0 +1,345 @@
+"""``import physicsbasedfwi2_amd.compat.pyapi_denise as api`` -- the subset of the (author-modified)
+pyapi_denise protocol that models/networks.py drives (import at line 31; canonical call sequence
+7603-7606, 7665-7666, 7698-7731, 7752-7761, 7787-7802; SEAM variant 9686-9877):
+
+    d = api.Denise(root, verbose=1); d.save_folder = ...; d.set_paths(); d.help()
+    d.NPROCX = 6; d.PHYSICS = 1; d.TIME = 5.0; d.FC_SPIKE_1 = ...          # plain attributes
+    model = api.Model(vp, vs, rho, dx); src = api.Sources(x, y, f); rec = api.Receivers(x, y)
+    d.fwi_stages = []; d.add_fwi_stage(fc_high=10, inv_rho_iter=10000)
+    d.grad(model, src, rec)                      # reference: mpirun of 30 DENISE ranks + files
+    loss = np.loadtxt('loss_curve_grad.out')
+    grads, names = d.get_fwi_gradients(['seis'], return_filenames=True)   # [rho, vp, vs]
+
+Here ``grad`` runs the HIP elastic propagator (forward, stage filter + L2 residual, exact adjoint,
+chain rule to Vp/Vs/rho) on the current HIP device; nothing is written except
+``loss_curve_grad.out`` (the caller reads it back).  Differences a maintainer must know:
+  * observed data come from tensors (``d.set_observed(vx, vy)``) or from SU files through
+    ``read_su`` -- DENISE reads them from ``DATA_DIR`` itself;
+  * MPI decomposition attributes (NPROCX/NPROCY) are accepted and ignored: shots, not
+    sub-domains, are the unit of parallelism (physicsbasedfwi2_amd.dist);
+  * DENISE's binaries are not available to pin against: wavelet, C-PML constants,
+    source scaling and the Butterworth stage filter follow the published formulas, and the
+    gradient is the exact discrete one (the caller rescales it by max|model|/max|grad| anyway,
+    networks.py:7843-7862).
+"""
+import math
+import os
+import struct
+
+import numpy as np
+import torch
+
+from .. import elastic, profiles
+from .._lib import MifwiError
+
+
+class Model:
+    """api.Model(vp, vs, rho, dx): 2-D arrays [ny, nx] in m/s and kg/m^3.  The caller passes them
+    ``np.flipud``-ed (networks.py:7587-7589), i.e. row 0 is the DEEPEST row."""
+
+    def __init__(self, vp, vs, rho, dx):
+        self.vp = np.asarray(vp, dtype=np.float32)
+        self.vs = np.asarray(vs, dtype=np.float32)
+        self.rho = np.asarray(rho, dtype=np.float32)
+        if not (self.vp.shape == self.vs.shape == self.rho.shape) or self.vp.ndim != 2:
+            raise MifwiError("vp, vs, rho must be 2-D arrays of one shape")
+        self.dx = float(dx)
+        self.ny, self.nx = self.vp.shape
+
+    def __repr__(self):
+        return ("vp:\t%s, %.4f, %.4f m/s\nvs:\t%s, %.4f, %.4f m/s\nrho:\t%s, %.4f, %.4f kg/m3\n"
+                "dx:\t%.4f\nSize:\n\tOX:\tmin %.4f\tmax %.4f m\n\tOZ:\tmin %.4f\tmax %.4f m"
+                % (self.vp.shape, self.vp.min(), self.vp.max(), self.vs.shape, self.vs.min(),
+                   self.vs.max(), self.rho.shape, self.rho.min(), self.rho.max(), self.dx, 0.0,
+                   self.nx * self.dx, 0.0, self.ny * self.dx))
+
+
+class _Points:
+    def __init__(self, x, y):
+        self.x = np.atleast_1d(np.asarray(x, dtype=np.float64))
+        self.y = np.atleast_1d(np.asarray(y, dtype=np.float64))
+        if self.x.shape != self.y.shape:
+            raise MifwiError("x and y must have one shape")
+
+    def __len__(self):
+        return int(self.x.size)
+
+
+class Receivers(_Points):
+    """api.Receivers(xrec, yrec): metres, y = depth."""
+
+
+class Sources(_Points):
+    """api.Sources(xsrc, ysrc, fsource): one shot per source; ``f`` = centre frequency [Hz]."""
+
+    def __init__(self, x, y, f, td=0.0, amp=1.0):
+        super().__init__(x, y)
+        self.f = np.broadcast_to(np.asarray(f, dtype=np.float64), self.x.shape).copy()
+        self.td = np.broadcast_to(np.asarray(td, dtype=np.float64), self.x.shape).copy()
+        self.amp = np.broadcast_to(np.asarray(amp, dtype=np.float64), self.x.shape).copy()
+
+
+def ricker_denise(fc, nt, dt, td=0.0):
+    """SOFI2D / DENISE source time function QUELLART=1:
+    tau = pi (t - 1.5/fc - td) / (1.5/fc);  s = (1 - 4 tau^2) exp(-2 tau^2)."""
+    t = np.arange(nt, dtype=np.float64) * dt
+    ts = 1.0 / fc
+    tau = np.pi * (t - 1.5 * ts - td) / (1.5 * ts)
+    return (1.0 - 4.0 * tau * tau) * np.exp(-2.0 * tau * tau)
+
+
+def butterworth(x, dt, fc_low=0.0, fc_high=0.0, order=6):
+    """Zero-phase Butterworth magnitude response applied along time (dim 0) in the frequency
+    domain; differentiable (torch.fft).  fc_high > 0: low-pass corner, fc_low > 0: high-pass corner
+    (both > 0: band-pass), as the FWI-stage filter of ``add_fwi_stage``."""
+    if (not fc_low or fc_low <= 0) and (not fc_high or fc_high <= 0):
+        return x
+    nt = x.shape[0]
+    nfft = 2 * nt
+    f = torch.fft.rfftfreq(nfft, d=dt).to(x.device)
+    h = torch.ones_like(f)
+    if fc_high and fc_high > 0:
+        h = h / torch.sqrt(1.0 + (f / fc_high) ** (2 * order))
+    if fc_low and fc_low > 0:
+        h = h * torch.sqrt(1.0 / (1.0 + (fc_low / torch.clamp(f, min=1e-12)) ** (2 * order)))
+    spec = torch.fft.rfft(x, n=nfft, dim=0) * h.view(-1, *([1] * (x.dim() - 1)))
+    return torch.fft.irfft(spec, n=nfft, dim=0)[:nt]
+
+
+def read_su(path):
+    """Minimal SU reader (240-byte trace header + ns native float32 samples, as DENISE writes):
+    returns (data [ntraces, ns], dt seconds)."""
+    raw = open(path, "rb").read()
+    ns = struct.unpack_from("<H", raw, 114)[0]
+    dt_us = struct.unpack_from("<H", raw, 116)[0]
+    tl = 240 + 4 * ns
+    ntr = len(raw) // tl
+    out = np.empty((ntr, ns), dtype=np.float32)
+    for i in range(ntr):
+        out[i] = np.frombuffer(raw, dtype="<f4", count=ns, offset=i * tl + 240)
+    return out, dt_us * 1e-6
+
+
+def write_su(path, data, dt):
+    """Inverse of :func:`read_su` (tests and hand-over of synthetic observed data)."""
+    data = np.asarray(data, dtype="<f4")
+    with open(path, "wb") as fh:
+        for i, tr in enumerate(data):
+            hdr = bytearray(240)
+            struct.pack_into("<i", hdr, 0, i + 1)
+            struct.pack_into("<H", hdr, 114, tr.size)
+            struct.pack_into("<H", hdr, 116, int(round(dt * 1e6)))
+            fh.write(bytes(hdr))
+            fh.write(tr.tobytes())
+
+
+def _nice_dt(limit):
+    """Largest of {1, 2, 2.5, 4, 5} x 10^k below 0.9 * limit."""
+    target = 0.9 * limit
+    k = math.floor(math.log10(target))
+    best = 0.0
+    for kk in (k - 1, k):
+        for m in (1.0, 2.0, 2.5, 4.0, 5.0):
+            v = m * 10.0 ** kk
+            if v <= target:
+                best = max(best, v)
+    return best
+
+
+class Denise:
+    """Stand-in for pyapi_denise.Denise: attribute bag + forward / grad on the HIP propagator."""
+
+    def __init__(self, root=None, verbose=1, device=None):
+        self.root = root
+        self.verbose = verbose
+        self.device = device
+        self.save_folder = "./outputs/"
+        # the pyapi attributes the reference touches (defaults follow pyapi_denise / DENISE.inp)
+        self.PHYSICS = 1
+        self.TIME = 6.0
+        self.DT = None
+        self.NPROCX = 1
+        self.NPROCY = 1
+        self.FD_ORDER = 4
+        self.FW = 10
+        self.DAMPING = 1500.0
+        self.FPML = 10.0
+        self.npower = 4.0
+        self.k_max_PML = 1.0
+        self.FREE_SURF = 1
+        self.QUELLART = 1
+        self.QUELLTYP = 1
+        self.QUELLTYPB = 1
+        self.FC_SPIKE_1 = -5.0
+        self.FC_SPIKE_2 = 15.0
+        self.ORDER_SPIKE = 5
+        self.SEISMO = 1
+        self.ITERMAX = 1
+        self.DATA_DIR = None
+        self.SEIS_FILE_VX = None
+        self.SEIS_FILE_VY = None
+        self.VPUPPERLIM = 6000.0
+        self.VPLOWERLIM = 0.0
+        self.VSUPPERLIM = 4000.0
+        self.VSLOWERLIM = 0.0
+        self.RHOUPPERLIM = 3000.0
+        self.RHOLOWERLIM = 1000.0
+        self.SWS_TAPER_GRAD_HOR = 0
+        self.EXP_TAPER_GRAD_HOR = 2.0
+        self.fwi_stages = []
+        self._observed = None
+        self._gradients = None
+        self._shots = None
+        self.loss = None
+
+    # -- protocol no-ops ------------------------------------------------------------------------
+    def set_paths(self, *a, **k):
+        return None
+
+    def help(self, *a, **k):
+        if self.verbose:
+            print("physicsbasedfwi2_amd pyapi_denise shim: attributes are plain Python fields")
+
+    def add_fwi_stage(self, fc_low=0.0, fc_high=0.0, inv_vp_iter=0, inv_vs_iter=0,
+                      inv_rho_iter=0, lnorm=2, order=6, **kw):
+        stage = dict(fc_low=fc_low, fc_high=fc_high, inv_vp_iter=inv_vp_iter,
+                     inv_vs_iter=inv_vs_iter, inv_rho_iter=inv_rho_iter, lnorm=lnorm, order=order)
+        stage.update(kw)
+        self.fwi_stages.append(stage)
+
+    # -- observed data ----------------------------------------------------------------------------
+    def set_observed(self, vx, vy):
+        """Observed particle velocities, each [nshot, nt, nrec] (array or tensor), in shot order of
+        the ``Sources`` passed to :meth:`grad`."""
+        self._observed = (torch.as_tensor(np.asarray(vx) if not torch.is_tensor(vx) else vx).float(),
+                          torch.as_tensor(np.asarray(vy) if not torch.is_tensor(vy) else vy).float())
+
+    def load_observed_su(self, nshots):
+        """DENISE layout: DATA_DIR + '_x.su.shot<k>' / '_y.su.shot<k>' (networks.py:7690-7692)."""
+        vx, vy = [], []
+        for k in range(1, nshots + 1):
+            ax, _ = read_su("%s_x.su.shot%d" % (self.DATA_DIR, k))
+            ay, _ = read_su("%s_y.su.shot%d" % (self.DATA_DIR, k))
+            vx.append(ax.T)
+            vy.append(ay.T)
+        self.set_observed(np.stack(vx), np.stack(vy))
+
+    # -- numerics -----------------------------------------------------------------------------------
+    def _setup(self, model, src, rec):
+        if self.PHYSICS != 1:
+            raise MifwiError("only PHYSICS=1 (P-SV elastic) is implemented")
+        if int(self.FREE_SURF) != 0:
+            raise MifwiError("FREE_SURF=1 is not implemented in this build: set d.FREE_SURF = 0 "
+                             "(C-PML on all four sides)")
+        dev = torch.device(self.device) if self.device is not None else \
+            torch.device("cuda", torch.cuda.current_device())
+        h = model.dx
+        vmax = float(model.vp.max())
+        limit = profiles.elastic_cfl_limit(h, vmax)
+        dt = float(self.DT) if self.DT else _nice_dt(limit)
+        if dt > limit:
+            raise MifwiError("DT=%g s violates the stability limit %g s (h=%g m, vp_max=%g m/s)"
+                             % (dt, limit, h, vmax))
+        nt = int(round(self.TIME / dt))
+        nz, nx = model.ny, model.nx
+        _, _, sc = profiles.cells_round(src.x, src.y, h, nx)
+        _, _, rc = profiles.cells_round(rec.x, rec.y, h, nx)
+        ns, nr = len(src), len(rec)
+        geom = dict(
+            sc=torch.tensor(sc).view(ns, 1, 1), sw=torch.ones(ns, 1, 1),
+            rc=torch.tensor(rc).view(1, nr, 1).repeat(ns, 1, 1), rw=torch.ones(ns, nr, 1))
+        if self.QUELLART == 1:
+            wav = np.stack([ricker_denise(src.f[i], nt, dt, src.td[i]) * src.amp[i]
+                            for i in range(ns)], axis=1)
+        else:
+            raise MifwiError("QUELLART=%s not implemented (1 = Ricker)" % self.QUELLART)
+        # explosive source: moment-rate density added to sxx and szz
+        f = torch.tensor(wav * (dt / (h * h)), dtype=torch.float32).view(nt, ns, 1)
+        fw = int(self.FW)
+        pz = torch.tensor(profiles.cpml_tables(nz, fw, h, dt, self.DAMPING, self.FPML, self.npower,
+                                               self.k_max_PML))
+        px = torch.tensor(profiles.cpml_tables(nx, fw, h, dt, self.DAMPING, self.FPML, self.npower,
+                                               self.k_max_PML))
+        return dev, h, dt, nt, geom, f, pz, px, fw
+
+    def _materials(self, model, dev, dt, h, requires_grad):
+        # undo the caller's flipud: internally row 0 is the surface
+        prm = [torch.tensor(np.flipud(a).copy(), device=dev, requires_grad=requires_grad)
+               for a in (model.vp, model.vs, model.rho)]
+        return prm, elastic.staggered_materials(prm[0], prm[1], prm[2], dt, h)
+
+    def forward(self, model, src, rec):
+        """Forward modelling; seismograms are kept in memory (``get_shots``)."""
+        dev, h, dt, nt, g, f, pz, px, fw = self._setup(model, src, rec)
+        with torch.no_grad():
+            _, mat = self._materials(model, dev, dt, h, False)
+            vx, vy = elastic.propagate(mat, f.to(dev), pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw)
+        self._shots = (vx.permute(1, 2, 0).cpu().numpy(), vy.permute(1, 2, 0).cpu().numpy())
+        self.DT_used = dt
+        return self._shots
+
+    def get_shots(self, keys=("_y",), return_filenames=False):
+        """List of [nrec, nt] arrays, one per shot, for the component named in ``keys``."""
+        if self._shots is None:
+            raise MifwiError("run forward() first")
+        comp = 0 if any("_x" in k for k in keys) else 1
+        out = [a for a in self._shots[comp]]
+        names = ["su/seis%s.su.shot%d" % ("_x" if comp == 0 else "_y", i + 1) for i in range(len(out))]
+        return (out, names) if return_filenames else out
+
+    def grad(self, model, src, rec):
+        """One gradient evaluation (ITERMAX=1): forward, stage filter, L2 residual against the
+        observed data, exact adjoint, chain rule to (Vp, Vs, rho).  Writes ./loss_curve_grad.out."""
+        if self._observed is None:
+            if self.DATA_DIR:
+                self.load_observed_su(len(src))
+            else:
+                raise MifwiError("no observed data: call set_observed(vx, vy) or set DATA_DIR")
+        dev, h, dt, nt, g, f, pz, px, fw = self._setup(model, src, rec)
+        prm, mat = self._materials(model, dev, dt, h, True)
+        vx, vy = elastic.propagate(mat, f.to(dev), pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw)
+        ox, oy = (o.to(dev).permute(1, 0, 2) for o in self._observed)     # -> [nt, ns, nrec]
+        if ox.shape != vx.shape:
+            raise MifwiError("observed data %s do not match modelled %s (nt, nshot, nrec)"
+                             % (tuple(ox.shape), tuple(vx.shape)))
+        st = self.fwi_stages[-1] if self.fwi_stages else dict(fc_low=0.0, fc_high=0.0, order=6, lnorm=2)
+        fl = lambda a: butterworth(a, dt, st.get("fc_low", 0.0), st.get("fc_high", 0.0),
+                                   st.get("order", 6))
+        rx, ry = fl(vx) - fl(ox), fl(vy) - fl(oy)
+        if self.QUELLTYPB == 2:
+            loss = 0.5 * (ry * ry).sum()
+        else:
+            loss = 0.5 * (rx * rx).sum() + 0.5 * (ry * ry).sum()
+        loss.backward()
+        self.loss = float(loss)
+        with open("loss_curve_grad.out", "w") as fh:
+            fh.write("%e\n" % self.loss)
+        # re-apply the caller's flipud convention on the way out
+        gvp, gvs, grho = (np.flipud(p.grad.detach().cpu().numpy()).copy() for p in prm)
+        self._gradients = {"rho": grho, "vp": gvp, "vs": gvs}
+        self.DT_used = dt
+        return self.loss
+
+    def get_fwi_gradients(self, keys=("seis",), return_filenames=False):
+        """Arrays in filename order: jacobian/..._rho, ..._vp, ..._vs  =>  [rho, vp, vs]
+        (the order models/networks.py:7800-7802 indexes)."""
+        if self._gradients is None:
+            raise MifwiError("run grad() first")
+        names = ["jacobian/gradient_seis_rho.bin", "jacobian/gradient_seis_vp.bin",
+                 "jacobian/gradient_seis_vs.bin"]
+        sel = [n for n in names if all(k in n for k in keys)]
+        out = [self._gradients[n.rsplit("_", 1)[1].split(".")[0]] for n in sel]
+        return (out, sel) if return_filenames else out
+
+
+def gradients_allreduce(d, group=None):
+    """Shot-parallel use: every rank calls ``d.grad`` on its block of sources, then this sums the
+    three gradients and the loss over ranks with ONE all-reduce (physicsbasedfwi2_amd.dist)."""
+    from .. import dist as mdist
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu"
+    ts = [torch.tensor(d._gradients[k], device=dev) for k in ("rho", "vp", "vs")]
+    ts, loss = mdist.all_reduce_gradient(ts, d.loss, group)
+    for k, t in zip(("rho", "vp", "vs"), ts):
+        d._gradients[k] = t.cpu().numpy()
+    d.loss = float(loss)
+    return d

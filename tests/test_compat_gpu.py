@@ -1,0 +1,148 @@
+"""Drop-in boundary tests: the pyapi_denise-shaped and seisgan-shaped call protocols run on the
+HIP propagator and agree with the CPU oracle composed the same way."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cases import rel_l2
+from oracle import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _denise_setup(tmp_path):
+    import physicsbasedfwi2_amd.compat.pyapi_denise as api
+    rng = np.random.default_rng(3)
+    nz, nx, dx = 60, 90, 20.0
+    vp = (1800 + 1200 * rng.random((nz, nx))).astype(np.float32)
+    vs = (vp / np.sqrt(3)).astype(np.float32)
+    rho = (1900 + 300 * rng.random((nz, nx))).astype(np.float32)
+    vs[:8] = 0; vp[:8] = 1500; rho[:8] = 1000
+    d = api.Denise("/nonexistent", verbose=0)
+    d.save_folder = str(tmp_path)
+    d.set_paths()
+    d.help()
+    d.NPROCX, d.NPROCY, d.PHYSICS, d.ITERMAX = 6, 5, 1, 1
+    d.TIME, d.DT, d.FREE_SURF, d.FW, d.FPML, d.DAMPING = 0.5, 0.002, 0, 10, 5.0, 1500.0
+    xsrc = np.array([400.0, 1000.0, 1400.0])
+    src = api.Sources(xsrc, 40.0 * xsrc / xsrc, 8.0)
+    xrec = np.arange(300.0, 1500.0 + dx, 40.0)
+    rec = api.Receivers(xrec, 460.0 * (xrec / xrec))
+    return api, d, (vp, vs, rho), dx, src, rec
+
+
+def test_denise_forward_matches_oracle(oracle32, tmp_path):
+    api, d, (vp, vs, rho), dx, src, rec = _denise_setup(tmp_path)
+    model = api.Model(np.flipud(vp), np.flipud(vs), np.flipud(rho), dx)
+    sx, sy = d.forward(model, src, rec)
+    assert sx.shape == (3, len(rec), 250) and len(d.get_shots(keys=["_y"])) == 3
+    dt = 0.002
+    mat = H.elastic_materials(vp, vs, rho, dt, dx)
+    nz, nx = vp.shape
+    pz, px = H.cpml_profiles(nz, 10, dx, dt, 1500.0, 5.0), H.cpml_profiles(nx, 10, dx, dt, 1500.0, 5.0)
+    f = np.stack([api.ricker_denise(8.0, 250, dt)] * 3, axis=1)[:, :, None] * (dt / dx ** 2)
+    iz = np.floor(src.y / dx + 0.5).astype(int) - 1
+    ix = np.floor(src.x / dx + 0.5).astype(int) - 1
+    sc, sw = H.cell_taps(iz[:, None], ix[:, None], nx)
+    rz = np.floor(rec.y / dx + 0.5).astype(int) - 1
+    rx = np.floor(rec.x / dx + 0.5).astype(int) - 1
+    rc, rw = H.cell_taps(np.tile(rz, (3, 1)), np.tile(rx, (3, 1)), nx)
+    ovx, ovz = oracle32.elastic_forward(mat, pz, px, f, sc, sw, rc, rw)
+    assert np.abs(ovz).max() > 0
+    assert rel_l2(np.transpose(sy, (2, 0, 1)), ovz) < 1e-5
+    assert rel_l2(np.transpose(sx, (2, 0, 1)), ovx) < 1e-5
+
+
+def test_denise_grad_protocol_and_directional_derivative(tmp_path, monkeypatch):
+    api, d, (vp, vs, rho), dx, src, rec = _denise_setup(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    true = api.Model(np.flipud(vp * 1.03), np.flipud(vs * 0.98), np.flipud(rho), dx)
+    ox, oy = d.forward(true, src, rec)
+    d.set_observed(np.transpose(ox, (0, 2, 1)), np.transpose(oy, (0, 2, 1)))
+    d.fwi_stages = []
+    d.add_fwi_stage(fc_high=10, inv_rho_iter=10000)
+    model = api.Model(np.flipud(vp), np.flipud(vs), np.flipud(rho), dx)
+    d.grad(model, src, rec)
+    loss = float(np.loadtxt("loss_curve_grad.out"))
+    assert loss > 0 and np.isclose(loss, d.loss, rtol=1e-5)
+    grads, names = d.get_fwi_gradients(["seis"], return_filenames=True)
+    assert [n.split("_")[-1] for n in names] == ["rho.bin", "vp.bin", "vs.bin"]      # networks.py:7800-7802
+    g_rho, g_vp, g_vs = (np.flipud(g) for g in grads)                                # caller's flipud
+    assert g_vp.shape == vp.shape and np.isfinite(g_vp).all() and np.abs(g_vp).max() > 0
+    # directional derivative along a smooth vp perturbation below the water layer
+    dv = np.zeros_like(vp)
+    dv[20:40, 30:60] = 30.0
+    lin = float(np.sum(g_vp * dv))
+    eps = 0.5
+    lp = api.Denise(None, 0); lm = api.Denise(None, 0)
+    vals = []
+    for sgn in (+1, -1):
+        dd = api.Denise(None, 0)
+        for k in ("TIME", "DT", "FREE_SURF", "FW", "FPML", "DAMPING"):
+            setattr(dd, k, getattr(d, k))
+        dd.set_observed(np.transpose(ox, (0, 2, 1)), np.transpose(oy, (0, 2, 1)))
+        dd.add_fwi_stage(fc_high=10, inv_rho_iter=10000)
+        vals.append(dd.grad(api.Model(np.flipud(vp + sgn * eps * dv), np.flipud(vs), np.flipud(rho), dx),
+                            src, rec))
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - lin) <= 0.03 * abs(fd), (fd, lin)
+
+
+def test_su_roundtrip(tmp_path):
+    import physicsbasedfwi2_amd.compat.pyapi_denise as api
+    a = np.random.default_rng(0).standard_normal((7, 33)).astype(np.float32)
+    api.write_su(str(tmp_path / "x.su"), a, 0.002)
+    b, dt = api.read_su(str(tmp_path / "x.su"))
+    assert np.array_equal(a, b) and abs(dt - 0.002) < 1e-9
+
+
+def test_seisgan_fwiloss_matches_oracle(oracle32):
+    from physicsbasedfwi2_amd.compat.seisgan_fwi import FWIConfiguration, FWILoss
+    rng = np.random.default_rng(5)
+    nx, nz, nb = 50, 40, 10
+    cfg = dict(origin=(0., 0.), shape=(nx, nz), spacing=(10., 10.), nbpml=nb, nshots=3,
+               source_min_x=50., source_min_y=20., tn=400., t0=0., f0=0.015, nreceivers=24,
+               rec_min_y=20., noise_percent=0.0)
+    vp_true = 1.5 + 1.5 * rng.random((nx, nz))
+    vp_0 = 1.5 + 1.5 * rng.random((nx, nz))
+    m_true = (1.0 / vp_true ** 2).astype(np.float32)
+    m0 = (1.0 / vp_0 ** 2).astype(np.float32)
+    conf = FWIConfiguration(cfg, m_true)
+    x = torch.tensor(m0[None, None], device="cuda:0", requires_grad=True)
+    lossfn = FWILoss(conf)
+    loss = lossfn(x)
+    loss.backward()
+    # --- oracle, composed by hand ---------------------------------------------------------------
+    h = (10., 10.)
+    dt = H.critical_dt(h, 1.0 / np.sqrt(m_true.min()))
+    nt, _ = H.time_axis_num(0.0, 400.0, dt)
+    assert nt == conf.nt and np.isclose(dt, conf.dt)
+    t = np.linspace(0.0, dt * (nt - 1), nt)
+    src = H.ricker_seisgan(0.015, t)
+    N0, N1 = nx + 2 * nb, nz + 2 * nb
+    d0, d1 = H.damp_profile_1d(N0, nb, 10.), H.damp_profile_1d(N1, nb, 10.)
+    f = np.zeros((nt, 3, 1)); f[:nt - 2, :, 0] = (src[1:nt - 1] * 100.0)[:, None]
+    sxy = np.zeros((3, 1, 2)); sxy[:, 0, 0] = np.linspace(50., 10. * nx - 50., 3); sxy[:, 0, 1] = 20.
+    rxy = np.zeros((3, 24, 2)); rxy[:, :, 0] = np.linspace(0, 24 * 10., 24)[None]; rxy[:, :, 1] = 20.
+    sc, sw = H.bilinear_taps(sxy, h, nb, (N0, N1))
+    rc, rw = H.bilinear_taps(rxy, h, nb, (N0, N1))
+
+    def run(m):
+        r, q0, q1, c0, c1 = H.acoustic_coeffs(H.pad_edge(m.astype(np.float64), nb), d0, d1, dt, h)
+        rec, G = oracle32.acoustic_forward(r, q0, q1, f, sc, sw, rc, rw, c0, c1, save=True)
+        syn = np.zeros_like(rec); syn[1:nt - 1] = rec[0:nt - 2]
+        return r, q0, q1, syn, G
+    _, _, _, obs, _ = run(m_true)
+    r, q0, q1, syn, G = run(m0)
+    res = syn - obs
+    J = 0.5 * np.sum(res.astype(np.float64) ** 2)
+    assert abs(float(loss) - J) <= 2e-4 * J
+    g = np.zeros_like(res); g[0:nt - 2] = res[1:nt - 1]
+    gr, _ = oracle32.acoustic_backward(r, q0, q1, sc, sw, rc, rw, g, G, want_grad_f=False)
+    mp = H.pad_edge(m0.astype(np.float64), nb)
+    gm = (gr * (-(dt * dt / 100.0) / mp ** 2))[nb:-nb, nb:-nb]
+    gm = gm / np.abs(gm).max()
+    assert rel_l2(x.grad[0, 0].cpu().numpy(), gm) < 2e-3
+    assert float(x.grad.abs().max()) == pytest.approx(1.0)
