@@ -141,7 +141,9 @@ typedef struct {
     int32_t nt, nshot, nsrc, nrec, ntap;
     int32_t pml_width;       /* C-PML nodes per side (0 = none); profiles may still be zero
                                 on a side (e.g. free surface)                                 */
-    int32_t free_surface;    /* reserved, must be 0                                           */
+    int32_t free_surface;    /* 1: stress-imaging free surface on row 0 (DENISE FREE_SURF): szz = 0
+                                there, stresses mirrored oddly above it; the caller passes row 0 of
+                                mat[0..1] in the effective form (0, M - L^2/M)                    */
     int32_t shots_per_group; /* adjoint: shots sharing one gradient accumulator; 0 = auto     */
 } mifwi_elastic_desc;
 

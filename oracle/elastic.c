@@ -35,6 +35,13 @@
  *       sxz += mus (Dp_z vx ' + Dp_x vz ')
  *   source: sxx, szz [cell] += w f[n] ;  receivers: rec_v*[n] = sum w v*[cell]  (after V)
  * Saved per step for the gradient (S, 5 arrays): e1', e2', e3'+e4', d1'+d2', d3'+d4'.
+ *
+ * free_surface = 1 (DENISE FREE_SURF, networks.py:9811): row 0 is the free surface (szz = 0 there).
+ *   V reads the stresses above it by odd mirroring: szz(-m) = -szz(m), sxz(-m) = -sxz(m-1), m = 1,2;
+ *   S keeps szz(0,.) = 0 and updates sxx(0,.) with Ms - Ls^2/Ms (the caller passes row 0 of the
+ *   material arrays already in that effective form: Ms_eff = Ms - Ls^2/Ms, Ls_eff = 0);
+ *   velocities above the surface are zero.  The adjoint transposes exactly this: the adjoint of
+ *   szz(0,.) is discarded in S^T, and V^T adds the mirrored scatter terms on rows 0..1.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -54,7 +61,7 @@ typedef float real;
 
 typedef struct {
     int nz, nx, nt, nshot, nsrc, nrec, ntap;
-    int free_surface;       /* reserved: must be 0 */
+    int free_surface;       /* 1: stress-imaging free surface on row 0 (see header) */
 } oracle_elastic_cfg;
 
 typedef struct {
@@ -150,7 +157,7 @@ int oracle_elastic_forward(const oracle_elastic_cfg *c, const real *mat, const r
                            const int *rec_cell, const real *rec_w, real *rec_vx, real *rec_vz,
                            real *S)
 {
-    if (c->free_surface) return 2;
+    if (c->free_surface && c->nz < 3) return 2;
     geom g = {c->nz, c->nx, (size_t)(c->nx + 2 * HALO), 0};
     g.n = (size_t)(c->nz + 2 * HALO) * g.p;
     const int ns = c->nshot, nx = c->nx;
@@ -163,8 +170,17 @@ int oracle_elastic_forward(const oracle_elastic_cfg *c, const real *mat, const r
         if (state_alloc(&st, &g)) { status = 1; state_free(&st); continue; }
         for (int n = 0; n < c->nt; ++n) {
             real *Sn = S ? S + ((size_t)n * ns + s) * 5 * nc : NULL;
+            if (c->free_surface)
+                for (int i = 0; i < nx; ++i) {
+                    st.szz[at(&g, -1, i)] = -st.szz[at(&g, 1, i)];
+                    st.szz[at(&g, -2, i)] = c->nz > 2 ? -st.szz[at(&g, 2, i)] : 0;
+                    st.sxz[at(&g, -1, i)] = -st.sxz[at(&g, 0, i)];
+                    st.sxz[at(&g, -2, i)] = -st.sxz[at(&g, 1, i)];
+                }
             step_v(&g, mat, pz, px, &st, Sn);
             step_s(&g, mat, pz, px, &st, Sn);
+            if (c->free_surface)
+                for (int i = 0; i < nx; ++i) st.szz[at(&g, 0, i)] = 0;
             for (int is = 0; is < c->nsrc; ++is) {
                 const real amp = f[((size_t)n * ns + s) * c->nsrc + is];
                 for (int t = 0; t < c->ntap; ++t) {
@@ -206,7 +222,7 @@ int oracle_elastic_backward(const oracle_elastic_cfg *c, const real *mat, const 
                             const int *rec_cell, const real *rec_w, const real *g_vx,
                             const real *g_vz, const real *S, real *grad_mat, real *grad_f)
 {
-    if (c->free_surface) return 2;
+    if (c->free_surface && c->nz < 3) return 2;
     geom g = {c->nz, c->nx, (size_t)(c->nx + 2 * HALO), 0};
     g.n = (size_t)(c->nz + 2 * HALO) * g.p;
     const int ns = c->nshot, nx = c->nx, nz = c->nz;
@@ -239,6 +255,9 @@ int oracle_elastic_backward(const oracle_elastic_cfg *c, const real *mat, const 
                     st.vz[k] += rec_w[e] * gz;
                 }
             }
+            /* free surface: szz(0,.) is identically 0 in the forward run, its adjoint is discarded */
+            if (c->free_surface)
+                for (int i = 0; i < nx; ++i) st.szz[at(&g, 0, i)] = 0;
             /* b. source^T */
             if (grad_f)
                 for (int is = 0; is < c->nsrc; ++is) {
@@ -297,6 +316,13 @@ int oracle_elastic_backward(const oracle_elastic_cfg *c, const real *mat, const 
                     st.sxx[k] = st.sxx[k] - DMX(T[0], k);
                     st.sxz[k] = st.sxz[k] - (DPZ(T[1], k, p) + DPX(T[2], k));
                     st.szz[k] = st.szz[k] - DMZ(T[3], k, p);
+                }
+            if (c->free_surface)       /* transposed odd mirroring of the stresses read by V */
+                for (int i = 0; i < nx; ++i) {
+                    const size_t k0 = at(&g, 0, i), k1 = at(&g, 1, i);
+                    st.sxz[k0] = st.sxz[k0] + FMA(C1, T[1][k0], C2 * T[1][k1]);
+                    st.sxz[k1] = st.sxz[k1] + C2 * T[1][k0];
+                    st.szz[k1] = st.szz[k1] + C2 * T[3][k0];
                 }
         }
         state_free(&st);

@@ -174,8 +174,9 @@ def cpml_profiles(n, fw, h, dt, vpml, fpml, npower=4.0, kmax=1.0, lo=True, hi=Tr
     return out
 
 
-def elastic_materials(vp, vs, rho, dt, h):
-    """Staggered, dt/h-scaled material arrays [5][nz][nx] = Ls, Ms, mus, bxs, bzs (numpy)."""
+def elastic_materials(vp, vs, rho, dt, h, free_surface=False):
+    """Staggered, dt/h-scaled material arrays [5][nz][nx] = Ls, Ms, mus, bxs, bzs (numpy).
+    free_surface: row 0 of (Ls, Ms) in the effective form Ls = 0, Ms = Ms - Ls^2/Ms."""
     vp, vs, rho = (np.asarray(a, dtype=np.float64) for a in (vp, vs, rho))
     mu = rho * vs ** 2
     lam = rho * vp ** 2 - 2.0 * mu
@@ -191,4 +192,9 @@ def elastic_materials(vp, vs, rho, dt, h):
         anyzero |= (m == 0)
     with np.errstate(divide="ignore"):
         muxz = np.where(anyzero, 0.0, 4.0 / sum(1.0 / np.where(m == 0, 1.0, m) for m in m4))
-    return np.stack([lam * s, (lam + 2 * mu) * s, muxz * s, s / rx, s / rz])
+    Ls, Ms = lam * s, (lam + 2 * mu) * s
+    if free_surface:
+        Ms = Ms.copy(); Ls = Ls.copy()
+        Ms[0] = Ms[0] - Ls[0] ** 2 / Ms[0]
+        Ls[0] = 0.0
+    return np.stack([Ls, Ms, muxz * s, s / rx, s / rz])

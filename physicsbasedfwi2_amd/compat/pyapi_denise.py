@@ -228,9 +228,6 @@ class Denise:
     def _setup(self, model, src, rec):
         if self.PHYSICS != 1:
             raise MifwiError("only PHYSICS=1 (P-SV elastic) is implemented")
-        if int(self.FREE_SURF) != 0:
-            raise MifwiError("FREE_SURF=1 is not implemented in this build: set d.FREE_SURF = 0 "
-                             "(C-PML on all four sides)")
         dev = torch.device(self.device) if self.device is not None else \
             torch.device("cuda", torch.cuda.current_device())
         h = model.dx
@@ -256,24 +253,26 @@ class Denise:
         # explosive source: moment-rate density added to sxx and szz
         f = torch.tensor(wav * (dt / (h * h)), dtype=torch.float32).view(nt, ns, 1)
         fw = int(self.FW)
+        fsurf = bool(int(self.FREE_SURF))
         pz = torch.tensor(profiles.cpml_tables(nz, fw, h, dt, self.DAMPING, self.FPML, self.npower,
-                                               self.k_max_PML))
+                                               self.k_max_PML, low=not fsurf))
         px = torch.tensor(profiles.cpml_tables(nx, fw, h, dt, self.DAMPING, self.FPML, self.npower,
                                                self.k_max_PML))
-        return dev, h, dt, nt, geom, f, pz, px, fw
+        return dev, h, dt, nt, geom, f, pz, px, fw, fsurf
 
-    def _materials(self, model, dev, dt, h, requires_grad):
+    def _materials(self, model, dev, dt, h, requires_grad, fsurf=False):
         # undo the caller's flipud: internally row 0 is the surface
         prm = [torch.tensor(np.flipud(a).copy(), device=dev, requires_grad=requires_grad)
                for a in (model.vp, model.vs, model.rho)]
-        return prm, elastic.staggered_materials(prm[0], prm[1], prm[2], dt, h)
+        return prm, elastic.staggered_materials(prm[0], prm[1], prm[2], dt, h, free_surface=fsurf)
 
     def forward(self, model, src, rec):
         """Forward modelling; seismograms are kept in memory (``get_shots``)."""
-        dev, h, dt, nt, g, f, pz, px, fw = self._setup(model, src, rec)
+        dev, h, dt, nt, g, f, pz, px, fw, fsurf = self._setup(model, src, rec)
         with torch.no_grad():
-            _, mat = self._materials(model, dev, dt, h, False)
-            vx, vy = elastic.propagate(mat, f.to(dev), pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw)
+            _, mat = self._materials(model, dev, dt, h, False, fsurf)
+            vx, vy = elastic.propagate(mat, f.to(dev), pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw,
+                                       free_surface=fsurf)
         self._shots = (vx.permute(1, 2, 0).cpu().numpy(), vy.permute(1, 2, 0).cpu().numpy())
         self.DT_used = dt
         return self._shots
@@ -295,9 +294,10 @@ class Denise:
                 self.load_observed_su(len(src))
             else:
                 raise MifwiError("no observed data: call set_observed(vx, vy) or set DATA_DIR")
-        dev, h, dt, nt, g, f, pz, px, fw = self._setup(model, src, rec)
-        prm, mat = self._materials(model, dev, dt, h, True)
-        vx, vy = elastic.propagate(mat, f.to(dev), pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw)
+        dev, h, dt, nt, g, f, pz, px, fw, fsurf = self._setup(model, src, rec)
+        prm, mat = self._materials(model, dev, dt, h, True, fsurf)
+        vx, vy = elastic.propagate(mat, f.to(dev), pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw,
+                                   free_surface=fsurf)
         ox, oy = (o.to(dev).permute(1, 0, 2) for o in self._observed)     # -> [nt, ns, nrec]
         if ox.shape != vx.shape:
             raise MifwiError("observed data %s do not match modelled %s (nt, nshot, nrec)"

@@ -45,6 +45,7 @@ struct ElParams {
     long long shot_stride;       // 5*field_stride
     int nshot, gs;
     int W, wl, xr0, wx;          // C-PML strip geometry; W = 0 disables the layer
+    int fsurf;                   // 1: stress-imaging free surface on row 0
     long long psix_shot, psiz_shot;   // floats per shot: 4*nz*wx, 4*2W*gp
     const float *mat, *pz, *px;
     float *fields;
@@ -64,10 +65,6 @@ struct ElParams {
     const float *smp_w;
     float *smp_out0, *smp_out1;
     int tiles_z;
-    // fused tile kernels: ping-pong state buffers and owned tile size
-    const float *fin;
-    float *fout;
-    int TZ, TG;
 };
 
 __device__ __forceinline__ float comp(const float4 &v, int c)
@@ -144,7 +141,8 @@ __device__ void sample_points(const ElParams &p)
                 a0 = fmaf(w, fl[F_VX * p.field_stride + off], a0);
                 a1 = fmaf(w, fl[F_VZ * p.field_stride + off], a1);
             } else {
-                a0 = fmaf(w, fl[F_SXX * p.field_stride + off] + fl[F_SZZ * p.field_stride + off], a0);
+                const float zz = (p.fsurf && j == 0) ? 0.f : fl[F_SZZ * p.field_stride + off];
+                a0 = fmaf(w, fl[F_SXX * p.field_stride + off] + zz, a0);
             }
         }
         p.smp_out0[(long long)s * p.nsmp + ip] = a0;
@@ -200,7 +198,8 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
     const unsigned col = 4 + 4 * g;
     const unsigned ncell = (unsigned)p.nz * p.gp;
     const int xs_off = xstrip(p, g);
-    float4 pxa, pxb, pxk, pxah, pxbh, pxkh;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pxa = zero4, pxb = zero4, pxk = zero4, pxah = zero4, pxbh = zero4, pxkh = zero4;
     if (xs_off >= 0) {
         pxa = ld4(p.px + PA * p.gp + 4 * g); pxb = ld4(p.px + PB * p.gp + 4 * g);
         pxk = ld4(p.px + PK * p.gp + 4 * g); pxah = ld4(p.px + PAH * p.gp + 4 * g);
@@ -219,8 +218,36 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
         if (j < p.nz) {
             const unsigned o = (unsigned)(j + 2) * p.pitch + col;
             const unsigned cc = (unsigned)j * p.gp + 4 * g;
+            // every global request of this row up front (one memory round trip per row): the
+            // memory variables of the C-PML strips are fetched together with the fields
+            const int zs = zstrip(p, j);
+            float *q1 = nullptr, *q3 = nullptr, *q2 = nullptr, *q4 = nullptr;
+            float4 s1 = zero4, s3 = zero4, s2 = zero4, s4 = zero4;
+            float za = 0.f, zb = 0.f, zk = 1.f, zah = 0.f, zbh = 0.f, zkh = 1.f;
+            if (xs_off >= 0) {
+                q1 = p.psix + (long long)s * p.psix_shot + ((long long)0 * p.nz + j) * p.wx + xs_off;
+                q3 = p.psix + (long long)s * p.psix_shot + ((long long)1 * p.nz + j) * p.wx + xs_off;
+                s1 = ld4(q1); s3 = ld4(q3);
+            }
+            if (zs >= 0) {
+                q2 = p.psiz + (long long)s * p.psiz_shot + ((long long)0 * 2 * p.W + zs) * p.gp + 4 * g;
+                q4 = p.psiz + (long long)s * p.psiz_shot + ((long long)1 * 2 * p.W + zs) * p.gp + 4 * g;
+                s2 = ld4(q2); s4 = ld4(q4);
+                za = p.pz[PA * p.nz + j]; zb = p.pz[PB * p.nz + j]; zk = p.pz[PK * p.nz + j];
+                zah = p.pz[PAH * p.nz + j]; zbh = p.pz[PBH * p.nz + j]; zkh = p.pz[PKH * p.nz + j];
+            }
             a3 = ld4(sxz + o + p.pitch);
             b3 = ld4(szz + o + 2 * p.pitch);
+            if (p.fsurf && j < 2) {
+                // odd mirroring about row 0: sxz(-m) = -sxz(m-1), szz(-m) = -szz(m)
+                if (j == 0) {
+                    a1 = make_float4(-a2.x, -a2.y, -a2.z, -a2.w);
+                    a0 = make_float4(-a3.x, -a3.y, -a3.z, -a3.w);
+                    b0 = make_float4(-b2.x, -b2.y, -b2.z, -b2.w);
+                } else {
+                    a0 = make_float4(-a1.x, -a1.y, -a1.z, -a1.w);
+                }
+            }
             const float4 cxx = ld4(sxx + o);
             const float2 Lxx = ld2(sxx + o - 2), Rxx = ld2(sxx + o + 4);
             const float2 Lxz = ld2(sxz + o - 2), Rxz = ld2(sxz + o + 4);
@@ -237,9 +264,6 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
                 d4[c] = dfw(comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
             }
             if (xs_off >= 0) {
-                float *q1 = p.psix + (long long)s * p.psix_shot + ((long long)0 * p.nz + j) * p.wx + xs_off;
-                float *q3 = p.psix + (long long)s * p.psix_shot + ((long long)1 * p.nz + j) * p.wx + xs_off;
-                float4 s1 = ld4(q1), s3 = ld4(q3);
                 float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t3[4] = {s3.x, s3.y, s3.z, s3.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -249,13 +273,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
                 st4(q1, make_float4(t1[0], t1[1], t1[2], t1[3]));
                 st4(q3, make_float4(t3[0], t3[1], t3[2], t3[3]));
             }
-            const int zs = zstrip(p, j);
             if (zs >= 0) {
-                const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
-                const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
-                float *q2 = p.psiz + (long long)s * p.psiz_shot + ((long long)0 * 2 * p.W + zs) * p.gp + 4 * g;
-                float *q4 = p.psiz + (long long)s * p.psiz_shot + ((long long)1 * 2 * p.W + zs) * p.gp + 4 * g;
-                float4 s2 = ld4(q2), s4 = ld4(q4);
                 float t2[4] = {s2.x, s2.y, s2.z, s2.w}, t4[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -392,6 +410,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const E
                             nxx[c] += a;
                             nzz[c] += a;
                         }
+                        if (p.fsurf && j == 0) nzz[c] = 0.f;
                     }
                     st4(sxx + o, make_float4(nxx[0], nxx[1], nxx[2], nxx[3]));
                     st4(szz + o, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
@@ -412,243 +431,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const E
 }
 
 // ================================================================================================
-// fused forward step (V then S in ONE launch).  A workgroup owns a TZ x 4*TG tile and stages the
-// tile + 4-row / 1-group halo of all five fields in LDS; ONE THREAD PER STAGED GROUP (4 cells):
-// every global operand the thread will need (fields, materials, memory variables) is requested up
-// front, so a workgroup pays one memory round trip instead of one per phase.  Velocities are
-// updated in LDS on tile + 2 (halo cells are recomputed by both neighbours -- that is what makes
-// the fusion legal), then the stresses of the owned cells; the new state goes to the OTHER state
-// buffer (neighbours still read this step's input).  60 B/cell-step instead of 80 and one launch
-// boundary per time step.  Receiver sampling is deferred by one launch: the sampling workgroups of
-// launch n read launch n's INPUT buffer, i.e. the velocities of step n-1.
-// ================================================================================================
-constexpr int FH = 4;            // halo rows per side
-constexpr int FHG = 1;           // halo groups (of 4 cells) per side
-
-template <bool SAVE>
-__global__ __launch_bounds__(512) void el_fwd_tile(const ElParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((int)blockIdx.y >= p.tiles_z) {
-        sample_points<0>(p);          // p.fields == p.fin here
-        return;
-    }
-    const int TZ = p.TZ, TG = p.TG;
-    const int EZ = TZ + 2 * FH, EG = TG + 2 * FHG;
-    const int rowp = 4 * EG, fsz = EZ * rowp;
-    float *L[5] = {smem, smem + fsz, smem + 2 * fsz, smem + 3 * fsz, smem + 4 * fsz};
-    float *inj = smem + 5 * fsz;
-    const int tile_j = (int)blockIdx.y * TZ, tile_g = (int)blockIdx.x * TG;
-    const int s = (int)blockIdx.z;
-    const int t = (int)threadIdx.x;
-    const unsigned fs = p.field_stride;
-    const unsigned ncell = (unsigned)p.nz * p.gp;
-    const float *fin = p.fin + (long long)s * p.shot_stride;
-    float *fout = p.fout + (long long)s * p.shot_stride;
-
-    // this thread's staged group
-    const bool staged = t < EZ * EG;
-    const int ej = t / EG, eg = t - ej * EG;
-    const int j = tile_j - FH + ej, g = tile_g - FHG + eg;
-    const bool ingrid = staged && j >= 0 && j < p.nz && g >= 0 && g < p.ng;
-    const bool vrow = ingrid && ej >= 2 && ej < EZ - 2;
-    const bool owned = ingrid && ej >= FH && ej < FH + TZ && eg >= FHG && eg < FHG + TG;
-    const int b = ej * rowp + 4 * eg;
-    const unsigned off = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
-    const unsigned cc = (unsigned)j * p.gp + 4 * g;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // ---- all global requests up front --------------------------------------------------------
-    float4 f0 = zero4, f1 = zero4, f2 = zero4, f3 = zero4, f4 = zero4;
-    if (ingrid) {
-        f0 = ld4(fin + F_VX * fs + off); f1 = ld4(fin + F_VZ * fs + off);
-        f2 = ld4(fin + F_SXX * fs + off); f3 = ld4(fin + F_SZZ * fs + off);
-        f4 = ld4(fin + F_SXZ * fs + off);
-    }
-    float4 bxs = zero4, bzs = zero4, Ls = zero4, Ms = zero4, mus = zero4;
-    if (vrow) { bxs = ld4(p.mat + M_BX * ncell + cc); bzs = ld4(p.mat + M_BZ * ncell + cc); }
-    if (owned) {
-        Ls = ld4(p.mat + M_L * ncell + cc); Ms = ld4(p.mat + M_M * ncell + cc);
-        mus = ld4(p.mat + M_MU * ncell + cc);
-    }
-    const int xs_off = ingrid ? xstrip(p, g) : -1;
-    const int zs = ingrid ? zstrip(p, j) : -1;
-    float4 pxa, pxb, pxk, pxah, pxbh, pxkh;
-    float4 s1 = zero4, s3 = zero4, s5 = zero4, s8 = zero4, s2 = zero4, s4 = zero4, s6 = zero4, s7 = zero4;
-    float za = 0.f, zb = 0.f, zk = 1.f, zah = 0.f, zbh = 0.f, zkh = 1.f;
-    long long qx = 0, qz = 0;
-    const long long xplane = (long long)p.nz * p.wx, zplane = 2LL * p.W * p.gp;
-    if (xs_off >= 0) {
-        pxa = ld4(p.px + PA * p.gp + 4 * g); pxb = ld4(p.px + PB * p.gp + 4 * g);
-        pxk = ld4(p.px + PK * p.gp + 4 * g); pxah = ld4(p.px + PAH * p.gp + 4 * g);
-        pxbh = ld4(p.px + PBH * p.gp + 4 * g); pxkh = ld4(p.px + PKH * p.gp + 4 * g);
-        qx = (long long)s * p.psix_shot + (long long)j * p.wx + xs_off;
-        if (vrow) { s1 = ld4(p.psix + qx); s3 = ld4(p.psix + qx + xplane); }
-        if (owned) { s5 = ld4(p.psix + qx + 2 * xplane); s8 = ld4(p.psix + qx + 3 * xplane); }
-    }
-    if (zs >= 0) {
-        za = p.pz[PA * p.nz + j]; zb = p.pz[PB * p.nz + j]; zk = p.pz[PK * p.nz + j];
-        zah = p.pz[PAH * p.nz + j]; zbh = p.pz[PBH * p.nz + j]; zkh = p.pz[PKH * p.nz + j];
-        qz = (long long)s * p.psiz_shot + (long long)zs * p.gp + 4 * g;
-        if (vrow) { s2 = ld4(p.psiz + qz); s4 = ld4(p.psiz + qz + zplane); }
-        if (owned) { s6 = ld4(p.psiz + qz + 2 * zplane); s7 = ld4(p.psiz + qz + 3 * zplane); }
-    }
-    // injection image of the owned tile (block-uniform decision)
-    bool has_inj = false;
-    if (p.ninj > 0) {
-        const int b0 = p.inj_bbox[4 * s + 0], b1 = p.inj_bbox[4 * s + 1];
-        const int b2 = p.inj_bbox[4 * s + 2], b3 = p.inj_bbox[4 * s + 3];
-        has_inj = (b0 < tile_j + TZ) && (b1 >= tile_j) && (b2 < 4 * (tile_g + TG)) && (b3 >= 4 * tile_g);
-    }
-    if (has_inj)
-        for (int e = t; e < TZ * 4 * TG; e += (int)blockDim.x) inj[e] = 0.f;
-
-    // ---- stage the fields ---------------------------------------------------------------------
-    if (staged) {
-        st4(L[F_VX] + b, f0); st4(L[F_VZ] + b, f1); st4(L[F_SXX] + b, f2);
-        st4(L[F_SZZ] + b, f3); st4(L[F_SXZ] + b, f4);
-    }
-    __syncthreads();
-    if (has_inj) {
-        const int total = p.ninj * p.ntap_inj;
-        for (int e = t; e < total; e += (int)blockDim.x) {
-            const long long ee = (long long)s * total + e;
-            const int cell = p.inj_cell[ee];
-            if (cell < 0) continue;
-            const int jj = cell / p.nx, ii = cell - jj * p.nx;
-            const int tj = jj - tile_j, ti = ii - 4 * tile_g;
-            if (tj >= 0 && tj < TZ && ti >= 0 && ti < 4 * TG)
-                atomicAdd(&inj[tj * 4 * TG + ti], p.inj_w[ee] * p.inj_amp0[(long long)s * p.ninj + e / p.ntap_inj]);
-        }
-    }
-
-    // ---- V: velocities on tile + 2 ---------------------------------------------------------------
-    float4 vxv = f0, vzv = f1;
-    if (vrow) {
-        // x neighbours: at the first / last staged group the missing side only feeds cells whose
-        // velocities are never consumed, so any finite value will do (own group re-read)
-        const int bl = eg > 0 ? b - 4 : b, br = eg < EG - 1 ? b + 4 : b;
-        const float4 lxx = ld4(L[F_SXX] + bl), rxx = ld4(L[F_SXX] + br);
-        const float4 lxz = ld4(L[F_SXZ] + bl), rxz = ld4(L[F_SXZ] + br);
-        const float4 a0 = ld4(L[F_SXZ] + b - 2 * rowp), a1 = ld4(L[F_SXZ] + b - rowp), a3 = ld4(L[F_SXZ] + b + rowp);
-        const float4 b0 = ld4(L[F_SZZ] + b - rowp), b2 = ld4(L[F_SZZ] + b + rowp), b3 = ld4(L[F_SZZ] + b + 2 * rowp);
-        const float xx[8] = {lxx.z, lxx.w, f2.x, f2.y, f2.z, f2.w, rxx.x, rxx.y};
-        const float xz[8] = {lxz.z, lxz.w, f4.x, f4.y, f4.z, f4.w, rxz.x, rxz.y};
-        float d1[4], d2[4], d3[4], d4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            d1[c] = dfw(xx[c + 1], xx[c + 2], xx[c + 3], xx[c + 4]);
-            d2[c] = dbw(comp(a0, c), comp(a1, c), comp(f4, c), comp(a3, c));
-            d3[c] = dbw(xz[c], xz[c + 1], xz[c + 2], xz[c + 3]);
-            d4[c] = dfw(comp(b0, c), comp(f3, c), comp(b2, c), comp(b3, c));
-        }
-        if (xs_off >= 0) {
-            float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t3[4] = {s3.x, s3.y, s3.z, s3.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                d1[c] = pml(t1[c], comp(pxah, c), comp(pxbh, c), comp(pxkh, c), d1[c]);
-                d3[c] = pml(t3[c], comp(pxa, c), comp(pxb, c), comp(pxk, c), d3[c]);
-            }
-            if (owned) {
-                st4(p.psix_out + qx, make_float4(t1[0], t1[1], t1[2], t1[3]));
-                st4(p.psix_out + qx + xplane, make_float4(t3[0], t3[1], t3[2], t3[3]));
-            }
-        }
-        if (zs >= 0) {
-            float t2[4] = {s2.x, s2.y, s2.z, s2.w}, t4[4] = {s4.x, s4.y, s4.z, s4.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                d2[c] = pml(t2[c], za, zb, zk, d2[c]);
-                d4[c] = pml(t4[c], zah, zbh, zkh, d4[c]);
-            }
-            if (owned) {
-                st4(p.psiz_out + qz, make_float4(t2[0], t2[1], t2[2], t2[3]));
-                st4(p.psiz_out + qz + zplane, make_float4(t4[0], t4[1], t4[2], t4[3]));
-            }
-        }
-        float s4v[4], s5v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { s4v[c] = d1[c] + d2[c]; s5v[c] = d3[c] + d4[c]; }
-        vxv.x = fmaf(bxs.x, s4v[0], vxv.x); vxv.y = fmaf(bxs.y, s4v[1], vxv.y);
-        vxv.z = fmaf(bxs.z, s4v[2], vxv.z); vxv.w = fmaf(bxs.w, s4v[3], vxv.w);
-        vzv.x = fmaf(bzs.x, s5v[0], vzv.x); vzv.y = fmaf(bzs.y, s5v[1], vzv.y);
-        vzv.z = fmaf(bzs.z, s5v[2], vzv.z); vzv.w = fmaf(bzs.w, s5v[3], vzv.w);
-        st4(L[F_VX] + b, vxv);
-        st4(L[F_VZ] + b, vzv);
-        if (SAVE && owned) {
-            float *Sp = p.S + (long long)s * 5 * ncell + cc;
-            st4(Sp + 3 * (long long)ncell, make_float4(s4v[0], s4v[1], s4v[2], s4v[3]));
-            st4(Sp + 4 * (long long)ncell, make_float4(s5v[0], s5v[1], s5v[2], s5v[3]));
-        }
-    }
-    __syncthreads();
-
-    // ---- S: stresses of the owned cells, write the new state ---------------------------------
-    if (owned) {
-        const float4 lvx = ld4(L[F_VX] + b - 4), rvx = ld4(L[F_VX] + b + 4);
-        const float4 lvz = ld4(L[F_VZ] + b - 4), rvz = ld4(L[F_VZ] + b + 4);
-        const float4 a0 = ld4(L[F_VZ] + b - 2 * rowp), a1 = ld4(L[F_VZ] + b - rowp), a3 = ld4(L[F_VZ] + b + rowp);
-        const float4 b0 = ld4(L[F_VX] + b - rowp), b2 = ld4(L[F_VX] + b + rowp), b3 = ld4(L[F_VX] + b + 2 * rowp);
-        const float xv[8] = {lvx.z, lvx.w, vxv.x, vxv.y, vxv.z, vxv.w, rvx.x, rvx.y};
-        const float zv[8] = {lvz.z, lvz.w, vzv.x, vzv.y, vzv.z, vzv.w, rvz.x, rvz.y};
-        float e1[4], e2[4], e3[4], e4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            e1[c] = dbw(xv[c], xv[c + 1], xv[c + 2], xv[c + 3]);
-            e2[c] = dbw(comp(a0, c), comp(a1, c), comp(vzv, c), comp(a3, c));
-            e3[c] = dfw(comp(b0, c), comp(vxv, c), comp(b2, c), comp(b3, c));
-            e4[c] = dfw(zv[c + 1], zv[c + 2], zv[c + 3], zv[c + 4]);
-        }
-        if (xs_off >= 0) {
-            float t5[4] = {s5.x, s5.y, s5.z, s5.w}, t8[4] = {s8.x, s8.y, s8.z, s8.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                e1[c] = pml(t5[c], comp(pxa, c), comp(pxb, c), comp(pxk, c), e1[c]);
-                e4[c] = pml(t8[c], comp(pxah, c), comp(pxbh, c), comp(pxkh, c), e4[c]);
-            }
-            st4(p.psix_out + qx + 2 * xplane, make_float4(t5[0], t5[1], t5[2], t5[3]));
-            st4(p.psix_out + qx + 3 * xplane, make_float4(t8[0], t8[1], t8[2], t8[3]));
-        }
-        if (zs >= 0) {
-            float t6[4] = {s6.x, s6.y, s6.z, s6.w}, t7[4] = {s7.x, s7.y, s7.z, s7.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                e2[c] = pml(t6[c], za, zb, zk, e2[c]);
-                e3[c] = pml(t7[c], zah, zbh, zkh, e3[c]);
-            }
-            st4(p.psiz_out + qz + 2 * zplane, make_float4(t6[0], t6[1], t6[2], t6[3]));
-            st4(p.psiz_out + qz + 3 * zplane, make_float4(t7[0], t7[1], t7[2], t7[3]));
-        }
-        float nxx[4], nzz[4], nxz[4], s3v[4];
-        const int r = ej - FH, c0 = eg - FHG;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            s3v[c] = e3[c] + e4[c];
-            nxx[c] = fmaf(comp(Ms, c), e1[c], fmaf(comp(Ls, c), e2[c], comp(f2, c)));
-            nzz[c] = fmaf(comp(Ls, c), e1[c], fmaf(comp(Ms, c), e2[c], comp(f3, c)));
-            nxz[c] = fmaf(comp(mus, c), s3v[c], comp(f4, c));
-            if (has_inj) {
-                const float a = inj[r * 4 * TG + 4 * c0 + c];
-                nxx[c] += a;
-                nzz[c] += a;
-            }
-        }
-        st4(fout + F_SXX * fs + off, make_float4(nxx[0], nxx[1], nxx[2], nxx[3]));
-        st4(fout + F_SZZ * fs + off, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
-        st4(fout + F_SXZ * fs + off, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
-        st4(fout + F_VX * fs + off, vxv);
-        st4(fout + F_VZ * fs + off, vzv);
-        if (SAVE) {
-            float *Sp = p.S + (long long)s * 5 * ncell + cc;
-            st4(Sp, make_float4(e1[0], e1[1], e1[2], e1[3]));
-            st4(Sp + (long long)ncell, make_float4(e2[0], e2[1], e2[2], e2[3]));
-            st4(Sp + 2 * (long long)ncell, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
-        }
-    }
-}
-
-// ================================================================================================
-// adjoint launches, LDS-staged variant (default).  Tile = TZ x (4*GXO) owned cells, staged on (TZ+4) x 4*(GXO+2) in LDS.
+// adjoint launches.  Tile = TZ x (4*GXO) owned cells, staged on (TZ+4) x 4*(GXO+2) in LDS.
 // ================================================================================================
 constexpr int ATZ = 16;          // owned rows
 constexpr int AGX = 16;          // staged groups per row (14 owned + 1 halo group each side)
@@ -658,7 +441,7 @@ constexpr int ASX = 4 * AGX;     // staged columns
 
 // S^T:  E = C^T sigma_bar through the transposed C-PML;  v_bar -= stencils(E);  v_bar += R^T g;
 //       all five material-gradient accumulators.
-__global__ __launch_bounds__(kThreads) void el_adj_s_lds(const ElParams p)
+__global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
 {
     if ((int)blockIdx.y >= p.tiles_z) {
         sample_points<1>(p);
@@ -696,7 +479,9 @@ __global__ __launch_bounds__(kThreads) void el_adj_s_lds(const ElParams p)
             if (j >= 0 && j < p.nz && g >= 0 && g < p.ng) {
                 const unsigned o = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
                 const unsigned cc = (unsigned)j * p.gp + 4 * g;
-                const float4 bxx = ld4(fl + F_SXX * fs + o), bzz = ld4(fl + F_SZZ * fs + o);
+                const float4 bxx = ld4(fl + F_SXX * fs + o);
+                float4 bzz = ld4(fl + F_SZZ * fs + o);
+                if (p.fsurf && j == 0) bzz = make_float4(0.f, 0.f, 0.f, 0.f);   // adjoint of szz(0,.) is discarded
                 const float4 bxz = ld4(fl + F_SXZ * fs + o);
                 const float4 Ls = ld4(p.mat + M_L * ncell + cc), Ms = ld4(p.mat + M_M * ncell + cc);
                 const float4 mus = ld4(p.mat + M_MU * ncell + cc);
@@ -758,7 +543,9 @@ __global__ __launch_bounds__(kThreads) void el_adj_s_lds(const ElParams p)
             const unsigned o = (unsigned)(oj + 2) * p.pitch + 4 + 4 * og;
             const int r = orow + 2, cb = 4 * (ogrp + 1);
             float4 vxb = ld4(fl + F_VX * fs + o), vzb = ld4(fl + F_VZ * fs + o);
-            const float4 bxx = ld4(fl + F_SXX * fs + o), bzz = ld4(fl + F_SZZ * fs + o);
+            const float4 bxx = ld4(fl + F_SXX * fs + o);
+            float4 bzz = ld4(fl + F_SZZ * fs + o);
+            if (p.fsurf && oj == 0) bzz = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 bxz = ld4(fl + F_SXZ * fs + o);
             const float *Sp = p.S + (long long)s * 5 * ncell + occ;
             const float4 S1 = ld4(Sp), S2 = ld4(Sp + (long long)ncell), S3 = ld4(Sp + 2 * (long long)ncell);
@@ -806,7 +593,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_s_lds(const ElParams p)
 }
 
 // V^T:  D = B^T v_bar through the transposed C-PML;  sigma_bar -= stencils(D)
-__global__ __launch_bounds__(kThreads) void el_adj_v_lds(const ElParams p)
+__global__ __launch_bounds__(kThreads) void el_adj_v(const ElParams p)
 {
     __shared__ float D[4][ASZ][ASX];
     const int tile_j = (int)blockIdx.y * ATZ;
@@ -895,6 +682,11 @@ __global__ __launch_bounds__(kThreads) void el_adj_v_lds(const ElParams p)
                 nxx[c] = comp(bxx, c) - dx1;
                 nxz[c] = comp(bxz, c) - (dz2 + dx3);
                 nzz[c] = comp(bzz, c) - dz4;
+                if (p.fsurf && oj < 2) {
+                    // transposed odd mirroring (tile_j == 0 here: staged row 2 is grid row 0)
+                    if (oj == 0) nxz[c] = nxz[c] + fmaf(C1, D[1][2][x], C2 * D[1][3][x]);
+                    else { nxz[c] = nxz[c] + C2 * D[1][2][x]; nzz[c] = nzz[c] + C2 * D[3][2][x]; }
+                }
                 if (4 * og + c >= p.nx) { nxx[c] = 0.f; nxz[c] = 0.f; nzz[c] = 0.f; }
             }
             st4(fl + F_SXX * fs + o, make_float4(nxx[0], nxx[1], nxx[2], nxx[3]));
@@ -902,331 +694,6 @@ __global__ __launch_bounds__(kThreads) void el_adj_v_lds(const ElParams p)
             st4(fl + F_SXZ * fs + o, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
         }
     }
-}
-
-// ================================================================================================
-// adjoint launches, register-only variant (MIFWI_EL_ADJ=lean; measured slower on MI355X, kept for A/B):
-// one thread per group of 4 cells, no LDS staging, no barriers.
-// The transposed C-PML acts on the material-scaled adjoint field BEFORE the spatial derivative, so
-// a thread evaluates that per-cell quantity for its own group and for the six neighbouring groups
-// its stencils reach (x: g-1, g+1; z: j-2..j+2); the operands of the neighbours are the lines the
-// neighbouring lanes / rows fetch anyway (L1/L2 hits).
-// All five material-gradient accumulators live in the S^T launch and stay in registers across the
-// shots of a group (one read-modify-write per group and step).
-// ================================================================================================
-struct AdjCtx {
-    const float *fl;            // this shot's adjoint state (5 fields)
-    const float *psix, *psiz;   // this shot's transposed memory variables (read side)
-    unsigned fs, ncell;
-};
-
-// E = (C^T sigma_bar) through the transposed C-PML for group (j,g).  WANT bit0: e1,e4 (x stencils),
-// bit1: e2 (z), bit2: e3 (z).  `n5..n8` return the updated memory variables of THIS group (only
-// meaningful for the centre group, which is the one that stores them).
-template <int WANT>
-__device__ __forceinline__ void adj_E(const ElParams &p, const AdjCtx &c, int j, int g, float4 &E1,
-                                      float4 &E2, float4 &E3, float4 &E4, float4 *n5, float4 *n6,
-                                      float4 *n7, float4 *n8)
-{
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    E1 = z; E2 = z; E3 = z; E4 = z;
-    if (j < 0 || j >= p.nz || g < 0 || g >= p.ng) return;
-    const unsigned o = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
-    const unsigned cc = (unsigned)j * p.gp + 4 * g;
-    float e1[4], e2[4], e3[4], e4[4];
-    if (WANT & 3) {
-        const float4 bxx = ld4(c.fl + F_SXX * c.fs + o), bzz = ld4(c.fl + F_SZZ * c.fs + o);
-        const float4 Ls = ld4(p.mat + M_L * c.ncell + cc), Ms = ld4(p.mat + M_M * c.ncell + cc);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            e1[k] = fmaf(comp(Ms, k), comp(bxx, k), comp(Ls, k) * comp(bzz, k));
-            e2[k] = fmaf(comp(Ls, k), comp(bxx, k), comp(Ms, k) * comp(bzz, k));
-        }
-    }
-    if (WANT & 5) {
-        const float4 bxz = ld4(c.fl + F_SXZ * c.fs + o);
-        const float4 mus = ld4(p.mat + M_MU * c.ncell + cc);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { e3[k] = comp(mus, k) * comp(bxz, k); e4[k] = e3[k]; }
-    }
-    if (WANT & 1) {
-        const int xs_off = xstrip(p, g);
-        if (xs_off >= 0) {
-            const float *pp = p.px + 4 * g;
-            const long long q = (long long)j * p.wx + xs_off, xplane = (long long)p.nz * p.wx;
-            const float4 s5 = ld4(c.psix + q + 2 * xplane), s8 = ld4(c.psix + q + 3 * xplane);
-            const float4 a = ld4(pp + PA * p.gp), b = ld4(pp + PB * p.gp), k_ = ld4(pp + PK * p.gp);
-            const float4 ah = ld4(pp + PAH * p.gp), bh = ld4(pp + PBH * p.gp), kh = ld4(pp + PKH * p.gp);
-            float m5[4], m8[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                e1[k] = pmlT(comp(s5, k), comp(a, k), comp(b, k), comp(k_, k), e1[k], m5[k]);
-                e4[k] = pmlT(comp(s8, k), comp(ah, k), comp(bh, k), comp(kh, k), e4[k], m8[k]);
-            }
-            if (n5) { *n5 = make_float4(m5[0], m5[1], m5[2], m5[3]); *n8 = make_float4(m8[0], m8[1], m8[2], m8[3]); }
-        }
-        E1 = make_float4(e1[0], e1[1], e1[2], e1[3]);
-        E4 = make_float4(e4[0], e4[1], e4[2], e4[3]);
-    }
-    if (WANT & 6) {
-        const int zs = zstrip(p, j);
-        if (zs >= 0) {
-            const long long q = (long long)zs * p.gp + 4 * g, zplane = 2LL * p.W * p.gp;
-            if (WANT & 2) {
-                const float4 s6 = ld4(c.psiz + q + 2 * zplane);
-                const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
-                float m6[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) e2[k] = pmlT(comp(s6, k), za, zb, zk, e2[k], m6[k]);
-                if (n6) *n6 = make_float4(m6[0], m6[1], m6[2], m6[3]);
-            }
-            if (WANT & 4) {
-                const float4 s7 = ld4(c.psiz + q + 3 * zplane);
-                const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
-                float m7[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) e3[k] = pmlT(comp(s7, k), zah, zbh, zkh, e3[k], m7[k]);
-                if (n7) *n7 = make_float4(m7[0], m7[1], m7[2], m7[3]);
-            }
-        }
-        if (WANT & 2) E2 = make_float4(e2[0], e2[1], e2[2], e2[3]);
-        if (WANT & 4) E3 = make_float4(e3[0], e3[1], e3[2], e3[3]);
-    }
-}
-
-template <int LX>
-__global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
-{
-    constexpr int LZ = kThreads / LX;
-    constexpr int TZ = LZ, TX = LX * 4;
-    if ((int)blockIdx.y >= p.tiles_z) {
-        sample_points<1>(p);
-        return;
-    }
-    __shared__ float inj[2 * TZ * TX];
-    const int lx = (int)threadIdx.x % LX, lz = (int)threadIdx.x / LX;
-    const int g = (int)blockIdx.x * LX + lx;
-    const int tile_j = (int)blockIdx.y * TZ, tile_i = (int)blockIdx.x * TX;
-    const int j = tile_j + lz;
-    const bool active = (g < p.ng) && (j < p.nz);
-    const unsigned fs = p.field_stride;
-    const unsigned ncell = (unsigned)p.nz * p.gp;
-    const unsigned o = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
-    const unsigned cc = (unsigned)j * p.gp + 4 * g;
-    float4 acc[5];
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) acc[k] = ld4(p.acc + ((long long)blockIdx.z * 5 + k) * ncell + cc);
-    }
-    const int xs_off = active ? xstrip(p, g) : -1;
-    const int zs = active ? zstrip(p, j) : -1;
-    for (int si = 0; si < p.gs; ++si) {
-        const int s = (int)blockIdx.z * p.gs + si;
-        if (s >= p.nshot) break;
-        float *fl = p.fields + (long long)s * p.shot_stride;
-        const bool has_inj = stage_injection<TZ, TX, 2>(p, s, tile_j, tile_i, inj);
-        if (active) {
-            AdjCtx c;
-            c.fl = fl; c.fs = fs; c.ncell = ncell;
-            c.psix = p.psix + (long long)s * p.psix_shot;
-            c.psiz = p.psiz + (long long)s * p.psiz_shot;
-            float4 e1c, e2c, e3c, e4c, t0, t1, t2, t3;
-            float4 n5, n6, n7, n8;
-            adj_E<7>(p, c, j, g, e1c, e2c, e3c, e4c, &n5, &n6, &n7, &n8);
-            float4 e1l, e4l, e1r, e4r;
-            adj_E<1>(p, c, j, g - 1, e1l, t1, t2, e4l, nullptr, nullptr, nullptr, nullptr);
-            adj_E<1>(p, c, j, g + 1, e1r, t1, t2, e4r, nullptr, nullptr, nullptr, nullptr);
-            float4 e3m2, e3m1, e2m1, e3p1, e2p1, e2p2;
-            adj_E<4>(p, c, j - 2, g, t0, t1, e3m2, t3, nullptr, nullptr, nullptr, nullptr);
-            adj_E<6>(p, c, j - 1, g, t0, e2m1, e3m1, t3, nullptr, nullptr, nullptr, nullptr);
-            adj_E<6>(p, c, j + 1, g, t0, e2p1, e3p1, t3, nullptr, nullptr, nullptr, nullptr);
-            adj_E<2>(p, c, j + 2, g, t0, e2p2, t2, t3, nullptr, nullptr, nullptr, nullptr);
-            // store the updated transposed memory variables of the own group
-            if (xs_off >= 0) {
-                const long long q = (long long)s * p.psix_shot + (long long)j * p.wx + xs_off;
-                const long long xplane = (long long)p.nz * p.wx;
-                st4(p.psix_out + q + 2 * xplane, n5);
-                st4(p.psix_out + q + 3 * xplane, n8);
-            }
-            if (zs >= 0) {
-                const long long q = (long long)s * p.psiz_shot + (long long)zs * p.gp + 4 * g;
-                const long long zplane = 2LL * p.W * p.gp;
-                st4(p.psiz_out + q + 2 * zplane, n6);
-                st4(p.psiz_out + q + 3 * zplane, n7);
-            }
-            const float4 vxb = ld4(fl + F_VX * fs + o), vzb = ld4(fl + F_VZ * fs + o);
-            const float4 bxx = ld4(fl + F_SXX * fs + o), bzz = ld4(fl + F_SZZ * fs + o);
-            const float4 bxz = ld4(fl + F_SXZ * fs + o);
-            const float *Sp = p.S + (long long)s * 5 * ncell + cc;
-            const float4 S1 = ld4(Sp), S2 = ld4(Sp + (long long)ncell), S3 = ld4(Sp + 2 * (long long)ncell);
-            const float4 S4 = ld4(Sp + 3 * (long long)ncell), S5 = ld4(Sp + 4 * (long long)ncell);
-            const float x1[8] = {e1l.z, e1l.w, e1c.x, e1c.y, e1c.z, e1c.w, e1r.x, e1r.y};
-            const float x4[8] = {e4l.z, e4l.w, e4c.x, e4c.y, e4c.z, e4c.w, e4r.x, e4r.y};
-            float nvx[4], nvz[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float dx1 = dfw(x1[k + 1], x1[k + 2], x1[k + 3], x1[k + 4]);
-                const float dz3 = dbw(comp(e3m2, k), comp(e3m1, k), comp(e3c, k), comp(e3p1, k));
-                const float dz2 = dfw(comp(e2m1, k), comp(e2c, k), comp(e2p1, k), comp(e2p2, k));
-                const float dx4 = dbw(x4[k], x4[k + 1], x4[k + 2], x4[k + 3]);
-                float ax = comp(vxb, k) - (dx1 + dz3);
-                float az = comp(vzb, k) - (dz2 + dx4);
-                if (has_inj) {
-                    ax += inj[lz * TX + 4 * lx + k];
-                    az += inj[TZ * TX + lz * TX + 4 * lx + k];
-                }
-                if (4 * g + k >= p.nx) { ax = 0.f; az = 0.f; }
-                nvx[k] = ax; nvz[k] = az;
-            }
-            st4(fl + F_VX * fs + o, make_float4(nvx[0], nvx[1], nvx[2], nvx[3]));
-            st4(fl + F_VZ * fs + o, make_float4(nvz[0], nvz[1], nvz[2], nvz[3]));
-#define ACC3(dst, a, b, c_, d) dst = fmaf(a, b, fmaf(c_, d, dst))
-            ACC3(acc[M_M].x, S1.x, bxx.x, S2.x, bzz.x); ACC3(acc[M_M].y, S1.y, bxx.y, S2.y, bzz.y);
-            ACC3(acc[M_M].z, S1.z, bxx.z, S2.z, bzz.z); ACC3(acc[M_M].w, S1.w, bxx.w, S2.w, bzz.w);
-            ACC3(acc[M_L].x, S2.x, bxx.x, S1.x, bzz.x); ACC3(acc[M_L].y, S2.y, bxx.y, S1.y, bzz.y);
-            ACC3(acc[M_L].z, S2.z, bxx.z, S1.z, bzz.z); ACC3(acc[M_L].w, S2.w, bxx.w, S1.w, bzz.w);
-#undef ACC3
-            acc[M_MU].x = fmaf(S3.x, bxz.x, acc[M_MU].x); acc[M_MU].y = fmaf(S3.y, bxz.y, acc[M_MU].y);
-            acc[M_MU].z = fmaf(S3.z, bxz.z, acc[M_MU].z); acc[M_MU].w = fmaf(S3.w, bxz.w, acc[M_MU].w);
-            acc[M_BX].x = fmaf(S4.x, nvx[0], acc[M_BX].x); acc[M_BX].y = fmaf(S4.y, nvx[1], acc[M_BX].y);
-            acc[M_BX].z = fmaf(S4.z, nvx[2], acc[M_BX].z); acc[M_BX].w = fmaf(S4.w, nvx[3], acc[M_BX].w);
-            acc[M_BZ].x = fmaf(S5.x, nvz[0], acc[M_BZ].x); acc[M_BZ].y = fmaf(S5.y, nvz[1], acc[M_BZ].y);
-            acc[M_BZ].z = fmaf(S5.z, nvz[2], acc[M_BZ].z); acc[M_BZ].w = fmaf(S5.w, nvz[3], acc[M_BZ].w);
-        }
-        if (has_inj) __syncthreads();
-    }
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) st4(p.acc + ((long long)blockIdx.z * 5 + k) * ncell + cc, acc[k]);
-    }
-}
-
-// D = (B^T v_bar) through the transposed C-PML for group (j,g).  WANT bit0: d1,d3 (x), bit1: d2 (z),
-// bit2: d4 (z).
-template <int WANT>
-__device__ __forceinline__ void adj_D(const ElParams &p, const AdjCtx &c, int j, int g, float4 &D1,
-                                      float4 &D2, float4 &D3, float4 &D4, float4 *n1, float4 *n2,
-                                      float4 *n3, float4 *n4)
-{
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    D1 = z; D2 = z; D3 = z; D4 = z;
-    if (j < 0 || j >= p.nz || g < 0 || g >= p.ng) return;
-    const unsigned o = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
-    const unsigned cc = (unsigned)j * p.gp + 4 * g;
-    float d1[4], d2[4], d3[4], d4[4];
-    if (WANT & 3) {
-        const float4 vxb = ld4(c.fl + F_VX * c.fs + o), bxs = ld4(p.mat + M_BX * c.ncell + cc);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { d1[k] = comp(bxs, k) * comp(vxb, k); d2[k] = d1[k]; }
-    }
-    if (WANT & 5) {
-        const float4 vzb = ld4(c.fl + F_VZ * c.fs + o), bzs = ld4(p.mat + M_BZ * c.ncell + cc);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { d3[k] = comp(bzs, k) * comp(vzb, k); d4[k] = d3[k]; }
-    }
-    if (WANT & 1) {
-        const int xs_off = xstrip(p, g);
-        if (xs_off >= 0) {
-            const float *pp = p.px + 4 * g;
-            const long long q = (long long)j * p.wx + xs_off, xplane = (long long)p.nz * p.wx;
-            const float4 s1 = ld4(c.psix + q), s3 = ld4(c.psix + q + xplane);
-            const float4 a = ld4(pp + PA * p.gp), b = ld4(pp + PB * p.gp), k_ = ld4(pp + PK * p.gp);
-            const float4 ah = ld4(pp + PAH * p.gp), bh = ld4(pp + PBH * p.gp), kh = ld4(pp + PKH * p.gp);
-            float m1[4], m3[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                d1[k] = pmlT(comp(s1, k), comp(ah, k), comp(bh, k), comp(kh, k), d1[k], m1[k]);
-                d3[k] = pmlT(comp(s3, k), comp(a, k), comp(b, k), comp(k_, k), d3[k], m3[k]);
-            }
-            if (n1) { *n1 = make_float4(m1[0], m1[1], m1[2], m1[3]); *n3 = make_float4(m3[0], m3[1], m3[2], m3[3]); }
-        }
-        D1 = make_float4(d1[0], d1[1], d1[2], d1[3]);
-        D3 = make_float4(d3[0], d3[1], d3[2], d3[3]);
-    }
-    if (WANT & 6) {
-        const int zs = zstrip(p, j);
-        if (zs >= 0) {
-            const long long q = (long long)zs * p.gp + 4 * g, zplane = 2LL * p.W * p.gp;
-            if (WANT & 2) {
-                const float4 s2 = ld4(c.psiz + q);
-                const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
-                float m2[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) d2[k] = pmlT(comp(s2, k), za, zb, zk, d2[k], m2[k]);
-                if (n2) *n2 = make_float4(m2[0], m2[1], m2[2], m2[3]);
-            }
-            if (WANT & 4) {
-                const float4 s4 = ld4(c.psiz + q + zplane);
-                const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
-                float m4[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) d4[k] = pmlT(comp(s4, k), zah, zbh, zkh, d4[k], m4[k]);
-                if (n4) *n4 = make_float4(m4[0], m4[1], m4[2], m4[3]);
-            }
-        }
-        if (WANT & 2) D2 = make_float4(d2[0], d2[1], d2[2], d2[3]);
-        if (WANT & 4) D4 = make_float4(d4[0], d4[1], d4[2], d4[3]);
-    }
-}
-
-// V^T:  sigma_bar -= stencils(D)
-template <int LX>
-__global__ __launch_bounds__(kThreads) void el_adj_v(const ElParams p)
-{
-    constexpr int LZ = kThreads / LX;
-    const int lx = (int)threadIdx.x % LX, lz = (int)threadIdx.x / LX;
-    const int g = (int)blockIdx.x * LX + lx;
-    const int j = (int)blockIdx.y * LZ + lz;
-    if (g >= p.ng || j >= p.nz) return;
-    const int s = (int)blockIdx.z;
-    const unsigned fs = p.field_stride;
-    float *fl = p.fields + (long long)s * p.shot_stride;
-    const unsigned o = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
-    AdjCtx c;
-    c.fl = fl; c.fs = fs; c.ncell = (unsigned)p.nz * p.gp;
-    c.psix = p.psix + (long long)s * p.psix_shot;
-    c.psiz = p.psiz + (long long)s * p.psiz_shot;
-    float4 d1c, d2c, d3c, d4c, t0, t1, t2, t3, n1, n2, n3, n4;
-    adj_D<7>(p, c, j, g, d1c, d2c, d3c, d4c, &n1, &n2, &n3, &n4);
-    float4 d1l, d3l, d1r, d3r;
-    adj_D<1>(p, c, j, g - 1, d1l, t1, d3l, t3, nullptr, nullptr, nullptr, nullptr);
-    adj_D<1>(p, c, j, g + 1, d1r, t1, d3r, t3, nullptr, nullptr, nullptr, nullptr);
-    float4 d4m2, d4m1, d2m1, d4p1, d2p1, d2p2;
-    adj_D<4>(p, c, j - 2, g, t0, t1, t2, d4m2, nullptr, nullptr, nullptr, nullptr);
-    adj_D<6>(p, c, j - 1, g, t0, d2m1, t2, d4m1, nullptr, nullptr, nullptr, nullptr);
-    adj_D<6>(p, c, j + 1, g, t0, d2p1, t2, d4p1, nullptr, nullptr, nullptr, nullptr);
-    adj_D<2>(p, c, j + 2, g, t0, d2p2, t2, t3, nullptr, nullptr, nullptr, nullptr);
-    const int xs_off = xstrip(p, g);
-    if (xs_off >= 0) {
-        const long long q = (long long)s * p.psix_shot + (long long)j * p.wx + xs_off;
-        st4(p.psix_out + q, n1);
-        st4(p.psix_out + q + (long long)p.nz * p.wx, n3);
-    }
-    const int zs = zstrip(p, j);
-    if (zs >= 0) {
-        const long long q = (long long)s * p.psiz_shot + (long long)zs * p.gp + 4 * g;
-        st4(p.psiz_out + q, n2);
-        st4(p.psiz_out + q + 2LL * p.W * p.gp, n4);
-    }
-    const float4 bxx = ld4(fl + F_SXX * fs + o), bzz = ld4(fl + F_SZZ * fs + o);
-    const float4 bxz = ld4(fl + F_SXZ * fs + o);
-    const float x1[8] = {d1l.z, d1l.w, d1c.x, d1c.y, d1c.z, d1c.w, d1r.x, d1r.y};
-    const float x3[8] = {d3l.z, d3l.w, d3c.x, d3c.y, d3c.z, d3c.w, d3r.x, d3r.y};
-    float nxx[4], nzz[4], nxz[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float dx1 = dbw(x1[k], x1[k + 1], x1[k + 2], x1[k + 3]);
-        const float dz2 = dfw(comp(d2m1, k), comp(d2c, k), comp(d2p1, k), comp(d2p2, k));
-        const float dx3 = dfw(x3[k + 1], x3[k + 2], x3[k + 3], x3[k + 4]);
-        const float dz4 = dbw(comp(d4m2, k), comp(d4m1, k), comp(d4c, k), comp(d4p1, k));
-        nxx[k] = comp(bxx, k) - dx1;
-        nxz[k] = comp(bxz, k) - (dz2 + dx3);
-        nzz[k] = comp(bzz, k) - dz4;
-        if (4 * g + k >= p.nx) { nxx[k] = 0.f; nxz[k] = 0.f; nzz[k] = 0.f; }
-    }
-    st4(fl + F_SXX * fs + o, make_float4(nxx[0], nxx[1], nxx[2], nxx[3]));
-    st4(fl + F_SZZ * fs + o, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
-    st4(fl + F_SXZ * fs + o, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
 }
 
 __global__ void el_points_bbox(const int *cell, int npts_per_shot, int n1, int *bbox)
@@ -1283,9 +750,6 @@ struct mifwi_elastic_plan {
     int ng, gp, pitch, lx, rz, gs, ngroups;
     int W, wl, xr0, wx;
     long long field_stride, shot_stride, fields_elems, psix_elems, psiz_elems, coef_elems;
-    int fused;            // 1: one fused launch per forward step (LDS tile), 0: V and S launches
-    int adj_lean;         // 1: register-only adjoint kernels, 0: LDS-staged adjoint kernels
-    int TZ, TG;           // owned tile of the fused kernels (rows, float4 groups)
     long long psi_elems;  // psix+psiz rounded up to 64
 };
 
@@ -1299,6 +763,7 @@ ElParams el_base(const mifwi_elastic_plan *pl, const float *mat, const float *pz
     p.field_stride = (unsigned)pl->field_stride; p.shot_stride = pl->shot_stride;
     p.nshot = pl->d.nshot; p.gs = 1;
     p.W = pl->W; p.wl = pl->wl; p.xr0 = pl->xr0; p.wx = pl->wx;
+    p.fsurf = pl->d.free_surface;
     p.psix_shot = 4LL * pl->d.nz * pl->wx; p.psiz_shot = 4LL * 2 * pl->W * pl->gp;
     p.mat = mat; p.pz = pz; p.px = px;
     return p;
@@ -1351,57 +816,6 @@ void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, hipStream_t st)
     }
 }
 
-// Owned tile (rows x float4-groups) of the fused kernels: fit `bytes_per_cell` per staged cell in
-// `lds_cap`, then minimise (rounds of resident workgroups) x (staged cells per workgroup).
-void choose_tile(int nz, int ng, int nshot, int halo_rows, int halo_groups, int bytes_per_cell,
-                 int extra_bytes_per_owned_cell, int lds_cap, int *TZ, int *TG)
-{
-    double best = 1e300;
-    *TZ = 8; *TG = 8;
-    for (int tz = 6; tz <= 64; ++tz) {
-        for (int tg = 4; tg <= 40; ++tg) {
-            const long long groups = (long long)(tz + 2 * halo_rows) * (tg + 2 * halo_groups);
-            if (groups > 512) continue;                       // one thread per staged group
-            const long long lds = groups * 4 * bytes_per_cell + (long long)tz * tg * 4 * extra_bytes_per_owned_cell;
-            if (lds > lds_cap) continue;
-            const long long threads = std::max<long long>(kThreads, mifwi::round_up64(groups, 64));
-            const int per_cu = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(8, (160 * 1024) / lds), 2048 / threads));
-            const long long blocks = (long long)mifwi::ceil_div(nz, tz) * mifwi::ceil_div(ng, tg) * nshot;
-            const long long rounds = (blocks + 256LL * per_cu - 1) / (256LL * per_cu);
-            // latency-bound regime: a round costs a fixed latency plus its staged volume per CU
-            const long long per_cu_now = std::min<long long>(per_cu, (blocks + 255) / 256);
-            const double cost = (double)rounds * (6000.0 + (double)groups * per_cu_now);
-            if (cost < best) { best = cost; *TZ = tz; *TG = tg; }
-        }
-    }
-}
-
-size_t fwd_tile_lds(const mifwi_elastic_plan *pl)
-{
-    const size_t staged = (size_t)(pl->TZ + 2 * FH) * (pl->TG + 2 * FHG) * 4;
-    return sizeof(float) * (5 * staged + (size_t)pl->TZ * pl->TG * 4);
-}
-
-int fwd_tile_threads(const mifwi_elastic_plan *pl)
-{
-    const int groups = (pl->TZ + 2 * FH) * (pl->TG + 2 * FHG);
-    return std::max(kThreads, (int)mifwi::round_up64(groups, 64));
-}
-
-template <bool SAVE>
-void launch_fwd_tile(const mifwi_elastic_plan *pl, const ElParams &p0, hipStream_t st)
-{
-    ElParams p = p0;
-    p.TZ = pl->TZ; p.TG = pl->TG;
-    const int tiles_x = mifwi::ceil_div(pl->ng, pl->TG);
-    p.tiles_z = mifwi::ceil_div(pl->d.nz, pl->TZ);
-    int extra = 0;
-    if (p.smp_out0 != nullptr && p.nsmp > 0)
-        extra = mifwi::ceil_div(mifwi::ceil_div(p.nsmp, kThreads), tiles_x);
-    dim3 grid(tiles_x, p.tiles_z + extra, pl->d.nshot), block(fwd_tile_threads(pl));
-    hipLaunchKernelGGL((el_fwd_tile<SAVE>), grid, block, fwd_tile_lds(pl), st, p);
-}
-
 }  // namespace
 
 extern "C" {
@@ -1413,8 +827,9 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
         return mifwi::fail(MIFWI_EINVAL, "bad sizes nz=%d nx=%d nt=%d nshot=%d", d->nz, d->nx, d->nt,
                            d->nshot);
     if (d->ntap != 1 && d->ntap != 4) return mifwi::fail(MIFWI_EINVAL, "ntap must be 1 or 4");
-    if (d->free_surface != 0)
-        return mifwi::fail(MIFWI_EINVAL, "free_surface is not implemented in this build");
+    if (d->free_surface != 0 && d->free_surface != 1)
+        return mifwi::fail(MIFWI_EINVAL, "free_surface must be 0 or 1");
+    if (d->free_surface && d->nz < 4) return mifwi::fail(MIFWI_EINVAL, "free surface needs nz >= 4");
     if (d->pml_width < 0) return mifwi::fail(MIFWI_EINVAL, "pml_width < 0");
     int rc = mifwi::check_device(device);
     if (rc) return rc;
@@ -1451,7 +866,6 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     }
     { const int v = env_int("MIFWI_EL_LX", 0); if (v == 16 || v == 32 || v == 64) pl->lx = v; }
     pl->rz = 1;
-    { const int v = env_int("MIFWI_EL_RZ", 0); if (v == 1 || v == 2) pl->rz = v; }
     int gs = d->shots_per_group;
     if (gs <= 0) gs = env_int("MIFWI_EL_GS", 4);
     if (gs <= 0) gs = 1;
@@ -1459,16 +873,6 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     pl->gs = gs;
     pl->ngroups = mifwi::ceil_div(d->nshot, gs);
     pl->psi_elems = mifwi::round_up64(pl->psix_elems + pl->psiz_elems, 64);
-    pl->fused = env_int("MIFWI_EL_FUSED", 0) ? 1 : 0;
-    pl->adj_lean = env_int("MIFWI_EL_ADJ_LEAN", 0) ? 1 : 0;
-    choose_tile(d->nz, pl->ng, d->nshot, FH, FHG, 5 * 4, 4, 64 * 1024, &pl->TZ, &pl->TG);
-    { const int v = env_int("MIFWI_EL_TZ", 0); if (v >= 4 && v <= 96) pl->TZ = v; }
-    { const int v = env_int("MIFWI_EL_TG", 0); if (v >= 2 && v <= 64) pl->TG = v; }
-    if (fwd_tile_lds(pl) > 64 * 1024 || fwd_tile_threads(pl) > 512) {
-        delete pl;
-        return mifwi::fail(MIFWI_EINVAL, "fused tile %dx%d does not fit (64 KiB LDS, 512 threads)",
-                           pl->TZ, pl->TG);
-    }
     *plan = pl;
     return MIFWI_OK;
 }
@@ -1487,7 +891,7 @@ int mifwi_elastic_plan_layout(const mifwi_elastic_plan *pl, mifwi_elastic_layout
     out->coef_elems = pl->coef_elems;
     const long long psi = pl->psi_elems;
     const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
-    out->state_elems = 2 * (pl->fields_elems + psi);
+    out->state_elems = pl->fields_elems + psi;
     out->work_forward_elems = out->state_elems + bbox;
     out->work_backward_elems = pl->fields_elems + 2 * psi + 5LL * pl->ngroups * pl->coef_elems + bbox;
     return MIFWI_OK;
@@ -1511,21 +915,20 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
     if (rc) return rc;
     MIFWI_HIP_TRY(hipSetDevice(pl->device));
     hipStream_t st = (hipStream_t)stream;
-    // state layout: [fields A | fields B | psi A | psi B | bbox]; step n reads set (n & 1) and (fused
-    // path) writes set ((n+1) & 1); the two-launch path works in place on set A
+    // state layout: [fields | psi | bbox], updated in place
     const long long psi = pl->psi_elems;
-    float *fbuf[2] = {work, work + pl->fields_elems};
-    float *pbuf[2] = {work + 2 * pl->fields_elems, work + 2 * pl->fields_elems + psi};
-    int *bbox = reinterpret_cast<int *>(work + 2 * (pl->fields_elems + psi));
+    float *fbuf[1] = {work};
+    float *pbuf[1] = {work + pl->fields_elems};
+    int *bbox = reinterpret_cast<int *>(work + pl->fields_elems + psi);
     if (flags & MIFWI_ZERO_STATE)
-        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * 2 * (pl->fields_elems + psi), st));
+        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (pl->fields_elems + psi), st));
     if (d.nsrc > 0)
         hipLaunchKernelGGL(el_points_bbox, dim3(d.nshot), dim3(kThreads), 0, st, src_cell,
                            d.nsrc * d.ntap, d.nx, bbox);
     ElParams p = el_base(pl, mat, pz, px);
     const long long snap_step = 5LL * d.nshot * pl->coef_elems;
     const bool want_rec = rec_vx != nullptr && d.nrec > 0;
-    if (!pl->fused) {
+    {
         p.fields = fbuf[0]; p.psix = pbuf[0]; p.psiz = pbuf[0] + pl->psix_elems;
         ElParams ps = p;
         ps.ninj = d.nsrc; ps.ntap_inj = d.ntap; ps.inj_cell = src_cell; ps.inj_w = src_w;
@@ -1539,37 +942,6 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
             ps.smp_out1 = want_rec ? rec_vz + (long long)n * d.nshot * d.nrec : nullptr;
             if (snap) { launch_v<true>(pl, p, st); launch_s<true>(pl, ps, st); }
             else { launch_v<false>(pl, p, st); launch_s<false>(pl, ps, st); }
-        }
-    } else {
-        p.ninj = d.nsrc; p.ntap_inj = d.ntap; p.inj_cell = src_cell; p.inj_w = src_w;
-        p.inj_bbox = bbox;
-        p.nsmp = want_rec ? d.nrec : 0; p.ntap_smp = d.ntap; p.smp_cell = rec_cell; p.smp_w = rec_w;
-        for (int n = n_begin; n < n_end; ++n) {
-            const int a = n & 1, b = a ^ 1;
-            p.fin = fbuf[a]; p.fout = fbuf[b]; p.fields = fbuf[a];
-            p.psix = pbuf[a]; p.psiz = pbuf[a] + pl->psix_elems;
-            p.psix_out = pbuf[b]; p.psiz_out = pbuf[b] + pl->psix_elems;
-            p.S = snap ? snap + (long long)(n - n_begin) * snap_step : nullptr;
-            p.inj_amp0 = f ? f + (long long)n * d.nshot * d.nsrc : nullptr;
-            // deferred sampling: this launch's input holds the velocities of step n-1
-            const bool smp = want_rec && n > n_begin;
-            p.smp_out0 = smp ? rec_vx + (long long)(n - 1) * d.nshot * d.nrec : nullptr;
-            p.smp_out1 = smp ? rec_vz + (long long)(n - 1) * d.nshot * d.nrec : nullptr;
-            if (snap) launch_fwd_tile<true>(pl, p, st);
-            else launch_fwd_tile<false>(pl, p, st);
-        }
-        if (want_rec && n_end > n_begin) {
-            // sampling-only launch for the last step of this range
-            ElParams q = p;
-            q.fields = fbuf[n_end & 1];
-            q.smp_out0 = rec_vx + (long long)(n_end - 1) * d.nshot * d.nrec;
-            q.smp_out1 = rec_vz + (long long)(n_end - 1) * d.nshot * d.nrec;
-            q.tiles_z = 0;
-            q.TZ = pl->TZ; q.TG = pl->TG;
-            const int tiles_x = mifwi::ceil_div(pl->ng, pl->TG);
-            const int extra = mifwi::ceil_div(mifwi::ceil_div(q.nsmp, kThreads), tiles_x);
-            hipLaunchKernelGGL((el_fwd_tile<false>), dim3(tiles_x, extra, d.nshot),
-                               dim3(fwd_tile_threads(pl)), fwd_tile_lds(pl), st, q);
         }
     }
     MIFWI_HIP_TRY(hipGetLastError());
@@ -1619,8 +991,6 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
     const bool want_f = grad_f != nullptr && d.nsrc > 0;
     ps.nsmp = want_f ? d.nsrc : 0; ps.ntap_smp = d.ntap; ps.smp_cell = src_cell; ps.smp_w = src_w;
     const long long snap_step = 5LL * d.nshot * pl->coef_elems;
-    const int lz = kThreads / pl->lx;
-    const int tiles_x = mifwi::ceil_div(pl->ng, pl->lx), tiles_z = mifwi::ceil_div(d.nz, lz);
     for (int n = n_hi; n >= n_lo; --n) {
         // ping-pong of the adjoint memory variables is absolute in n (resumable ranges)
         const int par = (d.nt - 1 - n) & 1;
@@ -1631,33 +1001,14 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         ps.inj_amp0 = g_vx + (long long)n * d.nshot * d.nrec;
         ps.inj_amp1 = g_vz + (long long)n * d.nshot * d.nrec;
         ps.smp_out0 = want_f ? grad_f + (long long)n * d.nshot * d.nsrc : nullptr;
-        ps.tiles_z = tiles_z;
-        int extra = 0;
-        if (want_f) extra = mifwi::ceil_div(mifwi::ceil_div(ps.gs * ps.nsmp, kThreads), tiles_x);
         p.psix = ps.psix; p.psiz = ps.psiz; p.psix_out = ps.psix_out; p.psiz_out = ps.psiz_out;
-        if (!pl->adj_lean) {
+        {
             const int tx = mifwi::ceil_div(pl->ng, AGO), tz = mifwi::ceil_div(d.nz, ATZ);
             ps.tiles_z = tz;
             int ex = 0;
             if (want_f) ex = mifwi::ceil_div(mifwi::ceil_div(ps.gs * ps.nsmp, kThreads), tx);
-            hipLaunchKernelGGL(el_adj_s_lds, dim3(tx, tz + ex, pl->ngroups), dim3(kThreads), 0, st, ps);
-            hipLaunchKernelGGL(el_adj_v_lds, dim3(tx, tz, d.nshot), dim3(kThreads), 0, st, p);
-            continue;
-        }
-        const dim3 gs_(tiles_x, tiles_z + extra, pl->ngroups), gv_(tiles_x, tiles_z, d.nshot);
-        switch (pl->lx) {
-            case 64:
-                hipLaunchKernelGGL((el_adj_s<64>), gs_, dim3(kThreads), 0, st, ps);
-                hipLaunchKernelGGL((el_adj_v<64>), gv_, dim3(kThreads), 0, st, p);
-                break;
-            case 32:
-                hipLaunchKernelGGL((el_adj_s<32>), gs_, dim3(kThreads), 0, st, ps);
-                hipLaunchKernelGGL((el_adj_v<32>), gv_, dim3(kThreads), 0, st, p);
-                break;
-            default:
-                hipLaunchKernelGGL((el_adj_s<16>), gs_, dim3(kThreads), 0, st, ps);
-                hipLaunchKernelGGL((el_adj_v<16>), gv_, dim3(kThreads), 0, st, p);
-                break;
+            hipLaunchKernelGGL(el_adj_s, dim3(tx, tz + ex, pl->ngroups), dim3(kThreads), 0, st, ps);
+            hipLaunchKernelGGL(el_adj_v, dim3(tx, tz, d.nshot), dim3(kThreads), 0, st, p);
         }
     }
     if (flags & MIFWI_FINALIZE) {

@@ -17,8 +17,11 @@ from .acoustic import _Geometry, _require_cuda, _stream
 DEFAULT_SNAPSHOT_BUDGET = 96 << 30
 
 
-def staggered_materials(vp, vs, rho, dt, h):
+def staggered_materials(vp, vs, rho, dt, h, free_surface=False):
     """[5, nz, nx] = lambda dt/h, (lambda+2mu) dt/h, mu_xz dt/h, dt/(h rho_x), dt/(h rho_z).
+    With ``free_surface`` row 0 of the first two planes is put in the effective form the
+    stress-imaging condition needs (szz = 0 there): lambda -> 0, lambda+2mu -> (lambda+2mu) -
+    lambda^2/(lambda+2mu).
 
     Arithmetic averaging of density to the vx / vz nodes, harmonic averaging of the shear
     modulus to the sxz node (0 where any of the four is 0, i.e. in water), edge values
@@ -37,7 +40,13 @@ def staggered_materials(vp, vs, rho, dt, h):
     anyzero = (m4[0] == 0) | (m4[1] == 0) | (m4[2] == 0) | (m4[3] == 0)
     inv = sum(1.0 / torch.where(m == 0, torch.ones_like(m), m) for m in m4)
     muxz = torch.where(anyzero, torch.zeros_like(mu), 4.0 / inv)
-    return torch.stack([lam * s, (lam + 2.0 * mu) * s, muxz * s, s / rx, s / rz])
+    Ls, Ms = lam * s, (lam + 2.0 * mu) * s
+    if free_surface:
+        top = torch.zeros_like(Ls)
+        top[0] = 1.0
+        Ms = Ms - top * (Ls * Ls / Ms)
+        Ls = Ls * (1.0 - top)
+    return torch.stack([Ls, Ms, muxz * s, s / rx, s / rz])
 
 
 class ElasticPlan:
@@ -70,7 +79,7 @@ class ElasticPlan:
 
 class _ElasticFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mat, f, pz, px, geom, pml_width, shots_per_group, snapshot_budget):
+    def forward(ctx, mat, f, pz, px, geom, pml_width, shots_per_group, snapshot_budget, free_surface):
         _require_cuda(mat, "mat")
         dev = mat.device
         lib = _lib.load()
@@ -85,7 +94,7 @@ class _ElasticFn(torch.autograd.Function):
                 raise MifwiError("%s holds a cell outside the %dx%d grid" % (name, nz, nx))
         with torch.cuda.device(dev):
             plan = ElasticPlan(nz, nx, nt, ns, nsrc, nrec, ntap, pml_width, dev.index,
-                               shots_per_group)
+                               shots_per_group, free_surface)
             lay = plan.layout
             gp = lay.gp
             mat_p = torch.zeros((5, nz, gp), device=dev, dtype=torch.float32)
@@ -182,18 +191,20 @@ class _ElasticFn(torch.autograd.Function):
             plan.close()
             ctx.snap = None
             ctx.ckpt = None
-        return (grad_mat[:, :, :nx].contiguous(), grad_f, None, None, None, None, None, None)
+        return (grad_mat[:, :, :nx].contiguous(), grad_f, None, None, None, None, None, None, None)
 
 
 def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
-              shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET):
+              shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET, free_surface=False):
     """Elastic forward modelling, differentiable w.r.t. ``mat`` and ``f``.
 
     mat [5,nz,nx] from :func:`staggered_materials`;  f [nt,nshot,nsrc] (added to sxx and szz);
     pz [6,nz], px [6,nx] from :func:`profiles.cpml_tables`;  cells are iz*nx+ix.
+    free_surface: row 0 is a stress-free surface (build ``mat`` with ``free_surface=True`` and
+    ``pz`` with ``low=False``).
     Returns (rec_vx, rec_vz), each [nt,nshot,nrec], sampled after the velocity update."""
     _require_cuda(mat, "mat")
     geom = _Geometry(src_cell, src_w, rec_cell, rec_w, mat.device)
     f = f.to(device=mat.device)
     return _ElasticFn.apply(mat, f, pz, px, geom, int(pml_width), int(shots_per_group),
-                            int(snapshot_budget))
+                            int(snapshot_budget), 1 if free_surface else 0)

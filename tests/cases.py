@@ -48,7 +48,7 @@ def rel_l2(a, b):
 
 
 def elastic_case(seed=0, nz=44, nx=60, fw=8, nt=120, ns=2, nsrc=1, nrec=9, h=20.0, dt=0.002,
-                 water=6, freq=8.0):
+                 water=6, freq=8.0, free_surface=False):
     """Random elastic model with a water layer, sources inside the top C-PML."""
     rng = np.random.default_rng(seed)
     vp = 1800 + 1500 * rng.random((nz, nx))
@@ -58,18 +58,20 @@ def elastic_case(seed=0, nz=44, nx=60, fw=8, nt=120, ns=2, nsrc=1, nrec=9, h=20.
         vs[:water] = 0.0
         vp[:water] = 1500.0
         rho[:water] = 1000.0
-    mat = H.elastic_materials(vp, vs, rho, dt, h)
-    pz = H.cpml_profiles(nz, fw, h, dt, 3000.0, 5.0)
+    mat = H.elastic_materials(vp, vs, rho, dt, h, free_surface=free_surface)
+    pz = H.cpml_profiles(nz, fw, h, dt, 3000.0, 5.0, lo=not free_surface)
     px = H.cpml_profiles(nx, fw, h, dt, 3000.0, 5.0)
     f = np.zeros((nt, ns, nsrc))
     for i in range(nsrc):
         f[:, :, i] = (H.ricker_deepwave(freq * (1 + 0.2 * i), nt, dt, 1.2 / freq) * 1e6)[:, None]
     f *= (1.0 + 0.1 * np.arange(ns))[None, :, None]
-    sz = rng.integers(2, 5, (ns, nsrc))
+    sz = rng.integers(0 if free_surface else 2, 5, (ns, nsrc))
     sx = rng.integers(4, nx - 4, (ns, nsrc))
     sc, sw = H.cell_taps(sz, sx, nx)
     rz_ = np.full((ns, nrec), min(nz - 3, water + 14))
     rx_ = np.linspace(2, nx - 3, nrec).astype(int)[None, :].repeat(ns, 0)
     rc, rw = H.cell_taps(rz_, rx_, nx)
+    if free_surface:           # a receiver spread on the surface row exercises the mirrored rows
+        rc[0], rw[0] = H.cell_taps(np.zeros((1, nrec), dtype=int), rx_[:1], nx)
     return dict(mat=mat, pz=pz, px=px, f=f, sc=sc, sw=sw, rc=rc, rw=rw, fw=fw, vp=vp, vs=vs,
-                rho=rho, dt=dt, h=h)
+                rho=rho, dt=dt, h=h, fs=1 if free_surface else 0)

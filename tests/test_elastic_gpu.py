@@ -24,7 +24,7 @@ def _run_hip(case, gs=0, budget=None, need_f=True):
     rvx, rvz = elastic.propagate(mat, f, torch.tensor(case["pz"]), torch.tensor(case["px"]),
                                  torch.tensor(case["sc"]), torch.tensor(case["sw"]),
                                  torch.tensor(case["rc"]), torch.tensor(case["rw"]),
-                                 case["fw"], shots_per_group=gs, **kw)
+                                 case["fw"], shots_per_group=gs, free_surface=bool(case["fs"]), **kw)
     return mat, f, rvx, rvz
 
 
@@ -33,12 +33,15 @@ def _run_hip(case, gs=0, budget=None, need_f=True):
     dict(nz=37, nx=53, fw=6, ns=3, nrec=11),              # ragged sizes
     dict(nz=70, nx=300, fw=10, ns=2, nrec=30, nt=80),     # reference grid width, LX=64
     dict(nz=50, nx=66, fw=0, water=0),                     # no absorbing layer at all
+    dict(free_surface=True),                               # stress-imaging free surface, water on top
+    dict(free_surface=True, water=0, nz=37, nx=53, fw=6),  # free surface on a solid, ragged sizes
 ])
 def test_forward_backward_parity(oracle32, kw):
     case = elastic_case(seed=4, **kw)
     o = oracle32
     ovx, ovz, S = o.elastic_forward(case["mat"], case["pz"], case["px"], case["f"], case["sc"],
-                                    case["sw"], case["rc"], case["rw"], save=True)
+                                    case["sw"], case["rc"], case["rw"], save=True,
+                                    free_surface=case["fs"])
     mat, f, rvx, rvz = _run_hip(case)
     hx, hz = rvx.detach().cpu().numpy(), rvz.detach().cpu().numpy()
     assert np.isfinite(hx).all() and np.abs(ovx).max() > 0 and np.abs(ovz).max() > 0
@@ -50,7 +53,7 @@ def test_forward_backward_parity(oracle32, kw):
     torch.autograd.backward([rvx, rvz], [torch.tensor(gx, device=rvx.device),
                                          torch.tensor(gz, device=rvx.device)])
     gm_o, gf_o = o.elastic_backward(case["mat"], case["pz"], case["px"], case["sc"], case["sw"],
-                                    case["rc"], case["rw"], gx, gz, S)
+                                    case["rc"], case["rw"], gx, gz, S, free_surface=case["fs"])
     gm_h = mat.grad.cpu().numpy()
     for k, name in enumerate(["lambda", "lambda+2mu", "mu_xz", "1/rho_x", "1/rho_z"]):
         assert rel_l2(gm_h[k], gm_o[k]) <= TOL_GRAD, name

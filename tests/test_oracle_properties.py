@@ -204,3 +204,47 @@ def test_elastic_homogeneous_pressure_wave_speed(oracle64):
     t_peak = np.argmax(np.abs(vx[:, 0, 0])) * dt
     expect = 0.05 + 60 * h / vp0
     assert abs(t_peak - expect) < 0.012
+
+
+@pytest.mark.parametrize("water", [0, 6])
+def test_elastic_free_surface_adjoint_is_exact(oracle64, water):
+    """FREE_SURF=1 (networks.py:9811): odd stress mirroring + szz(0)=0; the transposed scheme must
+    give a clean second-order Taylor remainder and pass the dot-product test."""
+    o = oracle64
+    c = elastic_case(seed=11, free_surface=True, water=water, nsrc=2)
+    geo = (c["sc"], c["sw"], c["rc"], c["rw"])
+    rng = np.random.default_rng(3)
+    vx, vz, S = o.elastic_forward(c["mat"], c["pz"], c["px"], c["f"], *geo, save=True, free_surface=1)
+    ox = vx + rng.standard_normal(vx.shape) * 0.3 * np.abs(vx).max()
+    oz = vz + rng.standard_normal(vz.shape) * 0.3 * np.abs(vz).max()
+    gm, gf = o.elastic_backward(c["mat"], c["pz"], c["px"], *geo, vx - ox, vz - oz, S, free_surface=1)
+    dm = rng.standard_normal(c["mat"].shape) * c["mat"] * 0.02
+    df = rng.standard_normal(c["f"].shape) * np.abs(c["f"]).max() * 0.05
+
+    def J(h):
+        a, b = o.elastic_forward(c["mat"] + h * dm, c["pz"], c["px"], c["f"] + h * df, *geo,
+                                 free_surface=1)
+        return 0.5 * np.sum((a - ox) ** 2) + 0.5 * np.sum((b - oz) ** 2)
+    _, p2 = _taylor(J, np.sum(gm * dm) + np.sum(gf * df), [1e-2, 1e-3, 1e-4])
+    assert abs(p2 - 2.0) < 0.02
+    q = rng.standard_normal(c["f"].shape)
+    a, b, S2 = o.elastic_forward(c["mat"], c["pz"], c["px"], q, *geo, save=True, free_surface=1)
+    dx, dz = rng.standard_normal(a.shape), rng.standard_normal(b.shape)
+    _, gq = o.elastic_backward(c["mat"], c["pz"], c["px"], *geo, dx, dz, S2, free_surface=1)
+    lhs, rhs = np.sum(a * dx) + np.sum(b * dz), np.sum(q * gq)
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
+
+
+def test_free_surface_reflects(oracle64):
+    """With the free surface the top reflects (energy stays longer) while C-PML on top absorbs."""
+    o = oracle64
+    kw = dict(seed=7, nz=70, nx=70, fw=10, nt=700, ns=1, nrec=5, water=0, freq=10.0)
+    cf, ca = elastic_case(free_surface=True, **kw), elastic_case(free_surface=False, **kw)
+    for c in (cf, ca):          # same source a few rows below the top, same receivers
+        c["sc"], c["sw"] = H.cell_taps([[6]], [[35]], 70)
+        c["rc"], c["rw"] = H.cell_taps([[30] * 5], [[15, 25, 35, 45, 55]], 70)
+    vf = o.elastic_forward(cf["mat"], cf["pz"], cf["px"], cf["f"], cf["sc"], cf["sw"], cf["rc"], cf["rw"],
+                           free_surface=1)[1]
+    va = o.elastic_forward(ca["mat"], ca["pz"], ca["px"], ca["f"], ca["sc"], ca["sw"], ca["rc"], ca["rw"])[1]
+    assert np.isfinite(vf).all()
+    assert np.sum(vf ** 2) > 1.2 * np.sum(va ** 2)
