@@ -179,8 +179,6 @@ int oracle_elastic_forward(const oracle_elastic_cfg *c, const real *mat, const r
                 }
             step_v(&g, mat, pz, px, &st, Sn);
             step_s(&g, mat, pz, px, &st, Sn);
-            if (c->free_surface)
-                for (int i = 0; i < nx; ++i) st.szz[at(&g, 0, i)] = 0;
             for (int is = 0; is < c->nsrc; ++is) {
                 const real amp = f[((size_t)n * ns + s) * c->nsrc + is];
                 for (int t = 0; t < c->ntap; ++t) {
@@ -193,6 +191,8 @@ int oracle_elastic_forward(const oracle_elastic_cfg *c, const real *mat, const r
                     st.szz[k] += a;
                 }
             }
+            if (c->free_surface)       /* after the source term: szz(0,.) stays identically 0 */
+                for (int i = 0; i < nx; ++i) st.szz[at(&g, 0, i)] = 0;
             for (int ir = 0; ir < c->nrec; ++ir) {
                 real ax = 0, az = 0;
                 for (int t = 0; t < c->ntap; ++t) {

@@ -66,6 +66,8 @@ def elastic_case(seed=0, nz=44, nx=60, fw=8, nt=120, ns=2, nsrc=1, nrec=9, h=20.
         f[:, :, i] = (H.ricker_deepwave(freq * (1 + 0.2 * i), nt, dt, 1.2 / freq) * 1e6)[:, None]
     f *= (1.0 + 0.1 * np.arange(ns))[None, :, None]
     sz = rng.integers(0 if free_surface else 2, 5, (ns, nsrc))
+    if free_surface:
+        sz[0, 0] = 0           # a source ON the free surface: szz(0,.) must stay 0
     sx = rng.integers(4, nx - 4, (ns, nsrc))
     sc, sw = H.cell_taps(sz, sx, nx)
     rz_ = np.full((ns, nrec), min(nz - 3, water + 14))
