@@ -21,6 +21,7 @@
 // -ffp-contract=off) so wavefields can be compared bitwise.
 #include "mifwi_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -295,6 +296,522 @@ __global__ void ac_finalize(const float *acc, int ngroups, int n0, int n1, int g
     grad[idx] = out;
 }
 
+
+// ================================================================================================
+// CLUSTER kernels: wavefields resident in LDS for the whole time loop.
+//
+// Marmousi-sized shots (the sizes the reference actually runs: 151x200, 174x500, 100x300 ...) are
+// far too small to keep 256 CUs busy with one launch per time step: such a step is bounded by the
+// launch boundary (1.5 us) and the memory round trip, not by HBM bandwidth.  Here a shot is cut
+// into NW row slabs, one workgroup (= one CU, ~130 KB of its 160 KB LDS) per slab, NW*nshot <= the
+// CU count so every workgroup is resident, and ONE launch runs all time steps:
+//   * both time levels of the slab (+2 halo rows) live in LDS; the coefficient r, the damping and
+//     (adjoint) the gradient accumulator of a thread's cells live in registers for the whole run,
+//     so the only per-step global traffic is the snapshot stream (4 B/cell) and the halo rows;
+//   * after each step the two boundary rows are handed to the neighbouring slab through global
+//     memory as self-validating 8-byte granules {epoch, value} written with agent-scope (sc1)
+//     stores and polled with agent-scope loads (cdna_hip_programming.md, Guideline 16, form R2):
+//     no flag, no fence, no grid barrier.  Granule slots are double-buffered on the epoch parity:
+//     a slab may run ONE step ahead of a neighbour (publishing epoch n+1 only needs the
+//     neighbour's epoch-n rows, not the neighbour's consumption of ours), but not two (epoch n+2
+//     needs the neighbour's n+1, which the neighbour publishes after consuming our epoch n);
+//   * every spin is bounded; on a time-out the workgroup raises a global error word that all other
+//     workgroups also watch, so the grid always drains.
+// The arithmetic per cell is the same fmaf chain as ac_step (bitwise identical results).
+// ================================================================================================
+constexpr int kClThreads = 1024;
+constexpr int kClMaxNG = 4;                  // groups of 4 cells a thread may own
+constexpr unsigned kClMaxSpin = 400000;
+
+struct ClParams {
+    int n0, n1, ng, gp, pitch;
+    long long shot_stride;
+    int nshot, NW, PL;           // slabs per shot, LDS row pitch (floats)
+    int shot0, shot1;            // shots [shot0, shot1) are handled by this launch
+    int dbg;                     // timing experiments only: 1 = skip the halo hand-off, 2 = skip snapshots
+    int nt, n_first, n_last;     // forward: steps n_first..n_last-1 ; adjoint: k = n_first down to n_last
+    float c0, c1;
+    const float *r, *q0, *q1;
+    float *ua, *ub;              // global state (same layout as the per-step kernels)
+    float *G;                    // snapshot base; step n at G + (n - g_first) * g_step
+    int g_first;
+    long long g_step;
+    float *acc;                  // adjoint: [nshot][n0][gp]
+    // few-point list handled by the cell owners (forward: sources -> injection + G term)
+    int nsrc, ntap;
+    const int *src_cell;
+    const float *src_w;
+    const float *f;              // forward: [nt][nshot][nsrc]
+    // many-point list (forward: receivers sampled from u^n; adjoint: receivers injected)
+    int nrec;
+    const int *rec_cell;
+    const float *rec_w;
+    float *rec_out;              // forward: [nt][nshot][nrec]
+    const float *grad_rec;       // adjoint: [nt][nshot][nrec]
+    float *grad_f;               // adjoint: [nt][nshot][nsrc] or null
+    const int *slab_cnt;         // adjoint: [nshot][NW] number of receiver taps in the slab
+    const int *slab_list;        // adjoint: [nshot][NW][nrec*ntap] tap ids (shot-local)
+    unsigned long long *xbuf;    // granules [nshot][NW][2 epoch slots][2 sides][2 rows][gp]
+    int *err;
+};
+
+__device__ __forceinline__ void slab_rows(int n0, int NW, int w, int &r0, int &rows)
+{
+    const int base = n0 / NW, rem = n0 - base * NW;
+    rows = base + (w < rem ? 1 : 0);
+    r0 = w * base + (w < rem ? w : rem);
+}
+
+// lists of the receiver taps that fall into each slab (adjoint injection), one block per shot
+__global__ void cl_build_slab_lists(const int *rec_cell, int ntaps, int n0, int n1, int NW,
+                                    int *slab_cnt, int *slab_list)
+{
+    const int s = blockIdx.x;
+    __shared__ int cnt[64];
+    if ((int)threadIdx.x < NW) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = n0 / NW, rem = n0 - base * NW;
+    for (int e = threadIdx.x; e < ntaps; e += blockDim.x) {
+        const int cell = rec_cell[(long long)s * ntaps + e];
+        if (cell < 0) continue;
+        const int i0 = cell / n1;
+        // invert slab_rows: first `rem` slabs have base+1 rows
+        int w = (i0 < rem * (base + 1)) ? i0 / (base + 1) : rem + (i0 - rem * (base + 1)) / base;
+        const int pos = atomicAdd(&cnt[w], 1);
+        slab_list[((long long)s * NW + w) * ntaps + pos] = e;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NW) slab_cnt[s * NW + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// one stencil update of a group of 4 cells whose operands sit in LDS.  Same fmaf chain as ac_step,
+// written on 2-wide vectors so that hipcc emits packed fp32 VALU (v_pk_fma/mul/add_f32: two cells
+// per instruction, IEEE per lane, so results stay bitwise identical to the scalar form).
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <bool WANT_G>
+__device__ __forceinline__ void cl_update(const float *c, const float *pp, int PL, const float4 &rv4,
+                                          float q0, const float4 &q1, bool damped, float c0, float c1,
+                                          int ncol_valid, float (&un)[4], float (&gk)[4])
+{
+    const float4 w2 = *reinterpret_cast<const float4 *>(c);
+    const float4 w0 = *reinterpret_cast<const float4 *>(c - 2 * PL);
+    const float4 w1 = *reinterpret_cast<const float4 *>(c - PL);
+    const float4 w3 = *reinterpret_cast<const float4 *>(c + PL);
+    const float4 w4 = *reinterpret_cast<const float4 *>(c + 2 * PL);
+    const float2 Lh = *reinterpret_cast<const float2 *>(c - 2);
+    const float2 Rh = *reinterpret_cast<const float2 *>(c + 4);
+    const float4 up = *reinterpret_cast<const float4 *>(pp);
+    const f2 k0 = {K0, K0}, k1 = {K1, K1}, k2 = {K2, K2}, vc0 = {c0, c0}, vc1 = {c1, c1};
+    const f2 two = {2.0f, 2.0f}, mone = {-1.0f, -1.0f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // cells 2h, 2h+1
+        const f2 uc = h == 0 ? f2{w2.x, w2.y} : f2{w2.z, w2.w};
+        const f2 zm1 = h == 0 ? f2{w1.x, w1.y} : f2{w1.z, w1.w};
+        const f2 zp1 = h == 0 ? f2{w3.x, w3.y} : f2{w3.z, w3.w};
+        const f2 zm2 = h == 0 ? f2{w0.x, w0.y} : f2{w0.z, w0.w};
+        const f2 zp2 = h == 0 ? f2{w4.x, w4.y} : f2{w4.z, w4.w};
+        const f2 xm1 = h == 0 ? f2{Lh.y, w2.x} : f2{w2.y, w2.z};
+        const f2 xp1 = h == 0 ? f2{w2.y, w2.z} : f2{w2.w, Rh.x};
+        const f2 xm2 = h == 0 ? f2{Lh.x, Lh.y} : f2{w2.x, w2.y};
+        const f2 xp2 = h == 0 ? f2{w2.z, w2.w} : f2{Rh.x, Rh.y};
+        const f2 rv = h == 0 ? f2{rv4.x, rv4.y} : f2{rv4.z, rv4.w};
+        const f2 upv = h == 0 ? f2{up.x, up.y} : f2{up.z, up.w};
+        const f2 s01 = zm1 + zp1, s02 = zm2 + zp2, s11 = xm1 + xp1, s12 = xm2 + xp2;
+        const f2 l0 = pk_fma(k1, s01, pk_fma(k2, s02, k0 * uc));
+        const f2 l1 = pk_fma(k1, s11, pk_fma(k2, s12, k0 * uc));
+        const f2 lap = pk_fma(vc0, l0, vc1 * l1);
+        f2 v, g;
+        if (damped) {
+            const f2 q = f2{q0, q0} + (h == 0 ? f2{q1.x, q1.y} : f2{q1.z, q1.w});
+            const f2 qr = q * rv;
+            const f2 den = f2{1.0f, 1.0f} + qr;
+            const f2 inv = {1.0f / den.x, 1.0f / den.y};
+            const f2 num = pk_fma(rv, lap, pk_fma(-(f2{1.0f, 1.0f} - qr), upv, two * uc));
+            v = inv * num;
+            g = inv * (pk_fma(q, upv, lap) - q * v);
+        } else {
+            // q == 0 on all four cells: inv == 1 exactly, the general formula reduces bit for bit to this
+            v = pk_fma(rv, lap, pk_fma(mone, upv, two * uc));
+            g = lap;
+        }
+        un[2 * h] = (2 * h >= ncol_valid) ? 0.f : v.x;
+        un[2 * h + 1] = (2 * h + 1 >= ncol_valid) ? 0.f : v.y;
+        if (WANT_G) { gk[2 * h] = g.x; gk[2 * h + 1] = g.y; }
+    }
+}
+
+template <int MODE>   // 0: forward, 1: forward + snapshots, 2: adjoint + imaging
+__global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // XCD-aware mapping: consecutive linear ids go to different XCDs, so give all slabs of a shot
+    // ids that are congruent mod 8 (speed only; correctness never depends on placement)
+    const int L = (int)blockIdx.x;
+    const int xcd = L & 7, k = L >> 3;
+    const int w = k % p.NW, s = p.shot0 + xcd + 8 * (k / p.NW);
+    if (s >= p.shot1) return;
+    const int t = (int)threadIdx.x;
+    constexpr bool adj = (MODE == 2);
+    int r0, R;
+    slab_rows(p.n0, p.NW, w, r0, R);
+    const int PL = p.PL, LR = R + 4;
+    float *bufA = lds, *bufB = lds + LR * PL;     // rows: 0,1 top halo | 2..R+1 own | R+2,R+3 bottom halo
+    float *ldq1 = bufB + LR * PL;                 // damping tables (constant over the run): q1[gp], q0[R]
+    float *ldq0 = ldq1 + p.gp;
+    const int ngrp = R * p.ng;
+    // row order with the four boundary rows first, so that a thread's slot 0 covers every group the
+    // neighbours wait for: 0, 1, R-2, R-1, 2, 3, ..., R-3   (R >= 4 is guaranteed by the plan)
+    auto row_of = [&](int k_) { return k_ < 2 ? k_ : (k_ < 4 ? R - 4 + k_ : k_ - 2); };
+
+    // ---- per-thread constants: owned groups, coefficients, accumulators -----------------------
+    int loff[kClMaxNG];                 // LDS offset of the group in a level buffer
+    float4 rr[kClMaxNG], acc[kClMaxNG];
+    int jg[kClMaxNG];                   // (grid row << 12) | group
+    auto goff = [&](int i_) { return (long long)(jg[i_] >> 12) * p.gp + 4 * (jg[i_] & 4095); };
+    unsigned dampmask = 0;
+    int nown = 0;
+#pragma unroll
+    for (int i = 0; i < kClMaxNG; ++i) {
+        const int gi = t + i * kClThreads;
+        loff[i] = 0; jg[i] = 0;
+        rr[i] = acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gi < ngrp) {
+            nown = i + 1;
+            const int kr = gi / p.ng, g = gi - kr * p.ng;
+            const int lrw = row_of(kr), j = r0 + lrw;
+            loff[i] = (lrw + 2) * PL + 4 + 4 * g;
+            jg[i] = (j << 12) | g;
+            rr[i] = *reinterpret_cast<const float4 *>(p.r + (long long)j * p.gp + 4 * g);
+            const float4 q1 = *reinterpret_cast<const float4 *>(p.q1 + 4 * g);
+            const float q0 = p.q0[j];
+            if (q0 != 0.f || q1.x != 0.f || q1.y != 0.f || q1.z != 0.f || q1.w != 0.f) dampmask |= 1u << i;
+            if (adj) acc[i] = *reinterpret_cast<const float4 *>(p.acc + ((long long)s * p.n0 + j) * p.gp + 4 * g);
+        }
+    }
+    // ---- per-thread sparse points (at most one of each kind per thread in this path) ------------
+    // forward: source tap inside one of my groups; receiver sampled by me.  adjoint: receiver tap
+    // injected by me (slab list); source sampled by me for grad_f.
+    int src_slot = -1, src_comp = 0, src_e = -1;        // forward injection (owner side)
+    float src_wt = 0.f;
+    int smp_off = -1, smp_e = -1;                        // sampling of `cur`
+    float smp_w = 0.f;
+    int inj_off = -1, inj_id = -1;                       // adjoint injection into LDS
+    float inj_scale = 0.f;
+    bool slow_sparse = false;                            // more points than one per thread: rescan per step
+    if (!adj) {
+        for (int e = 0; e < p.nsrc; ++e) {
+            const int cell = p.src_cell[(long long)s * p.nsrc + e];
+            if (cell < 0) continue;
+            const int i0 = cell / p.n1, i1 = cell - i0 * p.n1;
+            if (i0 < r0 || i0 >= r0 + R) continue;
+            const long long want = (long long)i0 * p.gp + (i1 & ~3);
+#pragma unroll
+            for (int i = 0; i < kClMaxNG; ++i)
+                if (i < nown && goff(i) == want) {
+                    if (src_slot >= 0) slow_sparse = true;
+                    src_slot = i; src_comp = i1 & 3; src_e = e;
+                    src_wt = p.src_w[(long long)s * p.nsrc + e];
+                }
+        }
+        if (p.nrec > kClThreads) slow_sparse = true;
+        if (p.rec_out != nullptr && t < p.nrec) {
+            const int cell = p.rec_cell[(long long)s * p.nrec + t];
+            smp_e = t;
+            if (cell >= 0) {
+                const int i0 = cell / p.n1, i1 = cell - i0 * p.n1;
+                if (i0 >= r0 && i0 < r0 + R) {
+                    smp_off = (i0 - r0 + 2) * PL + 4 + i1;
+                    smp_w = p.rec_w[(long long)s * p.nrec + t];
+                }
+            } else if (w == 0) {
+                smp_off = -2;                            // inactive tap: slab 0 writes the zero
+            }
+        }
+    } else {
+        const int cnt = p.slab_cnt[s * p.NW + w];
+        if (cnt > kClThreads || p.nsrc > kClThreads) slow_sparse = true;
+        if (t < cnt) {
+            const int id = p.slab_list[((long long)s * p.NW + w) * p.nrec + t];
+            const int cell = p.rec_cell[(long long)s * p.nrec + id];
+            const int i0 = cell / p.n1, i1 = cell - i0 * p.n1;
+            const float rv = p.r[(long long)i0 * p.gp + i1];
+            const float q = p.q0[i0] + p.q1[i1];
+            const float inv = 1.0f / (1.0f + q * rv);
+            inj_off = (i0 - r0 + 2) * PL + 4 + i1;
+            inj_id = id;
+            inj_scale = rv * inv;
+            smp_w = p.rec_w[(long long)s * p.nrec + id];          // reused as the tap weight
+        }
+        if (p.grad_f != nullptr && t < p.nsrc) {
+            const int cell = p.src_cell[(long long)s * p.nsrc + t];
+            smp_e = t;
+            if (cell >= 0) {
+                const int i0 = cell / p.n1, i1 = cell - i0 * p.n1;
+                if (i0 >= r0 && i0 < r0 + R) {
+                    const float q = p.q0[i0] + p.q1[i1];
+                    smp_off = (i0 - r0 + 2) * PL + 4 + i1;
+                    src_wt = p.src_w[(long long)s * p.nsrc + t] * (1.0f + q * p.r[(long long)i0 * p.gp + i1]);
+                }
+            } else if (w == 0) {
+                smp_off = -2;
+            }
+        }
+    }
+    slow_sparse = __syncthreads_or(slow_sparse ? 1 : 0) != 0;
+
+    for (int e = t; e < p.gp; e += kClThreads) ldq1[e] = p.q1[e];
+    for (int e = t; e < R; e += kClThreads) ldq0[e] = p.q0[r0 + e];
+    // ---- load the slab (+ halo rows) of both time levels from the global state ------------------
+    // buffer parity is absolute in the step index, as in the per-step path
+    const int par0 = adj ? ((p.nt - 1 - p.n_first) & 1) : (p.n_first & 1);
+    const float *gcur = (par0 ? p.ub : p.ua) + (long long)s * p.shot_stride;
+    const float *gprev = (par0 ? p.ua : p.ub) + (long long)s * p.shot_stride;
+    for (int e = t; e < LR * (PL / 4); e += kClThreads) {
+        const int lr = e / (PL / 4), lg = e - lr * (PL / 4);      // lg = 0 is the left halo group
+        const int j = r0 - 2 + lr, g = lg - 1;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (j >= 0 && j < p.n0 && g >= 0 && g < p.ng) {
+            const long long o = (long long)(j + 2) * p.pitch + 4 + 4 * g;
+            a = *reinterpret_cast<const float4 *>(gcur + o);
+            b = *reinterpret_cast<const float4 *>(gprev + o);
+        }
+        *reinterpret_cast<float4 *>(bufA + lr * PL + 4 * lg) = a;
+        *reinterpret_cast<float4 *>(bufB + lr * PL + 4 * lg) = b;
+    }
+    __syncthreads();
+    float *cur = bufA, *prv = bufB;
+
+    const long long xslab = 8LL * p.gp;                                   // 2 slots x 4 rows x gp
+    unsigned long long *xmine0 = p.xbuf + ((long long)s * p.NW + w) * xslab;
+    const unsigned long long *xup0 = xmine0 - xslab;                      // valid if w > 0
+    const unsigned long long *xdn0 = xmine0 + xslab;                      // valid if w < NW-1
+    const int nsteps = adj ? (p.n_first - p.n_last + 1) : (p.n_last - p.n_first);
+    const long long plane = (long long)s * p.n0 * p.gp;
+    bool failed = false;
+    const bool do_x = p.NW > 1 && !(p.dbg & 1);
+    // forward: all four boundary rows live in slot 0 when a row has at most kClThreads/4 groups
+    const bool early_pub = !adj && do_x && 4 * p.ng <= kClThreads;
+
+    // software prefetch of the next step's global operands (issued before this step's stores, so
+    // that they do not queue behind them): source / adjoint-source amplitude and, in the adjoint,
+    // the snapshot values the imaging condition multiplies with
+    float amp_next = 0.f;
+    float4 Gbuf[kClMaxNG];              // adjoint: snapshot values of the coming step; forward: values to store
+    auto prefetch = [&](int it_) {
+        if (it_ >= nsteps) return;
+        const int n_ = adj ? (p.n_first - it_) : (p.n_first + it_);
+        if (!adj) {
+            if (src_slot >= 0) amp_next = p.f[((long long)n_ * p.nshot + s) * p.nsrc + src_e];
+        } else {
+            if (inj_off >= 0) amp_next = p.grad_rec[((long long)n_ * p.nshot + s) * p.nrec + inj_id];
+            const float *Gq = p.G + (long long)((n_ - 1) - p.g_first) * p.g_step + plane;
+#pragma unroll
+            for (int i = 0; i < kClMaxNG; ++i)
+                if (i < nown) Gbuf[i] = *reinterpret_cast<const float4 *>(Gq + goff(i));
+        }
+    };
+    prefetch(0);
+
+    for (int it = 0; it < nsteps; ++it) {
+        const int n = adj ? (p.n_first - it) : (p.n_first + it);
+        const float amp = amp_next;
+        // ---- sampling of the current field (owner slab writes) -------------------------------
+        if (p.dbg & 8) {
+        } else if (!slow_sparse) {
+            if (smp_off >= 0) {
+                const float val = fmaf(adj ? src_wt : smp_w, cur[smp_off], 0.f);
+                if (!adj) p.rec_out[((long long)n * p.nshot + s) * p.nrec + smp_e] = val;
+                else p.grad_f[((long long)n * p.nshot + s) * p.nsrc + smp_e] = val;
+            } else if (smp_off == -2) {
+                if (!adj) p.rec_out[((long long)n * p.nshot + s) * p.nrec + smp_e] = 0.f;
+                else p.grad_f[((long long)n * p.nshot + s) * p.nsrc + smp_e] = 0.f;
+            }
+        } else if (!adj) {
+            if (p.rec_out != nullptr)
+                for (int e = t; e < p.nrec; e += kClThreads) {
+                    const int cell = p.rec_cell[(long long)s * p.nrec + e];
+                    if (cell < 0) {
+                        if (w == 0) p.rec_out[((long long)n * p.nshot + s) * p.nrec + e] = 0.f;
+                        continue;
+                    }
+                    const int i0 = cell / p.n1, i1 = cell - i0 * p.n1;
+                    if (i0 >= r0 && i0 < r0 + R)
+                        p.rec_out[((long long)n * p.nshot + s) * p.nrec + e] =
+                            fmaf(p.rec_w[(long long)s * p.nrec + e], cur[(i0 - r0 + 2) * PL + 4 + i1], 0.f);
+                }
+        } else if (p.grad_f != nullptr) {
+            for (int e = t; e < p.nsrc; e += kClThreads) {
+                const int cell = p.src_cell[(long long)s * p.nsrc + e];
+                if (cell < 0) {
+                    if (w == 0) p.grad_f[((long long)n * p.nshot + s) * p.nsrc + e] = 0.f;
+                    continue;
+                }
+                const int i0 = cell / p.n1, i1 = cell - i0 * p.n1;
+                if (i0 >= r0 && i0 < r0 + R) {
+                    const float q = p.q0[i0] + p.q1[i1];
+                    const float wq = p.src_w[(long long)s * p.nsrc + e] * (1.0f + q * p.r[(long long)i0 * p.gp + i1]);
+                    p.grad_f[((long long)n * p.nshot + s) * p.nsrc + e] = fmaf(wq, cur[(i0 - r0 + 2) * PL + 4 + i1], 0.f);
+                }
+            }
+        }
+        // ---- stencil: new field overwrites prv in place (prv is only read at the own cell) --
+        float *Gn = (MODE == 1) ? p.G + (long long)(n - p.g_first) * p.g_step + plane : nullptr;
+        const unsigned epoch = (unsigned)(it + 1);
+        unsigned long long *xmine = xmine0 + (epoch & 1u) * 4 * p.gp;
+        const unsigned long long *xup = xup0 + (epoch & 1u) * 4 * p.gp;
+        const unsigned long long *xdn = xdn0 + (epoch & 1u) * 4 * p.gp;
+#pragma unroll
+        for (int i = 0; i < kClMaxNG; ++i) {
+            if (i < nown && !(p.dbg & 4)) {
+                float un[4], gk[4];
+                float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                float q0 = 0.f;
+                const bool damped = (dampmask >> i) & 1u;
+                if (damped) {
+                    q1 = *reinterpret_cast<const float4 *>(ldq1 + 4 * (jg[i] & 4095));
+                    q0 = ldq0[(jg[i] >> 12) - r0];
+                }
+                cl_update<MODE == 1>(cur + loff[i], prv + loff[i], PL, rr[i], q0, q1, damped, p.c0, p.c1,
+                                     p.n1 - 4 * (jg[i] & 4095), un, gk);
+                if (!adj && !slow_sparse && i == src_slot) {
+                    const float a = src_wt * amp;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+                        if (cc == src_comp) { un[cc] += a * comp(rr[i], cc); if (MODE == 1) gk[cc] += a; }
+                }
+                if (!adj && slow_sparse && p.nsrc > 0) {
+                    for (int e = 0; e < p.nsrc; ++e) {
+                        const int cell = p.src_cell[(long long)s * p.nsrc + e];
+                        if (cell < 0) continue;
+                        const int i0 = cell / p.n1, i1 = cell - i0 * p.n1;
+                        if ((long long)i0 * p.gp + (i1 & ~3) == goff(i)) {
+                            const float a = p.src_w[(long long)s * p.nsrc + e] *
+                                            p.f[((long long)n * p.nshot + s) * p.nsrc + e];
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc)
+                                if (cc == (i1 & 3)) { un[cc] += a * comp(rr[i], cc); if (MODE == 1) gk[cc] += a; }
+                        }
+                    }
+                }
+                *reinterpret_cast<float4 *>(prv + loff[i]) = make_float4(un[0], un[1], un[2], un[3]);
+                if (MODE == 1) Gbuf[i] = make_float4(gk[0], gk[1], gk[2], gk[3]);
+            }
+            if (early_pub && i == 0) {
+                // forward: every boundary row is complete after slot 0 -> publish now, so that the
+                // hand-off travels while the interior (slots 1..) is computed
+                __syncthreads();
+                for (int e = t; e < 4 * p.gp; e += kClThreads) {
+                    const int side = e / (2 * p.gp), rem = e - side * 2 * p.gp;
+                    const int row = rem / p.gp, col = rem - row * p.gp;
+                    if ((side == 0 && w == 0) || (side == 1 && w == p.NW - 1)) continue;
+                    const int lr = (side == 0) ? 2 + row : R + row;
+                    const unsigned bits = __float_as_uint(prv[lr * PL + 4 + col]);
+                    __hip_atomic_store(xmine + e, ((unsigned long long)epoch << 32) | bits, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __syncthreads();
+        if (adj) {
+            // ---- adjoint sources: receiver taps of this slab, z^k[cell] += (w g) (r inv) -------
+            if (!slow_sparse) {
+                if (inj_off >= 0) atomicAdd(&prv[inj_off], (smp_w * amp) * inj_scale);
+            } else {
+                const int cnt = p.slab_cnt[s * p.NW + w];
+                const int *lst = p.slab_list + ((long long)s * p.NW + w) * p.nrec;
+                for (int e = t; e < cnt; e += kClThreads) {
+                    const int id = lst[e];
+                    const int cell = p.rec_cell[(long long)s * p.nrec + id];
+                    const int i0 = cell / p.n1, i1 = cell - i0 * p.n1;
+                    const float rv = p.r[(long long)i0 * p.gp + i1];
+                    const float q = p.q0[i0] + p.q1[i1];
+                    const float inv = 1.0f / (1.0f + q * rv);
+                    const float a = p.rec_w[(long long)s * p.nrec + id] *
+                                    p.grad_rec[((long long)n * p.nshot + s) * p.nrec + id];
+                    atomicAdd(&prv[(i0 - r0 + 2) * PL + 4 + i1], a * (rv * inv));
+                }
+            }
+            __syncthreads();
+            // ---- imaging with the injected field: acc += z^k * G^{k-1} ----------------------
+#pragma unroll
+            for (int i = 0; i < kClMaxNG; ++i) {
+                if (i < nown) {
+                    const float4 z = *reinterpret_cast<const float4 *>(prv + loff[i]);
+                    acc[i].x = fmaf(z.x, Gbuf[i].x, acc[i].x); acc[i].y = fmaf(z.y, Gbuf[i].y, acc[i].y);
+                    acc[i].z = fmaf(z.z, Gbuf[i].z, acc[i].z); acc[i].w = fmaf(z.w, Gbuf[i].w, acc[i].w);
+                }
+            }
+        }
+        if (do_x && !early_pub) {
+            for (int e = t; e < 4 * p.gp; e += kClThreads) {
+                const int side = e / (2 * p.gp), rem = e - side * 2 * p.gp;
+                const int row = rem / p.gp, col = rem - row * p.gp;
+                if ((side == 0 && w == 0) || (side == 1 && w == p.NW - 1)) continue;
+                const int lr = (side == 0) ? 2 + row : R + row;
+                const unsigned bits = __float_as_uint(prv[lr * PL + 4 + col]);
+                __hip_atomic_store(xmine + e, ((unsigned long long)epoch << 32) | bits, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- receive the neighbours' boundary rows of the NEW field into the halo rows -------------
+        if (do_x) {
+            for (int e = t; e < 4 * p.gp; e += kClThreads) {
+                const int side = e / (2 * p.gp), rem = e - side * 2 * p.gp;
+                const int row = rem / p.gp, col = rem - row * p.gp;
+                if ((side == 0 && w == 0) || (side == 1 && w == p.NW - 1)) continue;
+                // our top halo = the upper neighbour's "down" rows, our bottom halo = the lower one's "up" rows
+                const unsigned long long *src = (side == 0) ? xup + (2 * p.gp + row * p.gp + col)
+                                                            : xdn + (row * p.gp + col);
+                unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while ((unsigned)(v >> 32) != epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kClMaxSpin ||
+                        ((spins & 255u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        failed = true;
+                        break;
+                    }
+                    v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const int lr = (side == 0) ? row : R + 2 + row;
+                prv[lr * PL + 4 + col] = __uint_as_float((unsigned)v);
+            }
+        }
+        // global traffic that nobody waits for goes AFTER the hand-off (vector memory operations
+        // retire in order: a poll issued behind these would wait for them)
+        if (MODE == 1 && !(p.dbg & 2)) {
+#pragma unroll
+            for (int i = 0; i < kClMaxNG; ++i)
+                if (i < nown) *reinterpret_cast<float4 *>(Gn + goff(i)) = Gbuf[i];
+        }
+        prefetch(it + 1);
+        if (__syncthreads_or(failed ? 1 : 0)) {
+            if (t == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            failed = true;
+            break;
+        }
+        float *tmp = cur; cur = prv; prv = tmp;
+    }
+
+    // ---- write the state (own rows of both levels) and the accumulators back --------------------
+    const int parE = adj ? ((p.nt - 1 - (p.n_last - 1)) & 1) : (p.n_last & 1);
+    float *ocur = (parE ? p.ub : p.ua) + (long long)s * p.shot_stride;
+    float *oprev = (parE ? p.ua : p.ub) + (long long)s * p.shot_stride;
+#pragma unroll
+    for (int i = 0; i < kClMaxNG; ++i) {
+        if (i < nown) {
+            const long long o = (long long)((jg[i] >> 12) + 2) * p.pitch + 4 + 4 * (jg[i] & 4095);
+            *reinterpret_cast<float4 *>(ocur + o) = *reinterpret_cast<const float4 *>(cur + loff[i]);
+            *reinterpret_cast<float4 *>(oprev + o) = *reinterpret_cast<const float4 *>(prv + loff[i]);
+            if (adj) *reinterpret_cast<float4 *>(p.acc + plane + goff(i)) = acc[i];
+        }
+    }
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -303,6 +820,9 @@ struct mifwi_acoustic_plan {
     int device;
     int ng, gp, pitch, lx, rz, gs, ngroups;
     long long shot_stride, field_elems, coef_elems;
+    // cluster path (LDS-resident time loop), 0 when the shot does not fit
+    int cluster, NW, PL, cl_shots, cl_lds;
+    long long xbuf_elems, list_elems;      // in floats
 };
 
 namespace {
@@ -355,6 +875,74 @@ AcParams base_params(const mifwi_acoustic_plan *pl, const float *r, const float 
     return p;
 }
 
+// ---- cluster path helpers --------------------------------------------------------------------------
+void cluster_setup(mifwi_acoustic_plan *pl)
+{
+    pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0;
+    pl->xbuf_elems = 0; pl->list_elems = 0;
+    if (env_int("MIFWI_AC_CLUSTER", 1) == 0 || pl->d.ntap != 1) return;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device) != hipSuccess) return;
+    const int forced = env_int("MIFWI_AC_NW", 0);
+    for (int nw = 1; nw <= 32; ++nw) {
+        if (forced > 0 && nw != forced) continue;
+        const int rows = mifwi::ceil_div(pl->d.n0, nw);
+        if (pl->d.n0 / nw < 4) break;
+        const long long lds = (2LL * (rows + 4) * pl->PL + pl->gp + rows + 8) * sizeof(float);
+        if (lds > 150 * 1024) continue;
+        if ((long long)rows * pl->ng > (long long)kClMaxNG * kClThreads || pl->ng > 4095) continue;
+        const int per_launch = 8 * (ncu / (8 * nw));       // shots per launch (multiple of 8)
+        if (per_launch < 8) break;
+        pl->cluster = 1; pl->NW = nw; pl->cl_shots = per_launch; pl->cl_lds = (int)lds;
+        break;
+    }
+    if (!pl->cluster) return;
+    pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * pl->NW * 8 * pl->gp + 64, 64);   // granules + err word
+    pl->list_elems = mifwi::round_up64((long long)pl->d.nshot * pl->NW * (1 + (long long)pl->d.nrec), 64);
+    for (const void *fn : {(const void *)ac_cluster<0>, (const void *)ac_cluster<1>, (const void *)ac_cluster<2>})
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pl->cl_lds) != hipSuccess) {
+            pl->cluster = 0;
+            return;
+        }
+}
+
+ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const float *q0, const float *q1,
+                        float *ua, float *ub, float *xbuf)
+{
+    ClParams c;
+    memset(&c, 0, sizeof(c));
+    c.n0 = pl->d.n0; c.n1 = pl->d.n1; c.ng = pl->ng; c.gp = pl->gp; c.pitch = pl->pitch;
+    c.shot_stride = pl->shot_stride; c.nshot = pl->d.nshot; c.NW = pl->NW; c.PL = pl->PL;
+    c.nt = pl->d.nt; c.c0 = pl->d.c0; c.c1 = pl->d.c1; c.r = r; c.q0 = q0; c.q1 = q1;
+    c.ua = ua; c.ub = ub;
+    c.nsrc = pl->d.nsrc; c.ntap = 1; c.nrec = pl->d.nrec;
+    c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
+    c.err = reinterpret_cast<int *>(xbuf + 2LL * pl->d.nshot * pl->NW * 8 * pl->gp);
+    c.dbg = env_int("MIFWI_AC_CL_DBG", 0);
+    return c;
+}
+
+template <int MODE>
+int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStream_t st)
+{
+    MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
+    for (int s0 = 0; s0 < pl->d.nshot; s0 += pl->cl_shots) {
+        c.shot0 = s0;
+        c.shot1 = std::min(pl->d.nshot, s0 + pl->cl_shots);
+        const int nsl8 = mifwi::ceil_div(c.shot1 - s0, 8);
+        hipLaunchKernelGGL((ac_cluster<MODE>), dim3(8 * pl->NW * nsl8), dim3(kClThreads), pl->cl_lds, st, c);
+    }
+    MIFWI_HIP_TRY(hipGetLastError());
+    int err = 0;
+    MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
+    MIFWI_HIP_TRY(hipStreamSynchronize(st));
+    if (err != 0)
+        return mifwi::fail(MIFWI_EHIP, "cluster kernel: a halo hand-off timed out (not all %d workgroups "
+                           "were resident?); set MIFWI_AC_CLUSTER=0 to use one launch per step",
+                           8 * pl->NW * mifwi::ceil_div(std::min(pl->d.nshot, pl->cl_shots), 8));
+    return MIFWI_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -404,6 +992,11 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
     if (gs > d->nshot) gs = d->nshot;
     pl->gs = gs;
     pl->ngroups = mifwi::ceil_div(d->nshot, gs);
+    cluster_setup(pl);
+    if (pl->cluster) {                 // the cluster adjoint keeps one accumulator per shot in registers
+        pl->gs = 1;
+        pl->ngroups = d->nshot;
+    }
     *plan = pl;
     return MIFWI_OK;
 }
@@ -424,8 +1017,9 @@ int mifwi_acoustic_plan_layout(const mifwi_acoustic_plan *pl, mifwi_acoustic_lay
     out->field_elems = pl->field_elems;
     out->coef_elems = pl->coef_elems;
     const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
-    out->work_forward_elems = 2 * pl->field_elems + bbox;
-    out->work_backward_elems = 2 * pl->field_elems + pl->ngroups * pl->coef_elems + bbox;
+    const long long cl = pl->cluster ? pl->xbuf_elems + pl->list_elems : 0;
+    out->work_forward_elems = 2 * pl->field_elems + bbox + cl;
+    out->work_backward_elems = 2 * pl->field_elems + pl->ngroups * pl->coef_elems + bbox + cl;
     return MIFWI_OK;
 }
 
@@ -460,6 +1054,15 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *pl, const float *r, const float 
     p.nsmp = rec_out ? d.nrec : 0; p.ntap_smp = d.ntap; p.smp_mode = 0;
     p.smp_cell = rec_cell; p.smp_w = rec_w;
     const long long snap_step = (long long)d.nshot * pl->coef_elems;
+    if (pl->cluster && n_end > n_begin) {
+        float *xbuf = work + 2 * pl->field_elems + mifwi::round_up64(4LL * d.nshot, 64);
+        ClParams c = cluster_params(pl, r, q0, q1, ua, ub, xbuf);
+        c.n_first = n_begin; c.n_last = n_end;
+        c.src_cell = src_cell; c.src_w = src_w; c.f = f;
+        c.rec_cell = rec_cell; c.rec_w = rec_w; c.rec_out = (rec_out && d.nrec > 0) ? rec_out : nullptr;
+        c.G = snap; c.g_first = n_begin; c.g_step = snap_step;
+        return snap ? cluster_run<1>(pl, c, xbuf, st) : cluster_run<0>(pl, c, xbuf, st);
+    }
     for (int n = n_begin; n < n_end; ++n) {
         p.cur = (n & 1) ? ub : ua;
         p.prev = (n & 1) ? ua : ub;
@@ -516,6 +1119,22 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
     const long long snap_step = (long long)d.nshot * pl->coef_elems;
     // step k computes z^k from cur = z^{k+1}, prev = z^{k+2}; samples grad_f[k] from z^{k+1}.
     // Buffer parity is absolute in k so that a range can be resumed by a later call.
+    if (pl->cluster && k_hi >= k_lo) {
+        float *xbuf = reinterpret_cast<float *>(bbox) + mifwi::round_up64(4LL * d.nshot, 64);
+        int *lists = reinterpret_cast<int *>(xbuf + pl->xbuf_elems);
+        hipLaunchKernelGGL(cl_build_slab_lists, dim3(d.nshot), dim3(256), 0, st, rec_cell, d.nrec, d.n0, d.n1,
+                           pl->NW, lists, lists + (long long)d.nshot * pl->NW);
+        ClParams c = cluster_params(pl, r, q0, q1, za, zb, xbuf);
+        c.n_first = k_hi; c.n_last = k_lo;
+        c.src_cell = src_cell; c.src_w = src_w;
+        c.rec_cell = rec_cell; c.rec_w = rec_w; c.grad_rec = grad_rec;
+        c.grad_f = want_f ? grad_f : nullptr;
+        c.G = const_cast<float *>(snap); c.g_first = snap_first; c.g_step = snap_step;
+        c.acc = acc;
+        c.slab_cnt = lists; c.slab_list = lists + (long long)d.nshot * pl->NW;
+        rc = cluster_run<2>(pl, c, xbuf, st);
+        if (rc) return rc;
+    } else
     for (int k = k_hi; k >= k_lo; --k) {
         const int par = (d.nt - 1 - k) & 1;
         p.cur = par ? zb : za;

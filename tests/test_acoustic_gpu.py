@@ -166,3 +166,36 @@ def test_deepwave_shim_matches_oracle(oracle32):
     r_t.backward(torch.tensor(gr_o))
     assert abs(float(loss) - float(loss_o)) <= 1e-5 * abs(float(loss_o))
     assert rel_l2(vp.grad.cpu().numpy(), vpt.grad.numpy()) <= 1e-4
+
+
+@pytest.mark.parametrize("nw", [2, 3, 5])
+def test_cluster_path_with_halo_handoff(oracle32, monkeypatch, nw):
+    """Force the LDS-resident cluster kernels to cut a shot into several row slabs so that the
+    granule hand-off between workgroups is exercised; results must not change (bitwise traces)."""
+    monkeypatch.setenv("MIFWI_AC_NW", str(nw))
+    case = acoustic_case(seed=17, n0=61, n1=83, nb=9, nt=140, ns=3, nrec=15)
+    o = oracle32
+    rec_o, G_o = o.acoustic_forward(case["r"], case["q0"], case["q1"], case["f"], case["sc"],
+                                    case["sw"], case["rc"], case["rw"], save=True)
+    r, f, rec = _run_hip(case)
+    assert np.abs(rec.detach().cpu().numpy() - rec_o).max() == 0.0
+    g = np.sign(rec_o).astype(np.float32)
+    rec.backward(torch.tensor(g, device=rec.device))
+    gr_o, gf_o = o.acoustic_backward(case["r"], case["q0"], case["q1"], case["sc"], case["sw"],
+                                     case["rc"], case["rw"], g, G_o)
+    assert rel_l2(r.grad.cpu().numpy(), gr_o) <= TOL_GRAD
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= TOL_GRAD
+
+
+def test_cluster_and_per_step_paths_agree(monkeypatch):
+    case = acoustic_case(seed=19, n0=70, n1=120, nb=10, nt=90, ns=2, nrec=21)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MIFWI_AC_CLUSTER", flag)
+        monkeypatch.setenv("MIFWI_AC_NW", "4" if flag == "1" else "0")
+        r, f, rec = _run_hip(case)
+        rec.backward(torch.sign(rec.detach()))
+        outs.append((rec.detach().clone(), r.grad.clone(), f.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert rel_l2(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy()) <= TOL_GRAD
+    assert rel_l2(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()) <= TOL_GRAD
