@@ -438,8 +438,10 @@ __device__ __forceinline__ void cl_update(const float *c, const float *pp, int P
             v = pk_fma(rv, lap, pk_fma(mone, upv, two * uc));
             g = lap;
         }
-        un[2 * h] = (2 * h >= ncol_valid) ? 0.f : v.x;
-        un[2 * h + 1] = (2 * h + 1 >= ncol_valid) ? 0.f : v.y;
+        // columns >= n1 hold r = 0 and zero fields, so v is exactly 0 there without a mask
+        (void)ncol_valid;
+        un[2 * h] = v.x;
+        un[2 * h + 1] = v.y;
         if (WANT_G) { gk[2 * h] = g.x; gk[2 * h + 1] = g.y; }
     }
 }
@@ -585,6 +587,27 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     __syncthreads();
     float *cur = bufA, *prv = bufB;
 
+    // hand-off assignments of this thread (constant over the run): granule e = t + k*kClThreads
+    constexpr int kGr = 3;
+    int rcv_lo[kGr];                     // LDS offset of the halo cell (<0: none); bit 30 of the
+    unsigned upmask = 0;                 // mask: granule comes from the upper neighbour
+#pragma unroll
+    for (int kk = 0; kk < kGr; ++kk) {
+        const int e = t + kk * kClThreads;
+        rcv_lo[kk] = -1;
+        if (e < 4 * p.gp) {
+            const int side = e / (2 * p.gp), rem = e - side * 2 * p.gp;
+            const int row = rem / p.gp, col = rem - row * p.gp;
+            if (!((side == 0 && w == 0) || (side == 1 && w == p.NW - 1))) {
+                rcv_lo[kk] = ((side == 0) ? row : R + 2 + row) * PL + 4 + col;
+                if (side == 0) upmask |= 1u << kk;
+            }
+        }
+    }
+    // published cell = the own boundary cell two rows inside the halo cell; the neighbour's slot holds
+    // our halo at the mirrored side: index e +- 2*gp
+    auto pub_off = [&](int kk) { return rcv_lo[kk] + (((upmask >> kk) & 1u) ? 2 * PL : -2 * PL); };
+    auto src_idx = [&](int kk) { return t + kk * kClThreads + (((upmask >> kk) & 1u) ? 2 * p.gp : -2 * p.gp); };
     const long long xslab = 8LL * p.gp;                                   // 2 slots x 4 rows x gp
     unsigned long long *xmine0 = p.xbuf + ((long long)s * p.NW + w) * xslab;
     const unsigned long long *xup0 = xmine0 - xslab;                      // valid if w > 0
@@ -700,19 +723,17 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 *reinterpret_cast<float4 *>(prv + loff[i]) = make_float4(un[0], un[1], un[2], un[3]);
                 if (MODE == 1) Gbuf[i] = make_float4(gk[0], gk[1], gk[2], gk[3]);
             }
+            __builtin_amdgcn_sched_barrier(0);   // one group at a time: keeps the register peak below 128
             if (early_pub && i == 0) {
                 // forward: every boundary row is complete after slot 0 -> publish now, so that the
                 // hand-off travels while the interior (slots 1..) is computed
                 __syncthreads();
-                for (int e = t; e < 4 * p.gp; e += kClThreads) {
-                    const int side = e / (2 * p.gp), rem = e - side * 2 * p.gp;
-                    const int row = rem / p.gp, col = rem - row * p.gp;
-                    if ((side == 0 && w == 0) || (side == 1 && w == p.NW - 1)) continue;
-                    const int lr = (side == 0) ? 2 + row : R + row;
-                    const unsigned bits = __float_as_uint(prv[lr * PL + 4 + col]);
-                    __hip_atomic_store(xmine + e, ((unsigned long long)epoch << 32) | bits, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                }
+#pragma unroll
+                for (int kk = 0; kk < kGr; ++kk)
+                    if (rcv_lo[kk] >= 0)
+                        __hip_atomic_store(xmine + t + kk * kClThreads,
+                                           ((unsigned long long)epoch << 32) | __float_as_uint(prv[pub_off(kk)]),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
@@ -747,25 +768,20 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             }
         }
         if (do_x && !early_pub) {
-            for (int e = t; e < 4 * p.gp; e += kClThreads) {
-                const int side = e / (2 * p.gp), rem = e - side * 2 * p.gp;
-                const int row = rem / p.gp, col = rem - row * p.gp;
-                if ((side == 0 && w == 0) || (side == 1 && w == p.NW - 1)) continue;
-                const int lr = (side == 0) ? 2 + row : R + row;
-                const unsigned bits = __float_as_uint(prv[lr * PL + 4 + col]);
-                __hip_atomic_store(xmine + e, ((unsigned long long)epoch << 32) | bits, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
+#pragma unroll
+            for (int kk = 0; kk < kGr; ++kk)
+                if (rcv_lo[kk] >= 0)
+                    __hip_atomic_store(xmine + t + kk * kClThreads,
+                                       ((unsigned long long)epoch << 32) | __float_as_uint(prv[pub_off(kk)]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- receive the neighbours' boundary rows of the NEW field into the halo rows -------------
         if (do_x) {
-            for (int e = t; e < 4 * p.gp; e += kClThreads) {
-                const int side = e / (2 * p.gp), rem = e - side * 2 * p.gp;
-                const int row = rem / p.gp, col = rem - row * p.gp;
-                if ((side == 0 && w == 0) || (side == 1 && w == p.NW - 1)) continue;
+#pragma unroll
+            for (int kk = 0; kk < kGr; ++kk) {
+                if (rcv_lo[kk] < 0) continue;
                 // our top halo = the upper neighbour's "down" rows, our bottom halo = the lower one's "up" rows
-                const unsigned long long *src = (side == 0) ? xup + (2 * p.gp + row * p.gp + col)
-                                                            : xdn + (row * p.gp + col);
+                const unsigned long long *src = (((upmask >> kk) & 1u) ? xup : xdn) + src_idx(kk);
                 unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned spins = 0;
                 while ((unsigned)(v >> 32) != epoch) {
@@ -777,8 +793,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                     }
                     v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                const int lr = (side == 0) ? row : R + 2 + row;
-                prv[lr * PL + 4 + col] = __uint_as_float((unsigned)v);
+                prv[rcv_lo[kk]] = __uint_as_float((unsigned)v);
             }
         }
         // global traffic that nobody waits for goes AFTER the hand-off (vector memory operations
@@ -789,10 +804,15 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 if (i < nown) *reinterpret_cast<float4 *>(Gn + goff(i)) = Gbuf[i];
         }
         prefetch(it + 1);
-        if (__syncthreads_or(failed ? 1 : 0)) {
-            if (t == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            failed = true;
-            break;
+        // a timed-out thread carries garbage forward until the next collective check (fatal anyway)
+        if ((it & 31) == 31 || it == nsteps - 1) {
+            if (__syncthreads_or(failed ? 1 : 0)) {
+                if (t == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                failed = true;
+                break;
+            }
+        } else {
+            __syncthreads();
         }
         float *tmp = cur; cur = prv; prv = tmp;
     }
@@ -890,7 +910,8 @@ void cluster_setup(mifwi_acoustic_plan *pl)
         if (pl->d.n0 / nw < 4) break;
         const long long lds = (2LL * (rows + 4) * pl->PL + pl->gp + rows + 8) * sizeof(float);
         if (lds > 150 * 1024) continue;
-        if ((long long)rows * pl->ng > (long long)kClMaxNG * kClThreads || pl->ng > 4095) continue;
+        if ((long long)rows * pl->ng > (long long)kClMaxNG * kClThreads || pl->ng > 4095 ||
+            4 * pl->gp > 3 * kClThreads) continue;
         const int per_launch = 8 * (ncu / (8 * nw));       // shots per launch (multiple of 8)
         if (per_launch < 8) break;
         pl->cluster = 1; pl->NW = nw; pl->cl_shots = per_launch; pl->cl_lds = (int)lds;
