@@ -777,24 +777,36 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         }
         // ---- receive the neighbours' boundary rows of the NEW field into the halo rows -------------
         if (do_x) {
+            // sweep: each pass re-reads ALL of this thread's granules back to back (one memory round
+            // trip per pass, not one per granule) until every tag carries the epoch
+            unsigned long long v[kGr];
+            const unsigned long long *src[kGr];
 #pragma unroll
             for (int kk = 0; kk < kGr; ++kk) {
-                if (rcv_lo[kk] < 0) continue;
                 // our top halo = the upper neighbour's "down" rows, our bottom halo = the lower one's "up" rows
-                const unsigned long long *src = (((upmask >> kk) & 1u) ? xup : xdn) + src_idx(kk);
-                unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned spins = 0;
-                while ((unsigned)(v >> 32) != epoch) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > kClMaxSpin ||
-                        ((spins & 255u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                        failed = true;
-                        break;
-                    }
-                    v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                prv[rcv_lo[kk]] = __uint_as_float((unsigned)v);
+                src[kk] = (((upmask >> kk) & 1u) ? xup : xdn) + src_idx(kk);
+                v[kk] = 0;
             }
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int kk = 0; kk < kGr; ++kk)
+                    if (rcv_lo[kk] >= 0)
+                        v[kk] = __hip_atomic_load(src[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int kk = 0; kk < kGr; ++kk)
+                    if (rcv_lo[kk] >= 0) ok = ok && (unsigned)(v[kk] >> 32) == epoch;
+                if (ok) break;
+                if (spins > kClMaxSpin ||
+                    ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    failed = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int kk = 0; kk < kGr; ++kk)
+                if (rcv_lo[kk] >= 0) prv[rcv_lo[kk]] = __uint_as_float((unsigned)v[kk]);
         }
         // global traffic that nobody waits for goes AFTER the hand-off (vector memory operations
         // retire in order: a poll issued behind these would wait for them)

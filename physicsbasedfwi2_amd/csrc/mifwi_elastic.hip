@@ -735,6 +735,8 @@ __global__ void el_finalize(const float *acc, int ngroups, long long n5, float *
     grad[idx] = a;
 }
 
+#include "mifwi_elastic_cluster.h"
+
 int env_int(const char *name, int dflt)
 {
     const char *v = getenv(name);
@@ -751,6 +753,9 @@ struct mifwi_elastic_plan {
     int W, wl, xr0, wx;
     long long field_stride, shot_stride, fields_elems, psix_elems, psiz_elems, coef_elems;
     long long psi_elems;  // psix+psiz rounded up to 64
+    // cluster path (LDS-resident time loop); 0 when a shot does not fit
+    int cluster, NW, PL, cl_shots, cl_lds, cl_ng;
+    long long xbuf_elems;
 };
 
 namespace {
@@ -816,6 +821,61 @@ void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, hipStream_t st)
     }
 }
 
+void el_cluster_setup(mifwi_elastic_plan *pl)
+{
+    pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0; pl->xbuf_elems = 0;
+    if (env_int("MIFWI_EL_CLUSTER", 1) == 0 || pl->d.ntap != 1) return;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device) != hipSuccess) return;
+    const int forced = env_int("MIFWI_EL_NW", 0);
+    for (int nw = 1; nw <= 32; ++nw) {
+        if (forced > 0 && nw != forced) continue;
+        const int rows = mifwi::ceil_div(pl->d.nz, nw);
+        if (pl->d.nz / nw < 4) break;
+        const long long lds = (5LL * (rows + 4) * pl->PL + 6LL * pl->gp + 6LL * rows + 8) * sizeof(float);
+        if (lds > 150 * 1024) continue;
+        if ((long long)rows * pl->ng > 2 * kEcThreads || 8 * pl->gp > 5 * kEcThreads) continue;
+        const int per_launch = 8 * (ncu / (8 * nw));
+        if (per_launch < 8) break;
+        pl->cluster = 1; pl->NW = nw; pl->cl_shots = per_launch; pl->cl_lds = (int)lds;
+        pl->cl_ng = mifwi::ceil_div(rows * pl->ng, kEcThreads);
+        break;
+    }
+    if (!pl->cluster) return;
+    pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * pl->NW * 4 * 8 * pl->gp + 64, 64);
+    for (const void *fn : {(const void *)el_cluster_fwd<false, 1>, (const void *)el_cluster_fwd<true, 1>,
+                           (const void *)el_cluster_fwd<false, 2>, (const void *)el_cluster_fwd<true, 2>})
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pl->cl_lds) != hipSuccess) {
+            pl->cluster = 0;
+            return;
+        }
+}
+
+template <bool SAVE>
+int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStream_t st)
+{
+    MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
+    c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
+    c.err = reinterpret_cast<int *>(xbuf + 2LL * pl->d.nshot * pl->NW * 4 * 8 * pl->gp);
+    for (int s0 = 0; s0 < pl->d.nshot; s0 += pl->cl_shots) {
+        c.shot0 = s0;
+        c.shot1 = std::min(pl->d.nshot, s0 + pl->cl_shots);
+        const int nsl8 = mifwi::ceil_div(c.shot1 - s0, 8);
+        if (pl->cl_ng == 1)
+            hipLaunchKernelGGL((el_cluster_fwd<SAVE, 1>), dim3(8 * pl->NW * nsl8), dim3(kEcThreads), pl->cl_lds, st, c);
+        else
+            hipLaunchKernelGGL((el_cluster_fwd<SAVE, 2>), dim3(8 * pl->NW * nsl8), dim3(kEcThreads), pl->cl_lds, st, c);
+    }
+    MIFWI_HIP_TRY(hipGetLastError());
+    int err = 0;
+    MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
+    MIFWI_HIP_TRY(hipStreamSynchronize(st));
+    if (err != 0)
+        return mifwi::fail(MIFWI_EHIP, "elastic cluster kernel: a halo hand-off timed out; set "
+                           "MIFWI_EL_CLUSTER=0 to use one launch per half step");
+    return MIFWI_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -873,6 +933,7 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     pl->gs = gs;
     pl->ngroups = mifwi::ceil_div(d->nshot, gs);
     pl->psi_elems = mifwi::round_up64(pl->psix_elems + pl->psiz_elems, 64);
+    el_cluster_setup(pl);
     *plan = pl;
     return MIFWI_OK;
 }
@@ -892,7 +953,7 @@ int mifwi_elastic_plan_layout(const mifwi_elastic_plan *pl, mifwi_elastic_layout
     const long long psi = pl->psi_elems;
     const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
     out->state_elems = pl->fields_elems + psi;
-    out->work_forward_elems = out->state_elems + bbox;
+    out->work_forward_elems = out->state_elems + bbox + (pl->cluster ? pl->xbuf_elems : 0);
     out->work_backward_elems = pl->fields_elems + 2 * psi + 5LL * pl->ngroups * pl->coef_elems + bbox;
     return MIFWI_OK;
 }
@@ -928,6 +989,25 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
     ElParams p = el_base(pl, mat, pz, px);
     const long long snap_step = 5LL * d.nshot * pl->coef_elems;
     const bool want_rec = rec_vx != nullptr && d.nrec > 0;
+    if (pl->cluster && n_end > n_begin) {
+        float *xbuf = work + pl->fields_elems + psi + mifwi::round_up64(4LL * d.nshot, 64);
+        EcParams c;
+        memset(&c, 0, sizeof(c));
+        c.nz = d.nz; c.nx = d.nx; c.ng = pl->ng; c.gp = pl->gp; c.pitch = pl->pitch;
+        c.field_stride = (unsigned)pl->field_stride; c.shot_stride = pl->shot_stride;
+        c.nshot = d.nshot; c.NW = pl->NW; c.PL = pl->PL;
+        c.n_first = n_begin; c.n_last = n_end;
+        c.W = pl->W; c.wl = pl->wl; c.xr0 = pl->xr0; c.wx = pl->wx; c.fsurf = d.free_surface;
+        c.psix_shot = 4LL * d.nz * pl->wx; c.psiz_shot = 4LL * 2 * pl->W * pl->gp;
+        c.mat = mat; c.pz = pz; c.px = px;
+        c.fields = fbuf[0]; c.psix = pbuf[0]; c.psiz = pbuf[0] + pl->psix_elems;
+        c.S = snap; c.s_first = n_begin; c.s_step = snap_step;
+        c.nsrc = d.nsrc; c.nrec = d.nrec; c.src_cell = src_cell; c.src_w = src_w; c.f = f;
+        c.rec_cell = rec_cell; c.rec_w = rec_w;
+        c.rec_vx = want_rec ? rec_vx : nullptr; c.rec_vz = want_rec ? rec_vz : nullptr;
+        c.dbg = env_int("MIFWI_EL_CL_DBG", 0);
+        return snap ? el_cluster_run<true>(pl, c, xbuf, st) : el_cluster_run<false>(pl, c, xbuf, st);
+    }
     {
         p.fields = fbuf[0]; p.psix = pbuf[0]; p.psiz = pbuf[0] + pl->psix_elems;
         ElParams ps = p;

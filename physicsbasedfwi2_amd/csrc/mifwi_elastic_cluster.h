@@ -1,0 +1,530 @@
+// CLUSTER kernels of the elastic propagator: the whole time loop in ONE launch, the five wavefields
+// of a row slab resident in LDS, memory variables / materials of a thread's cells in registers.
+// Included by mifwi_elastic.hip inside its anonymous namespace (uses its helpers and enums).
+//
+// Why (profiles/): on the grids the reference actually runs (100x300, 150x294,
+// 190x324 ...) a time step launched as kernels is bound by launch boundaries and memory round trips
+// (V 12 us + S 14 us for 0.96 M cells), not by HBM.  Here a shot is cut into NW row slabs, one
+// 1024-thread workgroup (one CU, ~105 KB of LDS) per slab, NW x shots <= CU count so that every
+// workgroup is resident; per step the only global traffic is the snapshot stream (20 B/cell) and
+// the two halo hand-offs (velocities after V, stresses after S), done as self-validating 8-byte
+// {epoch,value} granules with agent-scope stores/loads (cdna_hip_programming.md, G16 form R2):
+// no flags, no fences, no grid barrier, every spin bounded.  The hand-off latency is hidden behind
+// the rows that do not need the halo: interior rows are updated before the poll, boundary rows after.
+// Arithmetic per cell = el_step_v / el_step_s (bitwise identical seismograms).
+#pragma once
+
+constexpr int kEcThreads = 512;       // 8 waves/CU: a 256-VGPR budget keeps a group's materials, memory
+                                      // variables and pending snapshot terms in registers without spilling
+constexpr unsigned kEcMaxSpin = 400000;
+
+struct EcParams {
+    int nz, nx, ng, gp, pitch;
+    unsigned field_stride;
+    long long shot_stride;
+    int nshot, NW, PL, shot0, shot1;
+    int n_first, n_last;                 // steps n_first .. n_last-1
+    int W, wl, xr0, wx, fsurf;
+    long long psix_shot, psiz_shot;
+    const float *mat, *pz, *px;
+    float *fields, *psix, *psiz;         // global state (layout of the per-step kernels)
+    float *S;                            // snapshots of step n at S + (n - s_first) * s_step (or null)
+    int s_first;
+    long long s_step;
+    int nsrc, nrec;
+    const int *src_cell;
+    const float *src_w, *f;              // f [nt][nshot][nsrc]
+    const int *rec_cell;
+    const float *rec_w;
+    float *rec_vx, *rec_vz;              // [nt][nshot][nrec] or null
+    unsigned long long *xbuf;            // [nshot][NW][2 kinds][2 parities][8*gp] granules
+    int *err;
+    int dbg;
+};
+
+__device__ __forceinline__ void ec_slab_rows(int nz, int NW, int w, int &r0, int &rows)
+{
+    const int base = nz / NW, rem = nz - base * NW;
+    rows = base + (w < rem ? 1 : 0);
+    r0 = w * base + (w < rem ? w : rem);
+}
+
+// granule index inside one exchange slot: [field 0..1][side 0=up,1=down][row 0..1][k 0..3][group]
+// (cell 4*group + k): the lanes of a publishing wave hold consecutive groups, so each of their store
+// instructions writes whole lines (8-byte stores 32 bytes apart are several times slower to land)
+__device__ __forceinline__ int ec_gran(int gp, int ng, int fld, int side, int row, int group, int k)
+{
+    return ((fld * 2 + side) * 2 + row) * gp + k * ng + group;
+}
+
+// Uniform value the compiler must treat as unknown at this point: stops it from hoisting every
+// `base + k * pitch` address of the loop body into a register of its own (they cost one add each,
+// but ~50 live registers when hoisted, which is what made this kernel spill).
+__device__ __forceinline__ int ec_opaque(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// per-thread state of one owned group of 4 cells (registers for the whole run)
+struct EcGroup {
+    bool own, inner;
+    int lrw, g, j, lo, xs_off, zs;
+    float4 mL, mM, mMu, mBx, mBz;                 // materials
+    float4 s1, s2, s3, s4, s5, s6, s7, s8;        // C-PML memory variables
+    int src;                                      // (source index << 2) | cell of the group, or -1
+    float src_wt, amp;                            // amp: this step's source term, fetched one step ahead
+};
+
+struct EcCtx {
+    float *Lf[5];
+    const float *lpx, *lpz;
+    int PL, R, gp, fsurf;
+};
+
+// V update (reads stresses from LDS, writes the group's velocities in place)
+__device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const int lo, const int gq, float4 &S4, float4 &S5, float4 &o0,
+                                            float4 &o1)
+{
+    const int PL = c.PL;
+    const float *sxx = c.Lf[F_SXX] + lo, *szz = c.Lf[F_SZZ] + lo, *sxz = c.Lf[F_SXZ] + lo;
+    const float4 cxx = ld4(sxx);
+    const float2 Lxx = ld2(sxx - 2), Rxx = ld2(sxx + 4);
+    const float4 a2 = ld4(sxz);
+    const float2 Lxz = ld2(sxz - 2), Rxz = ld2(sxz + 4);
+    float4 a0 = ld4(sxz - 2 * PL), a1 = ld4(sxz - PL);
+    const float4 a3 = ld4(sxz + PL);
+    float4 b0 = ld4(szz - PL);
+    const float4 b1 = ld4(szz), b2 = ld4(szz + PL), b3 = ld4(szz + 2 * PL);
+    if (c.fsurf && G.j < 2) {
+        if (G.j == 0) {
+            a1 = make_float4(-a2.x, -a2.y, -a2.z, -a2.w);
+            a0 = make_float4(-a3.x, -a3.y, -a3.z, -a3.w);
+            b0 = make_float4(-b2.x, -b2.y, -b2.z, -b2.w);
+        } else {
+            a0 = make_float4(-a1.x, -a1.y, -a1.z, -a1.w);
+        }
+    }
+    const float xx[8] = {Lxx.x, Lxx.y, cxx.x, cxx.y, cxx.z, cxx.w, Rxx.x, Rxx.y};
+    const float xz[8] = {Lxz.x, Lxz.y, a2.x, a2.y, a2.z, a2.w, Rxz.x, Rxz.y};
+    float d1[4], d2[4], d3[4], d4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        d1[k] = dfw(xx[k + 1], xx[k + 2], xx[k + 3], xx[k + 4]);
+        d2[k] = dbw(comp(a0, k), comp(a1, k), comp(a2, k), comp(a3, k));
+        d3[k] = dbw(xz[k], xz[k + 1], xz[k + 2], xz[k + 3]);
+        d4[k] = dfw(comp(b0, k), comp(b1, k), comp(b2, k), comp(b3, k));
+    }
+    if (G.xs_off >= 0) {
+        const float *q = c.lpx + 4 * gq;
+        const float4 pa = ld4(q + PA * c.gp), pb = ld4(q + PB * c.gp), pk = ld4(q + PK * c.gp);
+        const float4 pah = ld4(q + PAH * c.gp), pbh = ld4(q + PBH * c.gp), pkh = ld4(q + PKH * c.gp);
+        float t1[4] = {G.s1.x, G.s1.y, G.s1.z, G.s1.w}, t3[4] = {G.s3.x, G.s3.y, G.s3.z, G.s3.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d1[k] = pml(t1[k], comp(pah, k), comp(pbh, k), comp(pkh, k), d1[k]);
+            d3[k] = pml(t3[k], comp(pa, k), comp(pb, k), comp(pk, k), d3[k]);
+        }
+        G.s1 = make_float4(t1[0], t1[1], t1[2], t1[3]); G.s3 = make_float4(t3[0], t3[1], t3[2], t3[3]);
+    }
+    if (G.zs >= 0) {
+        const float *z = c.lpz + G.lrw;
+        const float za = z[PA * c.R], zb = z[PB * c.R], zk = z[PK * c.R];
+        const float zah = z[PAH * c.R], zbh = z[PBH * c.R], zkh = z[PKH * c.R];
+        float t2[4] = {G.s2.x, G.s2.y, G.s2.z, G.s2.w}, t4[4] = {G.s4.x, G.s4.y, G.s4.z, G.s4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d2[k] = pml(t2[k], za, zb, zk, d2[k]);
+            d4[k] = pml(t4[k], zah, zbh, zkh, d4[k]);
+        }
+        G.s2 = make_float4(t2[0], t2[1], t2[2], t2[3]); G.s4 = make_float4(t4[0], t4[1], t4[2], t4[3]);
+    }
+    const float4 vxo = ld4(c.Lf[F_VX] + lo), vzo = ld4(c.Lf[F_VZ] + lo);
+    S4 = make_float4(d1[0] + d2[0], d1[1] + d2[1], d1[2] + d2[2], d1[3] + d2[3]);
+    S5 = make_float4(d3[0] + d4[0], d3[1] + d4[1], d3[2] + d4[2], d3[3] + d4[3]);
+    o0 = make_float4(fmaf(G.mBx.x, S4.x, vxo.x), fmaf(G.mBx.y, S4.y, vxo.y), fmaf(G.mBx.z, S4.z, vxo.z),
+                     fmaf(G.mBx.w, S4.w, vxo.w));
+    o1 = make_float4(fmaf(G.mBz.x, S5.x, vzo.x), fmaf(G.mBz.y, S5.y, vzo.y), fmaf(G.mBz.z, S5.z, vzo.z),
+                     fmaf(G.mBz.w, S5.w, vzo.w));
+    st4(c.Lf[F_VX] + lo, o0);
+    st4(c.Lf[F_VZ] + lo, o1);
+}
+
+// S update (reads velocities from LDS, writes the group's stresses in place); `amp` = source term
+// of this step for the group's source cell (cell G.src & 3 of the group), 0 when there is none
+__device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const int lo, const int gq, float amp, float4 &S1, float4 &S2,
+                                            float4 &S3, float4 &o0, float4 &o1)
+{
+    const int PL = c.PL;
+    const float *vx = c.Lf[F_VX] + lo, *vz = c.Lf[F_VZ] + lo;
+    const float4 b1 = ld4(vx);
+    const float2 Lvx = ld2(vx - 2), Rvx = ld2(vx + 4);
+    const float4 a2 = ld4(vz);
+    const float2 Lvz = ld2(vz - 2), Rvz = ld2(vz + 4);
+    const float4 a0 = ld4(vz - 2 * PL), a1 = ld4(vz - PL), a3 = ld4(vz + PL);
+    const float4 b0 = ld4(vx - PL), b2 = ld4(vx + PL), b3 = ld4(vx + 2 * PL);
+    const float xv[8] = {Lvx.x, Lvx.y, b1.x, b1.y, b1.z, b1.w, Rvx.x, Rvx.y};
+    const float zv[8] = {Lvz.x, Lvz.y, a2.x, a2.y, a2.z, a2.w, Rvz.x, Rvz.y};
+    float e1[4], e2[4], e3[4], e4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        e1[k] = dbw(xv[k], xv[k + 1], xv[k + 2], xv[k + 3]);
+        e2[k] = dbw(comp(a0, k), comp(a1, k), comp(a2, k), comp(a3, k));
+        e3[k] = dfw(comp(b0, k), comp(b1, k), comp(b2, k), comp(b3, k));
+        e4[k] = dfw(zv[k + 1], zv[k + 2], zv[k + 3], zv[k + 4]);
+    }
+    if (G.xs_off >= 0) {
+        const float *q = c.lpx + 4 * gq;
+        const float4 pa = ld4(q + PA * c.gp), pb = ld4(q + PB * c.gp), pk = ld4(q + PK * c.gp);
+        const float4 pah = ld4(q + PAH * c.gp), pbh = ld4(q + PBH * c.gp), pkh = ld4(q + PKH * c.gp);
+        float t5[4] = {G.s5.x, G.s5.y, G.s5.z, G.s5.w}, t8[4] = {G.s8.x, G.s8.y, G.s8.z, G.s8.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            e1[k] = pml(t5[k], comp(pa, k), comp(pb, k), comp(pk, k), e1[k]);
+            e4[k] = pml(t8[k], comp(pah, k), comp(pbh, k), comp(pkh, k), e4[k]);
+        }
+        G.s5 = make_float4(t5[0], t5[1], t5[2], t5[3]); G.s8 = make_float4(t8[0], t8[1], t8[2], t8[3]);
+    }
+    if (G.zs >= 0) {
+        const float *z = c.lpz + G.lrw;
+        const float za = z[PA * c.R], zb = z[PB * c.R], zk = z[PK * c.R];
+        const float zah = z[PAH * c.R], zbh = z[PBH * c.R], zkh = z[PKH * c.R];
+        float t6[4] = {G.s6.x, G.s6.y, G.s6.z, G.s6.w}, t7[4] = {G.s7.x, G.s7.y, G.s7.z, G.s7.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            e2[k] = pml(t6[k], za, zb, zk, e2[k]);
+            e3[k] = pml(t7[k], zah, zbh, zkh, e3[k]);
+        }
+        G.s6 = make_float4(t6[0], t6[1], t6[2], t6[3]); G.s7 = make_float4(t7[0], t7[1], t7[2], t7[3]);
+    }
+    const float4 oxx = ld4(c.Lf[F_SXX] + lo), ozz = ld4(c.Lf[F_SZZ] + lo), oxz = ld4(c.Lf[F_SXZ] + lo);
+    float rxx[4], rzz[4], rxz[4], s3v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s3v[k] = e3[k] + e4[k];
+        rxx[k] = fmaf(comp(G.mM, k), e1[k], fmaf(comp(G.mL, k), e2[k], comp(oxx, k)));
+        rzz[k] = fmaf(comp(G.mL, k), e1[k], fmaf(comp(G.mM, k), e2[k], comp(ozz, k)));
+        rxz[k] = fmaf(comp(G.mMu, k), s3v[k], comp(oxz, k));
+        if (G.src >= 0 && k == (G.src & 3)) { rxx[k] += amp; rzz[k] += amp; }
+    }
+    if (c.fsurf && G.j == 0) { rzz[0] = rzz[1] = rzz[2] = rzz[3] = 0.f; }
+    S1 = make_float4(e1[0], e1[1], e1[2], e1[3]); S2 = make_float4(e2[0], e2[1], e2[2], e2[3]);
+    S3 = make_float4(s3v[0], s3v[1], s3v[2], s3v[3]);
+    o0 = make_float4(rzz[0], rzz[1], rzz[2], rzz[3]);            // published: szz, sxz
+    o1 = make_float4(rxz[0], rxz[1], rxz[2], rxz[3]);
+    st4(c.Lf[F_SXX] + lo, make_float4(rxx[0], rxx[1], rxx[2], rxx[3]));
+    st4(c.Lf[F_SZZ] + lo, o0);
+    st4(c.Lf[F_SXZ] + lo, o1);
+}
+
+template <bool SAVE, int NG>
+__global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int L = (int)blockIdx.x;
+    const int xcd = L & 7, kq = L >> 3;
+    const int w = kq % p.NW, s = p.shot0 + xcd + 8 * (kq / p.NW);
+    if (s >= p.shot1) return;
+    const int t = (int)threadIdx.x;
+    int r0, R;
+    ec_slab_rows(p.nz, p.NW, w, r0, R);
+    const int PL = p.PL, LR = R + 4;
+    const int fsz = LR * PL;
+    EcCtx c;
+    for (int k = 0; k < 5; ++k) c.Lf[k] = lds + k * fsz;
+    float *lpx = lds + 5 * fsz, *lpz = lpx + 6 * p.gp;        // C-PML tables: px [6][gp], pz [6][R]
+    c.lpx = lpx; c.lpz = lpz; c.PL = PL; c.R = R; c.gp = p.gp; c.fsurf = p.fsurf;
+    const unsigned ncell = (unsigned)p.nz * p.gp;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long xplane = (long long)p.nz * p.wx, zplane = 2LL * p.W * p.gp;
+
+    // ---- this thread's groups ---------------------------------------------------------------------
+    EcGroup G[NG];
+    bool slow = p.nrec > kEcThreads;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        EcGroup &g = G[q];
+        const int gi = t + q * kEcThreads;
+        g.own = gi < R * p.ng;
+        g.lrw = g.own ? gi / p.ng : 0;
+        g.g = g.own ? gi - g.lrw * p.ng : 0;
+        g.j = r0 + g.lrw;
+        g.lo = (g.lrw + 2) * PL + 4 + 4 * g.g;
+        g.inner = g.own && g.lrw >= 2 && g.lrw < R - 2;       // stencils stay inside the own rows
+        const unsigned gcc = (unsigned)g.j * p.gp + 4 * g.g;
+        g.mL = g.mM = g.mMu = g.mBx = g.mBz = zero4;
+        g.s1 = g.s2 = g.s3 = g.s4 = g.s5 = g.s6 = g.s7 = g.s8 = zero4;
+        g.xs_off = -1; g.zs = -1; g.src = -1; g.src_wt = 0.f; g.amp = 0.f;
+        if (g.own) {
+            g.mL = ld4(p.mat + M_L * ncell + gcc); g.mM = ld4(p.mat + M_M * ncell + gcc);
+            g.mMu = ld4(p.mat + M_MU * ncell + gcc);
+            g.mBx = ld4(p.mat + M_BX * ncell + gcc); g.mBz = ld4(p.mat + M_BZ * ncell + gcc);
+            if (p.W > 0) {
+                const int c0 = 4 * g.g;
+                if (c0 < p.wl) g.xs_off = c0; else if (c0 >= p.xr0) g.xs_off = p.wl + (c0 - p.xr0);
+                if (g.j < p.W) g.zs = g.j; else if (g.j >= p.nz - p.W) g.zs = g.j - (p.nz - 2 * p.W);
+            }
+        }
+        if (g.xs_off >= 0) {
+            const float *q = p.psix + (long long)s * p.psix_shot + (long long)g.j * p.wx + g.xs_off;
+            g.s1 = ld4(q); g.s3 = ld4(q + xplane); g.s5 = ld4(q + 2 * xplane); g.s8 = ld4(q + 3 * xplane);
+        }
+        if (g.zs >= 0) {
+            const float *q = p.psiz + (long long)s * p.psiz_shot + (long long)g.zs * p.gp + 4 * g.g;
+            g.s2 = ld4(q); g.s4 = ld4(q + zplane); g.s6 = ld4(q + 2 * zplane); g.s7 = ld4(q + 3 * zplane);
+        }
+        // at most one source tap per group (otherwise: slow path, rescan per step)
+        for (int e = 0; e < p.nsrc; ++e) {
+            const int cell = p.src_cell[(long long)s * p.nsrc + e];
+            if (cell < 0) continue;
+            const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
+            if (g.own && i0 == g.j && (i1 >> 2) == g.g) {
+                if (g.src >= 0) slow = true;
+                g.src = (e << 2) | (i1 & 3); g.src_wt = p.src_w[(long long)s * p.nsrc + e];
+            }
+        }
+    }
+    // one receiver per thread (otherwise: slow path)
+    int smp_lo = -1;                     // LDS offset of my receiver (-2: inactive tap, slab 0 writes zeros)
+    float smp_w = 0.f;
+    if (p.rec_vx != nullptr && t < p.nrec) {
+        const int cell = p.rec_cell[(long long)s * p.nrec + t];
+        if (cell >= 0) {
+            const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
+            if (i0 >= r0 && i0 < r0 + R) { smp_lo = (i0 - r0 + 2) * PL + 4 + i1; smp_w = p.rec_w[(long long)s * p.nrec + t]; }
+        } else if (w == 0) {
+            smp_lo = -2;
+        }
+    }
+    slow = __syncthreads_or(slow ? 1 : 0) != 0;
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+        if (!slow && G[q].src >= 0 && p.n_first < p.n_last)
+            G[q].amp = G[q].src_wt * p.f[((long long)p.n_first * p.nshot + s) * p.nsrc + (G[q].src >> 2)];
+
+    // ---- stage tables and the slab (+2 halo rows, + halo groups) of all five fields ----------------
+    for (int e = t; e < 6 * p.gp; e += kEcThreads) lpx[e] = p.px[e];
+    for (int e = t; e < 6 * R; e += kEcThreads) lpz[e] = p.pz[(e / R) * p.nz + r0 + (e % R)];
+    {
+        const float *gf = p.fields + (long long)s * p.shot_stride;
+        const int ngl = PL / 4;
+        for (int e = t; e < LR * ngl; e += kEcThreads) {
+            const int lr = e / ngl, lg = e - lr * ngl;
+            const int jj = r0 - 2 + lr, gg = lg - 1;
+            const bool ok = jj >= 0 && jj < p.nz && gg >= 0 && gg < p.ng;
+            const long long o = (long long)(jj + 2) * p.pitch + 4 + 4 * gg;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) st4(c.Lf[k] + lr * PL + 4 * lg, ok ? ld4(gf + k * p.field_stride + o) : zero4);
+        }
+    }
+    __syncthreads();
+
+    // ---- hand-off assignments (constant): granule e = t + k*kEcThreads of an 8*gp slot -------------
+    constexpr int kGr = 5;
+    int rcv_lo[kGr];                     // LDS offset inside the field (<0: none)
+    unsigned rcv_meta = 0;               // per k: bit0 field, bit1 from-upper-neighbour
+#pragma unroll
+    for (int k = 0; k < kGr; ++k) {
+        const int e = t + k * kEcThreads;
+        rcv_lo[k] = -1;
+        if (e < 8 * p.gp) {
+            const int cq = e % p.gp, q = e / p.gp;
+            const int col = 4 * (cq % p.ng) + cq / p.ng;         // granule order is [k][group]
+            const int row = q & 1, side = (q >> 1) & 1, fld = q >> 2;
+            if (cq < 4 * p.ng && !((side == 0 && w == 0) || (side == 1 && w == p.NW - 1))) {
+                rcv_lo[k] = ((side == 0) ? row : R + 2 + row) * PL + 4 + col;
+                rcv_meta |= (unsigned)(fld | (side == 0 ? 2 : 0)) << (2 * k);
+            }
+        }
+    }
+    const long long xslot = 8LL * p.gp;                       // granules per slot
+    unsigned long long *xw = p.xbuf + ((long long)s * p.NW + w) * 4 * xslot;      // [kind][parity][slot]
+    const bool do_x = p.NW > 1 && !(p.dbg & 1);
+    bool failed = false;
+
+    // receive one exchange: kind 0 = velocities (fields vx,vz), kind 1 = stresses (szz,sxz)
+    auto receive = [&](int kind, unsigned epoch, int parity) {
+        const unsigned long long *xu = xw - 4 * xslot + (kind * 2 + parity) * xslot;
+        const unsigned long long *xd = xw + 4 * xslot + (kind * 2 + parity) * xslot;
+        // sweep: every pass re-reads ALL of this thread's granules back to back (one memory round trip
+        // per pass, not one per granule) until every tag carries the epoch
+        const unsigned long long *src[kGr];
+        unsigned long long v[kGr];
+#pragma unroll
+        for (int k = 0; k < kGr; ++k) {
+            const int e = t + k * kEcThreads;
+            // my top halo = the upper neighbour's "down" rows (side 1), my bottom halo = the lower one's "up" rows
+            src[k] = ((rcv_meta >> (2 * k)) & 2u) ? xu + (e + 2 * p.gp) : xd + (e - 2 * p.gp);
+            v[k] = 0;
+        }
+        for (unsigned spins = 0;; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < kGr; ++k)
+                if (rcv_lo[k] >= 0) v[k] = __hip_atomic_load(src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < kGr; ++k)
+                if (rcv_lo[k] >= 0) ok = ok && (unsigned)(v[k] >> 32) == epoch;
+            if (ok || (p.dbg & 4)) break;                     // dbg 4: timing ablation only (wrong results)
+            if (spins > kEcMaxSpin ||
+                ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                failed = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int k = 0; k < kGr; ++k) {
+            if (rcv_lo[k] < 0) continue;
+            const unsigned m = (rcv_meta >> (2 * k)) & 3u;
+            const int fld = (kind == 0) ? ((m & 1u) ? F_VZ : F_VX) : ((m & 1u) ? F_SXZ : F_SZZ);
+            c.Lf[fld][rcv_lo[k]] = __uint_as_float((unsigned)v[k]);
+        }
+    };
+    // publish the four cells of a boundary-row group for the two fields of an exchange
+    auto publish = [&](const EcGroup &g, const int gq, int kind, unsigned epoch, int parity, const float4 &o0, const float4 &o1) {
+        unsigned long long *x = xw + (kind * 2 + parity) * xslot;
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        const float av[4] = {o0.x, o0.y, o0.z, o0.w}, bv[4] = {o1.x, o1.y, o1.z, o1.w};
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            // side 0 ("up"): my first two rows go to the upper neighbour; side 1: my last two rows
+            const int row = (sd == 0) ? g.lrw : g.lrw - (R - 2);
+            if (row < 0 || row > 1) continue;
+            if ((sd == 0 && w == 0) || (sd == 1 && w == p.NW - 1)) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __hip_atomic_store(x + (unsigned)ec_gran(p.gp, p.ng, 0, sd, row, gq, k), tag | __float_as_uint(av[k]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(x + (unsigned)ec_gran(p.gp, p.ng, 1, sd, row, gq, k), tag | __float_as_uint(bv[k]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    // source term of step n for a group: fetched one step ahead (a global load in the update itself
+    // would put a memory round trip on the workgroup's critical path every step)
+    auto source_amp = [&](EcGroup &g, int n) -> float {
+        if (!slow) {
+            const float a = g.amp;
+            if (g.src >= 0 && n + 1 < p.n_last)
+                g.amp = g.src_wt * p.f[((long long)(n + 1) * p.nshot + s) * p.nsrc + (g.src >> 2)];
+            return a;
+        }
+        float a = 0.f;                    // several taps in one group: they must share the component
+        for (int e = 0; e < p.nsrc; ++e) {
+            const int cell = p.src_cell[(long long)s * p.nsrc + e];
+            if (cell < 0) continue;
+            const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
+            if (g.own && i0 == g.j && (i1 >> 2) == g.g && (i1 & 3) == (g.src & 3))
+                a += p.src_w[(long long)s * p.nsrc + e] * p.f[((long long)n * p.nshot + s) * p.nsrc + e];
+        }
+        return a;
+    };
+
+    const int nsteps = p.n_last - p.n_first;
+    const long long sshot = (long long)s * 5 * ncell;
+    // Snapshot terms are stored right after they are produced; the interior update that follows gives
+    // them time to retire before the next poll is issued (vector memory operations retire in order).
+    auto do_v = [&](EcGroup &g, int n, int it, bool edge) {
+        float4 S4, S5, o0, o1;
+        const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g);   // per-step opaque: addresses are recomputed, not hoisted
+        ec_update_v(g, c, lo, gq, S4, S5, o0, o1);
+        if (edge && do_x && !(p.dbg & 16)) publish(g, gq, 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
+        if (SAVE && !(p.dbg & 2)) {
+            float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(ec_opaque(g.j) * p.gp + 4 * gq);
+            st4(Sn + 3 * (long long)ncell, S4); st4(Sn + 4 * (long long)ncell, S5);
+        }
+    };
+    auto do_s = [&](EcGroup &g, int n, int it, bool edge) {
+        float4 S1, S2, S3, o0, o1;
+        const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g);
+        ec_update_s(g, c, lo, gq, source_amp(g, n), S1, S2, S3, o0, o1);
+        if (edge && do_x && !(p.dbg & 16)) publish(g, gq, 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
+        if (SAVE && !(p.dbg & 2)) {
+            float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(ec_opaque(g.j) * p.gp + 4 * gq);
+            st4(Sn, S1); st4(Sn + (long long)ncell, S2); st4(Sn + 2 * (long long)ncell, S3);
+        }
+    };
+    for (int it = 0; it < nsteps; ++it) {
+        const int n = p.n_first + it;
+        // ---- V: interior rows first, then receive the stress halo, then the boundary rows --------
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (G[q].inner) do_v(G[q], n, it, false);
+            __builtin_amdgcn_sched_barrier(0);             // one group at a time: bounds the register peak
+        }
+        if (do_x && it > 0 && !(p.dbg & 32)) receive(1, (unsigned)(2 * it), (it - 1) & 1);
+        __syncthreads();                                   // A: stress halo rows are in LDS
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (G[q].own && !G[q].inner) do_v(G[q], n, it, true);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                   // B: all velocities of the slab are in LDS
+        // ---- S: interior rows, receive the velocity halo, boundary rows -----------------------------
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (G[q].inner) do_s(G[q], n, it, false);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (do_x && !(p.dbg & 32)) receive(0, (unsigned)(2 * it + 1), it & 1);
+        // ---- receivers sample the new velocities (stores after the poll) ----------------------------
+        if (p.rec_vx != nullptr && !(p.dbg & 8)) {
+            if (!slow) {
+                const long long ro = ((long long)n * p.nshot + s) * p.nrec + t;
+                if (smp_lo >= 0) {
+                    p.rec_vx[ro] = fmaf(smp_w, c.Lf[F_VX][smp_lo], 0.f);
+                    p.rec_vz[ro] = fmaf(smp_w, c.Lf[F_VZ][smp_lo], 0.f);
+                } else if (smp_lo == -2) {
+                    p.rec_vx[ro] = 0.f; p.rec_vz[ro] = 0.f;
+                }
+            } else {
+                for (int e = t; e < p.nrec; e += kEcThreads) {
+                    const long long ro = ((long long)n * p.nshot + s) * p.nrec + e;
+                    const int cell = p.rec_cell[(long long)s * p.nrec + e];
+                    if (cell < 0) { if (w == 0) { p.rec_vx[ro] = 0.f; p.rec_vz[ro] = 0.f; } continue; }
+                    const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
+                    if (i0 >= r0 && i0 < r0 + R) {
+                        const float ww = p.rec_w[(long long)s * p.nrec + e];
+                        const int o = (i0 - r0 + 2) * PL + 4 + i1;
+                        p.rec_vx[ro] = fmaf(ww, c.Lf[F_VX][o], 0.f);
+                        p.rec_vz[ro] = fmaf(ww, c.Lf[F_VZ][o], 0.f);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // C: velocity halo rows are in LDS
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (G[q].own && !G[q].inner) do_s(G[q], n, it, true);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((it & 31) == 31 || it == nsteps - 1) {
+            if (__syncthreads_or(failed ? 1 : 0)) {        // D (+ collective time-out check)
+                if (t == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        } else {
+            __syncthreads();                               // D: all stresses of the slab are in LDS
+        }
+    }
+
+    // ---- the own rows of the five fields and the memory variables go back to the global state -----
+    float *gf = p.fields + (long long)s * p.shot_stride;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const EcGroup &g = G[q];
+        if (!g.own) continue;
+        const long long o = (long long)(g.j + 2) * p.pitch + 4 + 4 * g.g;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) st4(gf + k * p.field_stride + o, ld4(c.Lf[k] + g.lo));
+        if (g.xs_off >= 0) {
+            float *q2 = p.psix + (long long)s * p.psix_shot + (long long)g.j * p.wx + g.xs_off;
+            st4(q2, g.s1); st4(q2 + xplane, g.s3); st4(q2 + 2 * xplane, g.s5); st4(q2 + 3 * xplane, g.s8);
+        }
+        if (g.zs >= 0) {
+            float *q2 = p.psiz + (long long)s * p.psiz_shot + (long long)g.zs * p.gp + 4 * g.g;
+            st4(q2, g.s2); st4(q2 + zplane, g.s4); st4(q2 + 2 * zplane, g.s6); st4(q2 + 3 * zplane, g.s7);
+        }
+    }
+}

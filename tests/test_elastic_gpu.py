@@ -37,8 +37,10 @@ def _run_hip(case, gs=0, budget=None, need_f=True):
     dict(free_surface=True, water=0, nz=37, nx=53, fw=6),  # free surface on a solid, ragged sizes
 ])
 def test_forward_backward_parity(oracle32, kw):
-    case = elastic_case(seed=4, **kw)
-    o = oracle32
+    _check_parity(oracle32, elastic_case(seed=4, **kw))
+
+
+def _check_parity(o, case, bitwise=False):
     ovx, ovz, S = o.elastic_forward(case["mat"], case["pz"], case["px"], case["f"], case["sc"],
                                     case["sw"], case["rc"], case["rw"], save=True,
                                     free_surface=case["fs"])
@@ -47,6 +49,8 @@ def test_forward_backward_parity(oracle32, kw):
     assert np.isfinite(hx).all() and np.abs(ovx).max() > 0 and np.abs(ovz).max() > 0
     print("max |hip-oracle| vx %.3e vz %.3e" % (np.abs(hx - ovx).max(), np.abs(hz - ovz).max()))
     assert rel_l2(hx, ovx) <= TOL_TRACE and rel_l2(hz, ovz) <= TOL_TRACE
+    if bitwise:
+        assert np.abs(hx - ovx).max() == 0.0 and np.abs(hz - ovz).max() == 0.0
     rng = np.random.default_rng(12)
     gx = (rng.standard_normal(ovx.shape) * np.abs(ovx).max()).astype(np.float32)
     gz = (rng.standard_normal(ovz.shape) * np.abs(ovz).max()).astype(np.float32)
@@ -58,6 +62,29 @@ def test_forward_backward_parity(oracle32, kw):
     for k, name in enumerate(["lambda", "lambda+2mu", "mu_xz", "1/rho_x", "1/rho_z"]):
         assert rel_l2(gm_h[k], gm_o[k]) <= TOL_GRAD, name
     assert rel_l2(f.grad.cpu().numpy(), gf_o) <= TOL_GRAD
+
+
+@pytest.mark.parametrize("nw,fs", [(2, False), (3, True), (5, False), (7, True)])
+def test_cluster_path_with_halo_handoff(oracle32, monkeypatch, nw, fs):
+    """Force the LDS-resident cluster kernel to cut a shot into several row slabs so that the
+    velocity/stress granule hand-off between workgroups is exercised: traces stay bitwise equal
+    to the oracle and the snapshot stream (checked through the gradients) is unchanged."""
+    monkeypatch.setenv("MIFWI_EL_NW", str(nw))
+    case = elastic_case(seed=23, nz=61, nx=83, fw=8, ns=3, nrec=15, nt=120, free_surface=fs)
+    _check_parity(oracle32, case, bitwise=True)
+
+
+def test_cluster_and_per_step_paths_agree(monkeypatch):
+    case = elastic_case(seed=29, nz=70, nx=300, fw=10, ns=2, nrec=40, nt=100)   # two groups per thread
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MIFWI_EL_CLUSTER", flag)
+        mat, f, rvx, rvz = _run_hip(case)
+        torch.autograd.backward([rvx, rvz], [torch.sign(rvx.detach()), torch.sign(rvz.detach())])
+        outs.append((rvx.detach().clone(), rvz.detach().clone(), mat.grad.clone(), f.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel_l2(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()) <= TOL_GRAD
+    assert rel_l2(outs[0][3].cpu().numpy(), outs[1][3].cpu().numpy()) <= TOL_GRAD
 
 
 @pytest.mark.parametrize("gs", [1, 2, 3])
