@@ -446,6 +446,16 @@ __device__ __forceinline__ void cl_update(const float *c, const float *pp, int P
     }
 }
 
+// Value the compiler must treat as unknown here.  Applied once per time step to a thread's group
+// offsets: the global / LDS addresses derived from them are then recomputed where they are used
+// (an add or two) instead of being hoisted out of the time loop into registers of their own, which
+// spilled - and every spill reload in the loop is a full s_waitcnt vmcnt(0) on the wave.
+__device__ __forceinline__ int cl_opaque(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 template <int MODE>   // 0: forward, 1: forward + snapshots, 2: adjoint + imaging
 __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
 {
@@ -474,6 +484,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     float4 rr[kClMaxNG], acc[kClMaxNG];
     int jg[kClMaxNG];                   // (grid row << 12) | group
     auto goff = [&](int i_) { return (long long)(jg[i_] >> 12) * p.gp + 4 * (jg[i_] & 4095); };
+    auto goff_of = [&](int jg_) { return (unsigned)((jg_ >> 12) * p.gp + 4 * (jg_ & 4095)); };
     unsigned dampmask = 0;
     int nown = 0;
 #pragma unroll
@@ -628,13 +639,13 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         if (it_ >= nsteps) return;
         const int n_ = adj ? (p.n_first - it_) : (p.n_first + it_);
         if (!adj) {
-            if (src_slot >= 0) amp_next = p.f[((long long)n_ * p.nshot + s) * p.nsrc + src_e];
+            if (src_slot >= 0) amp_next = (p.f + ((long long)n_ * p.nshot + s) * p.nsrc)[cl_opaque(src_e)];
         } else {
-            if (inj_off >= 0) amp_next = p.grad_rec[((long long)n_ * p.nshot + s) * p.nrec + inj_id];
+            if (inj_off >= 0) amp_next = (p.grad_rec + ((long long)n_ * p.nshot + s) * p.nrec)[cl_opaque(inj_id)];
             const float *Gq = p.G + (long long)((n_ - 1) - p.g_first) * p.g_step + plane;
 #pragma unroll
             for (int i = 0; i < kClMaxNG; ++i)
-                if (i < nown) Gbuf[i] = *reinterpret_cast<const float4 *>(Gq + goff(i));
+                if (i < nown) Gbuf[i] = *reinterpret_cast<const float4 *>(Gq + goff_of(cl_opaque(jg[i])));
         }
     };
     prefetch(0);
@@ -645,14 +656,11 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         // ---- sampling of the current field (owner slab writes) -------------------------------
         if (p.dbg & 8) {
         } else if (!slow_sparse) {
-            if (smp_off >= 0) {
-                const float val = fmaf(adj ? src_wt : smp_w, cur[smp_off], 0.f);
-                if (!adj) p.rec_out[((long long)n * p.nshot + s) * p.nrec + smp_e] = val;
-                else p.grad_f[((long long)n * p.nshot + s) * p.nsrc + smp_e] = val;
-            } else if (smp_off == -2) {
-                if (!adj) p.rec_out[((long long)n * p.nshot + s) * p.nrec + smp_e] = 0.f;
-                else p.grad_f[((long long)n * p.nshot + s) * p.nsrc + smp_e] = 0.f;
-            }
+            // uniform row base + a 32-bit lane offset: no per-lane 64-bit address to keep (or spill)
+            float *out_n = adj ? p.grad_f + ((long long)n * p.nshot + s) * p.nsrc
+                               : p.rec_out + ((long long)n * p.nshot + s) * p.nrec;
+            if (smp_off >= 0) out_n[cl_opaque(smp_e)] = fmaf(adj ? src_wt : smp_w, cur[cl_opaque(smp_off)], 0.f);
+            else if (smp_off == -2) out_n[cl_opaque(smp_e)] = 0.f;
         } else if (!adj) {
             if (p.rec_out != nullptr)
                 for (int e = t; e < p.nrec; e += kClThreads) {
@@ -694,12 +702,13 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
                 float q0 = 0.f;
                 const bool damped = (dampmask >> i) & 1u;
+                const int lo_i = cl_opaque(loff[i]), jg_i = cl_opaque(jg[i]);
                 if (damped) {
-                    q1 = *reinterpret_cast<const float4 *>(ldq1 + 4 * (jg[i] & 4095));
-                    q0 = ldq0[(jg[i] >> 12) - r0];
+                    q1 = *reinterpret_cast<const float4 *>(ldq1 + 4 * (jg_i & 4095));
+                    q0 = ldq0[(jg_i >> 12) - r0];
                 }
-                cl_update<MODE == 1>(cur + loff[i], prv + loff[i], PL, rr[i], q0, q1, damped, p.c0, p.c1,
-                                     p.n1 - 4 * (jg[i] & 4095), un, gk);
+                cl_update<MODE == 1>(cur + lo_i, prv + lo_i, PL, rr[i], q0, q1, damped, p.c0, p.c1,
+                                     p.n1 - 4 * (jg_i & 4095), un, gk);
                 if (!adj && !slow_sparse && i == src_slot) {
                     const float a = src_wt * amp;
 #pragma unroll
@@ -720,7 +729,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                         }
                     }
                 }
-                *reinterpret_cast<float4 *>(prv + loff[i]) = make_float4(un[0], un[1], un[2], un[3]);
+                *reinterpret_cast<float4 *>(prv + lo_i) = make_float4(un[0], un[1], un[2], un[3]);
                 if (MODE == 1) Gbuf[i] = make_float4(gk[0], gk[1], gk[2], gk[3]);
             }
             __builtin_amdgcn_sched_barrier(0);   // one group at a time: keeps the register peak below 128
@@ -740,7 +749,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         if (adj) {
             // ---- adjoint sources: receiver taps of this slab, z^k[cell] += (w g) (r inv) -------
             if (!slow_sparse) {
-                if (inj_off >= 0) atomicAdd(&prv[inj_off], (smp_w * amp) * inj_scale);
+                if (inj_off >= 0) atomicAdd(&prv[cl_opaque(inj_off)], (smp_w * amp) * inj_scale);
             } else {
                 const int cnt = p.slab_cnt[s * p.NW + w];
                 const int *lst = p.slab_list + ((long long)s * p.NW + w) * p.nrec;
@@ -761,7 +770,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
 #pragma unroll
             for (int i = 0; i < kClMaxNG; ++i) {
                 if (i < nown) {
-                    const float4 z = *reinterpret_cast<const float4 *>(prv + loff[i]);
+                    const float4 z = *reinterpret_cast<const float4 *>(prv + cl_opaque(loff[i]));
                     acc[i].x = fmaf(z.x, Gbuf[i].x, acc[i].x); acc[i].y = fmaf(z.y, Gbuf[i].y, acc[i].y);
                     acc[i].z = fmaf(z.z, Gbuf[i].z, acc[i].z); acc[i].w = fmaf(z.w, Gbuf[i].w, acc[i].w);
                 }
@@ -813,7 +822,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         if (MODE == 1 && !(p.dbg & 2)) {
 #pragma unroll
             for (int i = 0; i < kClMaxNG; ++i)
-                if (i < nown) *reinterpret_cast<float4 *>(Gn + goff(i)) = Gbuf[i];
+                if (i < nown) *reinterpret_cast<float4 *>(Gn + goff_of(cl_opaque(jg[i]))) = Gbuf[i];
         }
         prefetch(it + 1);
         // a timed-out thread carries garbage forward until the next collective check (fatal anyway)

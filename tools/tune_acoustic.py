@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Sweep the acoustic kernel's tile parameters on the bench workload (GPU box only)."""
-import itertools
+"""A/B the acoustic kernels' tuning knobs on the bench workload (GPU box only).
+usage: tune_acoustic.py NT "K1=V1,K2=V2;K1=V3,..."   (each ';'-separated group is one configuration,
+e.g. "MIFWI_AC_CLUSTER=0,MIFWI_AC_LX=64,MIFWI_AC_RZ=2;MIFWI_AC_CLUSTER=1")
+"""
 import os
 import sys
-import time
 
 import torch
 
@@ -21,19 +22,25 @@ def run(nt, reps=3):
         wl.step(True)
     torch.cuda.synchronize()
     tf, tb = wl.kernel_times()
+    del wl
+    torch.cuda.empty_cache()
     return tf * 1e6, tb * 1e6
 
 
 if __name__ == "__main__":
     nt = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-    combos = list(itertools.product([16, 32, 64], [1, 2], [1, 2, 4]))
-    print("lx rz gs  fwd+save_us  adj_us")
-    for lx, rz, gs in combos:
-        os.environ["MIFWI_AC_LX"] = str(lx)
-        os.environ["MIFWI_AC_RZ"] = str(rz)
-        os.environ["MIFWI_AC_GS"] = str(gs)
+    configs = sys.argv[2].split(";") if len(sys.argv) > 2 else [""]
+    print("config -> fwd+save_step_us adj_step_us")
+    for cfg in configs:
+        keys = []
+        for kv in [c for c in cfg.split(",") if c]:
+            k, v = kv.split("=")
+            os.environ[k] = v
+            keys.append(k)
         try:
             tf, tb = run(nt)
-            print("%2d %d %d   %7.2f   %7.2f" % (lx, rz, gs, tf, tb), flush=True)
+            print("%-50s %8.2f %8.2f" % (cfg or "(default)", tf, tb), flush=True)
         except Exception as e:  # noqa: BLE001
-            print(lx, rz, gs, "FAILED", e, flush=True)
+            print(cfg, "FAILED", repr(e)[:300], flush=True)
+        for k in keys:
+            os.environ.pop(k, None)
