@@ -755,7 +755,9 @@ struct mifwi_elastic_plan {
     long long psi_elems;  // psix+psiz rounded up to 64
     // cluster path (LDS-resident time loop); 0 when a shot does not fit
     int cluster, NW, PL, cl_shots, cl_lds, cl_ng;
-    long long xbuf_elems;
+    // adjoint cluster kernel (its own slab count: different LDS footprint)
+    int cl_adj, adj_NW, adj_shots, adj_lds, adj_ng, adj_zrows;
+    long long xbuf_elems, list_elems;
 };
 
 namespace {
@@ -824,11 +826,13 @@ void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, hipStream_t st)
 void el_cluster_setup(mifwi_elastic_plan *pl)
 {
     pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0; pl->xbuf_elems = 0;
-    if (env_int("MIFWI_EL_CLUSTER", 1) == 0 || pl->d.ntap != 1) return;
+    pl->cl_adj = 0; pl->adj_NW = 0; pl->adj_shots = 0; pl->adj_lds = 0; pl->adj_ng = 0; pl->adj_zrows = 0; pl->list_elems = 0;
+    if (pl->d.ntap != 1) return;
+    const bool want_fwd = env_int("MIFWI_EL_CLUSTER", 1) != 0;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device) != hipSuccess) return;
     const int forced = env_int("MIFWI_EL_NW", 0);
-    for (int nw = 1; nw <= 32; ++nw) {
+    for (int nw = 1; nw <= 32 && want_fwd; ++nw) {
         if (forced > 0 && nw != forced) continue;
         const int rows = mifwi::ceil_div(pl->d.nz, nw);
         if (pl->d.nz / nw < 4) break;
@@ -841,14 +845,48 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
         pl->cl_ng = mifwi::ceil_div(rows * pl->ng, kEcThreads);
         break;
     }
-    if (!pl->cluster) return;
-    pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * pl->NW * 4 * 8 * pl->gp + 64, 64);
-    for (const void *fn : {(const void *)el_cluster_fwd<false, 1>, (const void *)el_cluster_fwd<true, 1>,
-                           (const void *)el_cluster_fwd<false, 2>, (const void *)el_cluster_fwd<true, 2>})
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pl->cl_lds) != hipSuccess) {
-            pl->cluster = 0;
-            return;
+    if (pl->cluster) {
+        for (const void *fn : {(const void *)el_cluster_fwd<false, 1>, (const void *)el_cluster_fwd<true, 1>,
+                               (const void *)el_cluster_fwd<false, 2>, (const void *)el_cluster_fwd<true, 2>})
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pl->cl_lds) != hipSuccess)
+                pl->cluster = 0;
+    }
+    // adjoint: four E/D planes + the adjoint memory variables of the slab's C-PML cells in LDS; the
+    // gradient accumulators are per shot, so it needs shot groups of one (not used when the caller
+    // asked for a group size)
+    const int forced_adj = env_int("MIFWI_EL_ADJ_NW", forced);
+    if (env_int("MIFWI_EL_CLUSTER_ADJ", 1) != 0 && pl->d.shots_per_group <= 0) {
+        for (int nw = 1; nw <= 32; ++nw) {
+            if (forced_adj > 0 && nw != forced_adj) continue;
+            if (pl->d.nz / nw < 4) break;
+            const int rows = mifwi::ceil_div(pl->d.nz, nw);
+            int zmax = 0;
+            for (int w = 0; w < nw && pl->W > 0; ++w) {
+                const int base = pl->d.nz / nw, rem = pl->d.nz - base * nw;
+                const int R = base + (w < rem ? 1 : 0), r0 = w * base + std::min(w, rem);
+                const int ntop = std::max(0, std::min(r0 + R, pl->W) - r0);
+                const int nbot = std::max(0, r0 + R - std::max(r0, pl->d.nz - pl->W));
+                zmax = std::max(zmax, ntop + nbot);
+            }
+            const long long lds = (4LL * (rows + 4) * pl->PL + 6LL * pl->gp + 6LL * ((rows + 3) & ~3) +
+                                   4LL * rows * pl->wx + 4LL * zmax * pl->gp) * sizeof(float);
+            if (lds > 150 * 1024) continue;
+            if ((long long)rows * pl->ng > 2 * kEcThreads || 8 * pl->gp > 5 * kEcThreads) continue;
+            const int per_launch = 8 * (ncu / (8 * nw));
+            if (per_launch < 8) break;
+            pl->cl_adj = 1; pl->adj_NW = nw; pl->adj_shots = per_launch; pl->adj_lds = (int)lds;
+            pl->adj_ng = mifwi::ceil_div(rows * pl->ng, kEcThreads); pl->adj_zrows = zmax;
+            break;
         }
+        if (pl->cl_adj)
+            for (const void *fn : {(const void *)el_cluster_adj<1>, (const void *)el_cluster_adj<2>})
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pl->adj_lds) != hipSuccess)
+                    pl->cl_adj = 0;
+    }
+    const int nwmax = std::max(pl->cluster ? pl->NW : 0, pl->cl_adj ? pl->adj_NW : 0);
+    if (nwmax > 0) pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * nwmax * 4 * 8 * pl->gp + 64, 64);
+    if (pl->cl_adj)
+        pl->list_elems = mifwi::round_up64((long long)pl->d.nshot * pl->adj_NW * (1 + pl->d.nrec), 64);
 }
 
 template <bool SAVE>
@@ -856,7 +894,7 @@ int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStr
 {
     MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
     c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
-    c.err = reinterpret_cast<int *>(xbuf + 2LL * pl->d.nshot * pl->NW * 4 * 8 * pl->gp);
+    c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
     for (int s0 = 0; s0 < pl->d.nshot; s0 += pl->cl_shots) {
         c.shot0 = s0;
         c.shot1 = std::min(pl->d.nshot, s0 + pl->cl_shots);
@@ -934,6 +972,10 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     pl->ngroups = mifwi::ceil_div(d->nshot, gs);
     pl->psi_elems = mifwi::round_up64(pl->psix_elems + pl->psiz_elems, 64);
     el_cluster_setup(pl);
+    if (pl->cl_adj) {                    // the adjoint cluster kernel keeps one accumulator set per shot
+        pl->gs = 1;
+        pl->ngroups = d->nshot;
+    }
     *plan = pl;
     return MIFWI_OK;
 }
@@ -954,7 +996,8 @@ int mifwi_elastic_plan_layout(const mifwi_elastic_plan *pl, mifwi_elastic_layout
     const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
     out->state_elems = pl->fields_elems + psi;
     out->work_forward_elems = out->state_elems + bbox + (pl->cluster ? pl->xbuf_elems : 0);
-    out->work_backward_elems = pl->fields_elems + 2 * psi + 5LL * pl->ngroups * pl->coef_elems + bbox;
+    out->work_backward_elems = pl->fields_elems + 2 * psi + 5LL * pl->ngroups * pl->coef_elems + bbox +
+                               (pl->cl_adj ? pl->xbuf_elems + pl->list_elems : 0);
     return MIFWI_OK;
 }
 
@@ -1071,6 +1114,49 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
     const bool want_f = grad_f != nullptr && d.nsrc > 0;
     ps.nsmp = want_f ? d.nsrc : 0; ps.ntap_smp = d.ntap; ps.smp_cell = src_cell; ps.smp_w = src_w;
     const long long snap_step = 5LL * d.nshot * pl->coef_elems;
+    if (pl->cl_adj && n_hi >= n_lo) {
+        float *xbuf = reinterpret_cast<float *>(bbox) + mifwi::round_up64(4LL * d.nshot, 64);
+        int *lists = reinterpret_cast<int *>(xbuf + pl->xbuf_elems);
+        hipLaunchKernelGGL(ec_build_slab_lists, dim3(d.nshot), dim3(256), 0, st, rec_cell, d.nrec, d.nz, d.nx,
+                           pl->adj_NW, lists, lists + (long long)d.nshot * pl->adj_NW);
+        EaParams c;
+        memset(&c, 0, sizeof(c));
+        c.nz = d.nz; c.nx = d.nx; c.ng = pl->ng; c.gp = pl->gp; c.pitch = pl->pitch;
+        c.field_stride = (unsigned)pl->field_stride; c.shot_stride = pl->shot_stride;
+        c.nshot = d.nshot; c.NW = pl->adj_NW; c.PL = pl->PL;
+        c.n_first = n_hi; c.n_last = n_lo; c.nt = d.nt;
+        c.W = pl->W; c.wl = pl->wl; c.xr0 = pl->xr0; c.wx = pl->wx; c.fsurf = d.free_surface;
+        c.zrows_max = pl->adj_zrows;
+        c.psix_shot = 4LL * d.nz * pl->wx; c.psiz_shot = 4LL * 2 * pl->W * pl->gp; c.psix_elems = pl->psix_elems;
+        c.mat = mat; c.pz = pz; c.px = px;
+        c.fields = fields; c.psiA = psiA; c.psiB = psiB;
+        c.S = snap; c.s_first = snap_first; c.s_step = snap_step;
+        c.acc = acc;
+        c.nsrc = d.nsrc; c.nrec = d.nrec; c.src_cell = src_cell; c.src_w = src_w;
+        c.grad_f = want_f ? grad_f : nullptr;
+        c.rec_cell = rec_cell; c.rec_w = rec_w; c.g_vx = g_vx; c.g_vz = g_vz;
+        c.slab_cnt = lists; c.slab_list = lists + (long long)d.nshot * pl->adj_NW;
+        c.dbg = env_int("MIFWI_EL_CL_DBG", 0);
+        MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
+        c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
+        c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
+        for (int s0 = 0; s0 < d.nshot; s0 += pl->adj_shots) {
+            c.shot0 = s0;
+            c.shot1 = std::min(d.nshot, s0 + pl->adj_shots);
+            const int nsl8 = mifwi::ceil_div(c.shot1 - s0, 8);
+            if (pl->adj_ng == 1)
+                hipLaunchKernelGGL((el_cluster_adj<1>), dim3(8 * pl->adj_NW * nsl8), dim3(kEcThreads), pl->adj_lds, st, c);
+            else
+                hipLaunchKernelGGL((el_cluster_adj<2>), dim3(8 * pl->adj_NW * nsl8), dim3(kEcThreads), pl->adj_lds, st, c);
+        }
+        MIFWI_HIP_TRY(hipGetLastError());
+        int err = 0;
+        MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
+        MIFWI_HIP_TRY(hipStreamSynchronize(st));
+        if (err != 0)
+            return mifwi::fail(MIFWI_EHIP, "elastic adjoint cluster kernel: a halo hand-off timed out; set "
+                               "MIFWI_EL_CLUSTER_ADJ=0 to use one launch per half step");
+    } else
     for (int n = n_hi; n >= n_lo; --n) {
         // ping-pong of the adjoint memory variables is absolute in n (resumable ranges)
         const int par = (d.nt - 1 - n) & 1;

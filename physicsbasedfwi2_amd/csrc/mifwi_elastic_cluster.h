@@ -69,11 +69,9 @@ __device__ __forceinline__ int ec_opaque(int x)
 // per-thread state of one owned group of 4 cells (registers for the whole run)
 struct EcGroup {
     bool own, inner;
-    int lrw, g, j, lo, xs_off, zs;
+    int g, j, xs_off, zs;                         // group in the row, grid row, strip slots (or -1)
     float4 mL, mM, mMu, mBx, mBz;                 // materials
     float4 s1, s2, s3, s4, s5, s6, s7, s8;        // C-PML memory variables
-    int src;                                      // (source index << 2) | cell of the group, or -1
-    float src_wt, amp;                            // amp: this step's source term, fetched one step ahead
 };
 
 struct EcCtx {
@@ -83,7 +81,7 @@ struct EcCtx {
 };
 
 // V update (reads stresses from LDS, writes the group's velocities in place)
-__device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const int lo, const int gq, float4 &S4, float4 &S5, float4 &o0,
+__device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const int lo, const int gq, const int lrw, float4 &S4, float4 &S5, float4 &o0,
                                             float4 &o1)
 {
     const int PL = c.PL;
@@ -128,7 +126,7 @@ __device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const in
         G.s1 = make_float4(t1[0], t1[1], t1[2], t1[3]); G.s3 = make_float4(t3[0], t3[1], t3[2], t3[3]);
     }
     if (G.zs >= 0) {
-        const float *z = c.lpz + G.lrw;
+        const float *z = c.lpz + lrw;
         const float za = z[PA * c.R], zb = z[PB * c.R], zk = z[PK * c.R];
         const float zah = z[PAH * c.R], zbh = z[PBH * c.R], zkh = z[PKH * c.R];
         float t2[4] = {G.s2.x, G.s2.y, G.s2.z, G.s2.w}, t4[4] = {G.s4.x, G.s4.y, G.s4.z, G.s4.w};
@@ -152,7 +150,7 @@ __device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const in
 
 // S update (reads velocities from LDS, writes the group's stresses in place); `amp` = source term
 // of this step for the group's source cell (cell G.src & 3 of the group), 0 when there is none
-__device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const int lo, const int gq, float amp, float4 &S1, float4 &S2,
+__device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const int lo, const int gq, const int lrw, const float4 &amp, float4 &S1, float4 &S2,
                                             float4 &S3, float4 &o0, float4 &o1)
 {
     const int PL = c.PL;
@@ -186,7 +184,7 @@ __device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const in
         G.s5 = make_float4(t5[0], t5[1], t5[2], t5[3]); G.s8 = make_float4(t8[0], t8[1], t8[2], t8[3]);
     }
     if (G.zs >= 0) {
-        const float *z = c.lpz + G.lrw;
+        const float *z = c.lpz + lrw;
         const float za = z[PA * c.R], zb = z[PB * c.R], zk = z[PK * c.R];
         const float zah = z[PAH * c.R], zbh = z[PBH * c.R], zkh = z[PKH * c.R];
         float t6[4] = {G.s6.x, G.s6.y, G.s6.z, G.s6.w}, t7[4] = {G.s7.x, G.s7.y, G.s7.z, G.s7.w};
@@ -205,7 +203,7 @@ __device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const in
         rxx[k] = fmaf(comp(G.mM, k), e1[k], fmaf(comp(G.mL, k), e2[k], comp(oxx, k)));
         rzz[k] = fmaf(comp(G.mL, k), e1[k], fmaf(comp(G.mM, k), e2[k], comp(ozz, k)));
         rxz[k] = fmaf(comp(G.mMu, k), s3v[k], comp(oxz, k));
-        if (G.src >= 0 && k == (G.src & 3)) { rxx[k] += amp; rzz[k] += amp; }
+        rxx[k] += comp(amp, k); rzz[k] += comp(amp, k);       // source term of the cell (0 without one)
     }
     if (c.fsurf && G.j == 0) { rzz[0] = rzz[1] = rzz[2] = rzz[3] = 0.f; }
     S1 = make_float4(e1[0], e1[1], e1[2], e1[3]); S2 = make_float4(e2[0], e2[1], e2[2], e2[3]);
@@ -241,20 +239,21 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     // ---- this thread's groups ---------------------------------------------------------------------
     EcGroup G[NG];
     bool slow = p.nrec > kEcThreads;
+    int tsrc = -1, src_mask = 0;         // (source index << 3) | (slot << 2) | cell of the group; slots with sources
+    float tsrc_wt = 0.f, tamp = 0.f;     // tamp: this step's source term, fetched one step ahead
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
         EcGroup &g = G[q];
         const int gi = t + q * kEcThreads;
         g.own = gi < R * p.ng;
-        g.lrw = g.own ? gi / p.ng : 0;
-        g.g = g.own ? gi - g.lrw * p.ng : 0;
-        g.j = r0 + g.lrw;
-        g.lo = (g.lrw + 2) * PL + 4 + 4 * g.g;
-        g.inner = g.own && g.lrw >= 2 && g.lrw < R - 2;       // stencils stay inside the own rows
+        const int lrw = g.own ? gi / p.ng : 0;
+        g.g = g.own ? gi - lrw * p.ng : 0;
+        g.j = r0 + lrw;
+        g.inner = g.own && lrw >= 2 && lrw < R - 2;           // stencils stay inside the own rows
         const unsigned gcc = (unsigned)g.j * p.gp + 4 * g.g;
         g.mL = g.mM = g.mMu = g.mBx = g.mBz = zero4;
         g.s1 = g.s2 = g.s3 = g.s4 = g.s5 = g.s6 = g.s7 = g.s8 = zero4;
-        g.xs_off = -1; g.zs = -1; g.src = -1; g.src_wt = 0.f; g.amp = 0.f;
+        g.xs_off = -1; g.zs = -1;
         if (g.own) {
             g.mL = ld4(p.mat + M_L * ncell + gcc); g.mM = ld4(p.mat + M_M * ncell + gcc);
             g.mMu = ld4(p.mat + M_MU * ncell + gcc);
@@ -279,8 +278,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
             if (cell < 0) continue;
             const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
             if (g.own && i0 == g.j && (i1 >> 2) == g.g) {
-                if (g.src >= 0) slow = true;
-                g.src = (e << 2) | (i1 & 3); g.src_wt = p.src_w[(long long)s * p.nsrc + e];
+                if (tsrc >= 0) slow = true;             // fast path: one source cell per thread
+                tsrc = (e << 3) | (q << 2) | (i1 & 3); tsrc_wt = p.src_w[(long long)s * p.nsrc + e];
+                src_mask |= 1 << q;
             }
         }
     }
@@ -297,10 +297,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         }
     }
     slow = __syncthreads_or(slow ? 1 : 0) != 0;
-#pragma unroll
-    for (int q = 0; q < NG; ++q)
-        if (!slow && G[q].src >= 0 && p.n_first < p.n_last)
-            G[q].amp = G[q].src_wt * p.f[((long long)p.n_first * p.nshot + s) * p.nsrc + (G[q].src >> 2)];
+    if (!slow && tsrc >= 0 && p.n_first < p.n_last)
+        tamp = tsrc_wt * p.f[((long long)p.n_first * p.nshot + s) * p.nsrc + (tsrc >> 3)];
 
     // ---- stage tables and the slab (+2 halo rows, + halo groups) of all five fields ----------------
     for (int e = t; e < 6 * p.gp; e += kEcThreads) lpx[e] = p.px[e];
@@ -382,14 +380,14 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         }
     };
     // publish the four cells of a boundary-row group for the two fields of an exchange
-    auto publish = [&](const EcGroup &g, const int gq, int kind, unsigned epoch, int parity, const float4 &o0, const float4 &o1) {
+    auto publish = [&](const int lrw, const int gq, int kind, unsigned epoch, int parity, const float4 &o0, const float4 &o1) {
         unsigned long long *x = xw + (kind * 2 + parity) * xslot;
         const unsigned long long tag = (unsigned long long)epoch << 32;
         const float av[4] = {o0.x, o0.y, o0.z, o0.w}, bv[4] = {o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
         for (int sd = 0; sd < 2; ++sd) {
             // side 0 ("up"): my first two rows go to the upper neighbour; side 1: my last two rows
-            const int row = (sd == 0) ? g.lrw : g.lrw - (R - 2);
+            const int row = (sd == 0) ? lrw : lrw - (R - 2);
             if (row < 0 || row > 1) continue;
             if ((sd == 0 && w == 0) || (sd == 1 && w == p.NW - 1)) continue;
 #pragma unroll
@@ -403,22 +401,29 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     };
     // source term of step n for a group: fetched one step ahead (a global load in the update itself
     // would put a memory round trip on the workgroup's critical path every step)
-    auto source_amp = [&](EcGroup &g, int n) -> float {
+    auto source_amp = [&](const EcGroup &g, int q, int n) -> float4 {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
         if (!slow) {
-            const float a = g.amp;
-            if (g.src >= 0 && n + 1 < p.n_last)
-                g.amp = g.src_wt * p.f[((long long)(n + 1) * p.nshot + s) * p.nsrc + (g.src >> 2)];
-            return a;
+            if (tsrc >= 0 && ((tsrc >> 2) & 1) == q) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k == (tsrc & 3)) a[k] = tamp;
+                if (n + 1 < p.n_last)
+                    tamp = tsrc_wt * p.f[((long long)(n + 1) * p.nshot + s) * p.nsrc + (tsrc >> 3)];
+            }
+        } else if ((src_mask >> q) & 1) {   // several sources in this thread's cells: rescan the list every step
+            for (int e = 0; e < p.nsrc; ++e) {
+                const int cell = p.src_cell[(long long)s * p.nsrc + e];
+                if (cell < 0) continue;
+                const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
+                if (i0 != g.j || (i1 >> 2) != g.g) continue;
+                const float v = p.src_w[(long long)s * p.nsrc + e] * p.f[((long long)n * p.nshot + s) * p.nsrc + e];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k == (i1 & 3)) a[k] += v;
+            }
         }
-        float a = 0.f;                    // several taps in one group: they must share the component
-        for (int e = 0; e < p.nsrc; ++e) {
-            const int cell = p.src_cell[(long long)s * p.nsrc + e];
-            if (cell < 0) continue;
-            const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
-            if (g.own && i0 == g.j && (i1 >> 2) == g.g && (i1 & 3) == (g.src & 3))
-                a += p.src_w[(long long)s * p.nsrc + e] * p.f[((long long)n * p.nshot + s) * p.nsrc + e];
-        }
-        return a;
+        return make_float4(a[0], a[1], a[2], a[3]);
     };
 
     const int nsteps = p.n_last - p.n_first;
@@ -427,21 +432,22 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     // them time to retire before the next poll is issued (vector memory operations retire in order).
     auto do_v = [&](EcGroup &g, int n, int it, bool edge) {
         float4 S4, S5, o0, o1;
-        const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g);   // per-step opaque: addresses are recomputed, not hoisted
-        ec_update_v(g, c, lo, gq, S4, S5, o0, o1);
-        if (edge && do_x && !(p.dbg & 16)) publish(g, gq, 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
+        // per-step opaque: the addresses derived from these are recomputed, not hoisted out of the loop
+        const int gq = ec_opaque(g.g), jq = ec_opaque(g.j), lrw = jq - r0, lo = (lrw + 2) * PL + 4 + 4 * gq;
+        ec_update_v(g, c, lo, gq, lrw, S4, S5, o0, o1);
+        if (edge && do_x && !(p.dbg & 16)) publish(lrw, gq, 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
         if (SAVE && !(p.dbg & 2)) {
-            float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(ec_opaque(g.j) * p.gp + 4 * gq);
+            float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(jq * p.gp + 4 * gq);
             st4(Sn + 3 * (long long)ncell, S4); st4(Sn + 4 * (long long)ncell, S5);
         }
     };
-    auto do_s = [&](EcGroup &g, int n, int it, bool edge) {
+    auto do_s = [&](EcGroup &g, int q, int n, int it, bool edge) {
         float4 S1, S2, S3, o0, o1;
-        const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g);
-        ec_update_s(g, c, lo, gq, source_amp(g, n), S1, S2, S3, o0, o1);
-        if (edge && do_x && !(p.dbg & 16)) publish(g, gq, 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
+        const int gq = ec_opaque(g.g), jq = ec_opaque(g.j), lrw = jq - r0, lo = (lrw + 2) * PL + 4 + 4 * gq;
+        ec_update_s(g, c, lo, gq, lrw, source_amp(g, q, n), S1, S2, S3, o0, o1);
+        if (edge && do_x && !(p.dbg & 16)) publish(lrw, gq, 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
         if (SAVE && !(p.dbg & 2)) {
-            float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(ec_opaque(g.j) * p.gp + 4 * gq);
+            float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(jq * p.gp + 4 * gq);
             st4(Sn, S1); st4(Sn + (long long)ncell, S2); st4(Sn + 2 * (long long)ncell, S3);
         }
     };
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         // ---- S: interior rows, receive the velocity halo, boundary rows -----------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].inner) do_s(G[q], n, it, false);
+            if (G[q].inner) do_s(G[q], q, n, it, false);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (do_x && !(p.dbg & 32)) receive(0, (unsigned)(2 * it + 1), it & 1);
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         __syncthreads();                                   // C: velocity halo rows are in LDS
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].own && !G[q].inner) do_s(G[q], n, it, true);
+            if (G[q].own && !G[q].inner) do_s(G[q], q, n, it, true);
             __builtin_amdgcn_sched_barrier(0);
         }
         if ((it & 31) == 31 || it == nsteps - 1) {
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         if (!g.own) continue;
         const long long o = (long long)(g.j + 2) * p.pitch + 4 + 4 * g.g;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) st4(gf + k * p.field_stride + o, ld4(c.Lf[k] + g.lo));
+        for (int k = 0; k < 5; ++k) st4(gf + k * p.field_stride + o, ld4(c.Lf[k] + (g.j - r0 + 2) * PL + 4 + 4 * g.g));
         if (g.xs_off >= 0) {
             float *q2 = p.psix + (long long)s * p.psix_shot + (long long)g.j * p.wx + g.xs_off;
             st4(q2, g.s1); st4(q2 + xplane, g.s3); st4(q2 + 2 * xplane, g.s5); st4(q2 + 3 * xplane, g.s8);
@@ -525,6 +531,612 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         if (g.zs >= 0) {
             float *q2 = p.psiz + (long long)s * p.psiz_shot + (long long)g.zs * p.gp + 4 * g.g;
             st4(q2, g.s2); st4(q2 + zplane, g.s4); st4(q2 + 2 * zplane, g.s6); st4(q2 + 3 * zplane, g.s7);
+        }
+    }
+}
+
+// ================================================================================================
+// ADJOINT cluster kernel.  One launch runs adjoint steps n_first, n_first-1, ..., n_last.
+//   registers : the five adjoint fields of a thread's cells, the five gradient accumulators, the
+//               snapshot terms S1..S5 of the step (requested one phase group ahead)
+//   LDS       : four planes holding E1..E4 (S^T half) and then D1..D4 (V^T half) on the slab + 2 halo
+//               rows, the adjoint memory variables of the slab's C-PML cells, the C-PML tables
+//   hand-off  : E2,E3 after the pointwise phase A and D2,D4 after the pointwise phase C (the planes a
+//               z-stencil reads); both are functions of the owner's registers only, so they are
+//               published before any stencil runs and travel while the interior rows are updated.
+// Per step:  A (E, publish, grad_f) | B interior, receive E, B boundary | [receiver injection through
+// planes 0,1] | C (D, publish, gradients) | D interior, receive D, D boundary.
+// Arithmetic per cell = el_adj_s / el_adj_v.
+// ================================================================================================
+struct EaParams {
+    int nz, nx, ng, gp, pitch;
+    unsigned field_stride;
+    long long shot_stride;
+    int nshot, NW, PL, shot0, shot1;
+    int n_first, n_last;                 // steps n_first, n_first-1, ..., n_last
+    int nt;
+    int W, wl, xr0, wx, fsurf;
+    int zrows_max;                       // LDS rows reserved for the z-strip memory variables
+    long long psix_shot, psiz_shot, psix_elems;
+    const float *mat, *pz, *px;
+    float *fields;                       // adjoint fields, global state
+    float *psiA, *psiB;                  // ping-pong buffers of the per-step path (absolute in n)
+    const float *S;                      // snapshots of step n at S + (n - s_first) * s_step
+    int s_first;
+    long long s_step;
+    float *acc;                          // [nshot][5][nz][gp]
+    int nsrc, nrec;
+    const int *src_cell;
+    const float *src_w;
+    float *grad_f;                       // [nt][nshot][nsrc] or null
+    const int *rec_cell;
+    const float *rec_w, *g_vx, *g_vz;    // g [nt][nshot][nrec]
+    const int *slab_cnt, *slab_list;     // receivers per slab: [nshot][NW], [nshot][NW][nrec]
+    unsigned long long *xbuf;
+    int *err;
+    int dbg;
+};
+
+// receivers of each slab (adjoint sources), one block per shot
+__global__ void ec_build_slab_lists(const int *rec_cell, int nrec, int nz, int nx, int NW, int *slab_cnt,
+                                    int *slab_list)
+{
+    const int s = blockIdx.x;
+    __shared__ int cnt[64];
+    if ((int)threadIdx.x < NW) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = nz / NW, rem = nz - base * NW;
+    for (int e = threadIdx.x; e < nrec; e += blockDim.x) {
+        const int cell = rec_cell[(long long)s * nrec + e];
+        if (cell < 0) continue;
+        const int i0 = cell / nx;
+        const int w = (i0 < rem * (base + 1)) ? i0 / (base + 1) : rem + (i0 - rem * (base + 1)) / base;
+        const int pos = atomicAdd(&cnt[w], 1);
+        slab_list[((long long)s * NW + w) * nrec + pos] = e;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NW) slab_cnt[s * NW + threadIdx.x] = cnt[threadIdx.x];
+}
+
+struct EaGroup {
+    bool own, inner;
+    int lrw, g, j, lo;
+    int xsl, zsl;                                 // LDS float offset of the group's psi-bar slot, or -1
+    float4 bxx, bzz, bxz, vx, vz;                 // adjoint fields
+    float4 a0, a1, a2, a3, a4;                    // gradient accumulators (M_L, M_M, M_MU, M_BX, M_BZ order = index)
+    float4 S1, S2, S3, S4, S5;                    // snapshot terms of the current step
+    int src;                                      // (source index << 2) | cell, or -1
+    float src_wt;
+};
+
+template <int NG>
+__global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int L = (int)blockIdx.x;
+    const int xcd = L & 7, kq = L >> 3;
+    const int w = kq % p.NW, s = p.shot0 + xcd + 8 * (kq / p.NW);
+    if (s >= p.shot1) return;
+    const int t = (int)threadIdx.x;
+    int r0, R;
+    ec_slab_rows(p.nz, p.NW, w, r0, R);
+    const int PL = p.PL, LR = R + 4;
+    const int fsz = LR * PL;
+    float *pln = lds;                                         // 4 planes [LR][PL]
+    float *lpx = lds + 4 * fsz, *lpz = lpx + 6 * p.gp;        // C-PML tables: px [6][gp], pz [6][R]
+    float *lxs = lpz + 6 * ((R + 3) & ~3);                    // psi-bar of the x strips [4][R][wx]
+    float *lzs = lxs + 4 * R * p.wx;                          // psi-bar of the z strips [4][zrows][gp]
+    const unsigned ncell = (unsigned)p.nz * p.gp;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long xplane = (long long)p.nz * p.wx, zplane = 2LL * p.W * p.gp;
+    // z-strip rows of this slab: top rows [r0, ztop_end), bottom rows [zbot_beg, r0+R)
+    const int ztop_end = p.W > 0 ? min(r0 + R, p.W) : r0;
+    const int ntop = max(0, ztop_end - r0);
+    const int zbot_beg = p.W > 0 ? max(r0, p.nz - p.W) : r0 + R;
+    const int zrows = ntop + max(0, r0 + R - zbot_beg);
+    const int xsz = R * p.wx, zsz = zrows * p.gp;             // floats per memory variable
+
+    // the buffer the per-step path would READ at step n_first, and the one it would read next
+    const int par_in = (p.nt - 1 - p.n_first) & 1;
+    const float *psi_in = par_in ? p.psiB : p.psiA;
+    const int par_out = (p.nt - 1 - (p.n_last - 1)) & 1;
+    float *psi_out = par_out ? p.psiB : p.psiA;
+
+    EaGroup G[NG];
+    bool slow = false;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        EaGroup &g = G[q];
+        const int gi = t + q * kEcThreads;
+        g.own = gi < R * p.ng;
+        g.lrw = g.own ? gi / p.ng : 0;
+        g.g = g.own ? gi - g.lrw * p.ng : 0;
+        g.j = r0 + g.lrw;
+        g.lo = (g.lrw + 2) * PL + 4 + 4 * g.g;
+        g.inner = g.own && g.lrw >= 2 && g.lrw < R - 2;
+        g.bxx = g.bzz = g.bxz = g.vx = g.vz = zero4;
+        g.a0 = g.a1 = g.a2 = g.a3 = g.a4 = zero4;
+        g.S1 = g.S2 = g.S3 = g.S4 = g.S5 = zero4;
+        g.xsl = -1; g.zsl = -1; g.src = -1; g.src_wt = 0.f;
+        if (g.own) {
+            const unsigned gcc = (unsigned)g.j * p.gp + 4 * g.g;
+            const long long o = (long long)(g.j + 2) * p.pitch + 4 + 4 * g.g;
+            const float *gf = p.fields + (long long)s * p.shot_stride;
+            g.vx = ld4(gf + F_VX * p.field_stride + o); g.vz = ld4(gf + F_VZ * p.field_stride + o);
+            g.bxx = ld4(gf + F_SXX * p.field_stride + o); g.bzz = ld4(gf + F_SZZ * p.field_stride + o);
+            g.bxz = ld4(gf + F_SXZ * p.field_stride + o);
+            const float *ga = p.acc + (long long)s * 5 * ncell + gcc;
+            g.a0 = ld4(ga); g.a1 = ld4(ga + ncell); g.a2 = ld4(ga + 2 * (long long)ncell);
+            g.a3 = ld4(ga + 3 * (long long)ncell); g.a4 = ld4(ga + 4 * (long long)ncell);
+            if (p.W > 0) {
+                const int c0 = 4 * g.g;
+                int xs_off = -1, zs = -1;
+                if (c0 < p.wl) xs_off = c0; else if (c0 >= p.xr0) xs_off = p.wl + (c0 - p.xr0);
+                if (g.j < p.W) zs = g.j; else if (g.j >= p.nz - p.W) zs = g.j - (p.nz - 2 * p.W);
+                if (xs_off >= 0) {
+                    g.xsl = g.lrw * p.wx + xs_off;
+                    const float *qx = psi_in + (long long)s * p.psix_shot + (long long)g.j * p.wx + xs_off;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) st4(lxs + k * xsz + g.xsl, ld4(qx + k * xplane));
+                }
+                if (zs >= 0) {
+                    const int zl = (g.j < p.W) ? g.j - r0 : ntop + (g.j - zbot_beg);
+                    g.zsl = zl * p.gp + 4 * g.g;
+                    const float *qz = psi_in + p.psix_elems + (long long)s * p.psiz_shot + (long long)zs * p.gp + 4 * g.g;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) st4(lzs + k * zsz + g.zsl, ld4(qz + k * zplane));
+                }
+            }
+        }
+        if (p.grad_f != nullptr)
+            for (int e = 0; e < p.nsrc; ++e) {
+                const int cell = p.src_cell[(long long)s * p.nsrc + e];
+                if (cell < 0) continue;
+                const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
+                if (g.own && i0 == g.j && (i1 >> 2) == g.g) {
+                    if (g.src >= 0) slow = true;
+                    g.src = (e << 2) | (i1 & 3); g.src_wt = p.src_w[(long long)s * p.nsrc + e];
+                }
+            }
+    }
+    slow = __syncthreads_or(slow ? 1 : 0) != 0;
+    const bool zero_tap = p.grad_f != nullptr && w == 0 && t < p.nsrc && p.src_cell[(long long)s * p.nsrc + t] < 0;
+    // my receiver (adjoint source) of this slab: LDS offset inside a plane + weight; amplitudes are
+    // fetched one step ahead
+    const int cnt = p.slab_cnt[s * p.NW + w];
+    const bool inj_fast = cnt <= kEcThreads;
+    int inj_lo = -1, inj_id = 0;
+    float inj_w = 0.f, amp_x = 0.f, amp_z = 0.f;
+    if (inj_fast && t < cnt) {
+        inj_id = p.slab_list[((long long)s * p.NW + w) * p.nrec + t];
+        const int cell = p.rec_cell[(long long)s * p.nrec + inj_id];
+        const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
+        inj_lo = (i0 - r0 + 2) * PL + 4 + i1;
+        inj_w = p.rec_w[(long long)s * p.nrec + inj_id];
+    }
+
+    // ---- tables; planes zeroed once (halo rows/columns outside the grid stay zero) -----------------
+    for (int e = t; e < 6 * p.gp; e += kEcThreads) lpx[e] = p.px[e];
+    for (int e = t; e < 6 * R; e += kEcThreads) lpz[e] = p.pz[(e / R) * p.nz + r0 + (e % R)];
+    for (int e = t; e < fsz; e += kEcThreads) { pln[e] = 0.f; pln[fsz + e] = 0.f; pln[2 * fsz + e] = 0.f; pln[3 * fsz + e] = 0.f; }
+    __syncthreads();
+
+    // ---- hand-off assignments (as in the forward kernel) ------------------------------------------
+    constexpr int kGr = 5;
+    int rcv_lo[kGr];
+    unsigned rcv_meta = 0;               // per k: bit0 field, bit1 from-upper-neighbour
+#pragma unroll
+    for (int k = 0; k < kGr; ++k) {
+        const int e = t + k * kEcThreads;
+        rcv_lo[k] = -1;
+        if (e < 8 * p.gp) {
+            const int cq = e % p.gp, q = e / p.gp;
+            const int col = 4 * (cq % p.ng) + cq / p.ng;
+            const int row = q & 1, side = (q >> 1) & 1, fld = q >> 2;
+            if (cq < 4 * p.ng && !((side == 0 && w == 0) || (side == 1 && w == p.NW - 1))) {
+                rcv_lo[k] = ((side == 0) ? row : R + 2 + row) * PL + 4 + col;
+                rcv_meta |= (unsigned)(fld | (side == 0 ? 2 : 0)) << (2 * k);
+            }
+        }
+    }
+    const long long xslot = 8LL * p.gp;
+    unsigned long long *xw = p.xbuf + ((long long)s * p.NW + w) * 4 * xslot;
+    const bool do_x = p.NW > 1 && !(p.dbg & 1);
+    bool failed = false;
+    // kind 0: planes 1,2 (E2,E3); kind 1: planes 1,3 (D2,D4)
+    auto receive = [&](int kind, unsigned epoch, int parity) {
+        const unsigned long long *xu = xw - 4 * xslot + (kind * 2 + parity) * xslot;
+        const unsigned long long *xd = xw + 4 * xslot + (kind * 2 + parity) * xslot;
+        const unsigned long long *src[kGr];
+        unsigned long long v[kGr];
+#pragma unroll
+        for (int k = 0; k < kGr; ++k) {
+            const int e = t + k * kEcThreads;
+            src[k] = ((rcv_meta >> (2 * k)) & 2u) ? xu + (e + 2 * p.gp) : xd + (e - 2 * p.gp);
+            v[k] = 0;
+        }
+        for (unsigned spins = 0;; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < kGr; ++k)
+                if (rcv_lo[k] >= 0) v[k] = __hip_atomic_load(src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < kGr; ++k)
+                if (rcv_lo[k] >= 0) ok = ok && (unsigned)(v[k] >> 32) == epoch;
+            if (ok) break;
+            if (spins > kEcMaxSpin ||
+                ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                failed = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int k = 0; k < kGr; ++k) {
+            if (rcv_lo[k] < 0) continue;
+            const unsigned m = (rcv_meta >> (2 * k)) & 3u;
+            const int plane = (m & 1u) ? (kind == 0 ? 2 : 3) : 1;
+            pln[plane * fsz + rcv_lo[k]] = __uint_as_float((unsigned)v[k]);
+        }
+    };
+    auto publish = [&](const int lrw, const int gq, int kind, unsigned epoch, int parity, const float4 &o0,
+                       const float4 &o1) {
+        unsigned long long *x = xw + (kind * 2 + parity) * xslot;
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        const float av[4] = {o0.x, o0.y, o0.z, o0.w}, bv[4] = {o1.x, o1.y, o1.z, o1.w};
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            const int row = (sd == 0) ? lrw : lrw - (R - 2);
+            if (row < 0 || row > 1) continue;
+            if ((sd == 0 && w == 0) || (sd == 1 && w == p.NW - 1)) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __hip_atomic_store(x + (unsigned)ec_gran(p.gp, p.ng, 0, sd, row, gq, k), tag | __float_as_uint(av[k]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(x + (unsigned)ec_gran(p.gp, p.ng, 1, sd, row, gq, k), tag | __float_as_uint(bv[k]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    const long long sshot = (long long)s * 5 * ncell;
+    auto request_S = [&](EaGroup &g, int n) {
+        if (!g.own || (p.dbg & 2)) return;
+        const float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot +
+                          (unsigned)(ec_opaque(g.j) * p.gp + 4 * ec_opaque(g.g));
+        g.S1 = ld4(Sn); g.S2 = ld4(Sn + (long long)ncell); g.S3 = ld4(Sn + 2 * (long long)ncell);
+        g.S4 = ld4(Sn + 3 * (long long)ncell); g.S5 = ld4(Sn + 4 * (long long)ncell);
+    };
+    auto request_amp = [&](int n) {
+        if (inj_lo >= 0 && n >= p.n_last) {
+            const long long o = ((long long)n * p.nshot + s) * p.nrec;
+            amp_x = (p.g_vx + o)[ec_opaque(inj_id)];
+            amp_z = (p.g_vz + o)[ec_opaque(inj_id)];
+        }
+    };
+
+    // ---- phase bodies ----------------------------------------------------------------------------------
+    // A: E from the owner's sigma-bar through the transposed C-PML -> planes; boundary rows publish E2,E3
+    auto phase_a = [&](EaGroup &g, int n, int it) {
+        const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g), jq = ec_opaque(g.j);
+        const unsigned gcc = (unsigned)(jq * p.gp + 4 * gq);
+        const float4 Ls = ld4(p.mat + M_L * ncell + gcc), Ms = ld4(p.mat + M_M * ncell + gcc);
+        const float4 mus = ld4(p.mat + M_MU * ncell + gcc);
+        float4 bzz = g.bzz;
+        if (p.fsurf && jq == 0) bzz = zero4;              // adjoint of szz(0,.) is discarded
+        if (p.grad_f != nullptr && g.src >= 0) {
+            float *out = p.grad_f + ((long long)n * p.nshot + s) * p.nsrc;
+            if (!slow) {
+                const int c = g.src & 3;
+                out[g.src >> 2] = fmaf(g.src_wt, comp(g.bxx, c) + comp(bzz, c), 0.f);
+            } else {                                      // several sources in this group: rescan
+                for (int e = 0; e < p.nsrc; ++e) {
+                    const int cell = p.src_cell[(long long)s * p.nsrc + e];
+                    if (cell < 0) continue;
+                    const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
+                    if (i0 == jq && (i1 >> 2) == gq)
+                        out[e] = fmaf(p.src_w[(long long)s * p.nsrc + e], comp(g.bxx, i1 & 3) + comp(bzz, i1 & 3), 0.f);
+                }
+            }
+        }
+        float e1[4], e2[4], e3[4], e4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            e1[c] = fmaf(comp(Ms, c), comp(g.bxx, c), comp(Ls, c) * comp(bzz, c));
+            e2[c] = fmaf(comp(Ls, c), comp(g.bxx, c), comp(Ms, c) * comp(bzz, c));
+            e3[c] = comp(mus, c) * comp(g.bxz, c);
+            e4[c] = e3[c];
+        }
+        if (g.xsl >= 0) {
+            const float *q = lpx + 4 * gq;
+            const float4 pa = ld4(q + PA * p.gp), pb = ld4(q + PB * p.gp), pk = ld4(q + PK * p.gp);
+            const float4 pah = ld4(q + PAH * p.gp), pbh = ld4(q + PBH * p.gp), pkh = ld4(q + PKH * p.gp);
+            float *sl = lxs + ec_opaque(g.xsl);
+            const float4 s5 = ld4(sl + 2 * xsz), s8 = ld4(sl + 3 * xsz);
+            float n5[4], n8[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                e1[c] = pmlT(comp(s5, c), comp(pa, c), comp(pb, c), comp(pk, c), e1[c], n5[c]);
+                e4[c] = pmlT(comp(s8, c), comp(pah, c), comp(pbh, c), comp(pkh, c), e4[c], n8[c]);
+            }
+            st4(sl + 2 * xsz, make_float4(n5[0], n5[1], n5[2], n5[3]));
+            st4(sl + 3 * xsz, make_float4(n8[0], n8[1], n8[2], n8[3]));
+        }
+        if (g.zsl >= 0) {
+            const float *z = lpz + (jq - r0);
+            const float za = z[PA * R], zb = z[PB * R], zk = z[PK * R];
+            const float zah = z[PAH * R], zbh = z[PBH * R], zkh = z[PKH * R];
+            float *sl = lzs + ec_opaque(g.zsl);
+            const float4 s6 = ld4(sl + 2 * zsz), s7 = ld4(sl + 3 * zsz);
+            float n6[4], n7[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                e2[c] = pmlT(comp(s6, c), za, zb, zk, e2[c], n6[c]);
+                e3[c] = pmlT(comp(s7, c), zah, zbh, zkh, e3[c], n7[c]);
+            }
+            st4(sl + 2 * zsz, make_float4(n6[0], n6[1], n6[2], n6[3]));
+            st4(sl + 3 * zsz, make_float4(n7[0], n7[1], n7[2], n7[3]));
+        }
+        const float4 E2 = make_float4(e2[0], e2[1], e2[2], e2[3]), E3 = make_float4(e3[0], e3[1], e3[2], e3[3]);
+        st4(pln + lo, make_float4(e1[0], e1[1], e1[2], e1[3]));
+        st4(pln + fsz + lo, E2);
+        st4(pln + 2 * fsz + lo, E3);
+        st4(pln + 3 * fsz + lo, make_float4(e4[0], e4[1], e4[2], e4[3]));
+        if (do_x && !g.inner) publish(jq - r0, gq, 0, (unsigned)(2 * it + 1), it & 1, E2, E3);
+    };
+    // B: v_bar -= stencils(E)
+    auto phase_b = [&](EaGroup &g) {
+        const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g);
+        const float *E1 = pln + lo, *E2 = pln + fsz + lo, *E3 = pln + 2 * fsz + lo, *E4 = pln + 3 * fsz + lo;
+        const float4 c1 = ld4(E1);
+        const float2 L1 = ld2(E1 - 2), R1 = ld2(E1 + 4);
+        const float4 c4 = ld4(E4);
+        const float2 L4 = ld2(E4 - 2), R4 = ld2(E4 + 4);
+        const float4 t0 = ld4(E3 - 2 * PL), t1 = ld4(E3 - PL), t2 = ld4(E3), t3 = ld4(E3 + PL);
+        const float4 u0 = ld4(E2 - PL), u1 = ld4(E2), u2 = ld4(E2 + PL), u3 = ld4(E2 + 2 * PL);
+        const float x1[8] = {L1.x, L1.y, c1.x, c1.y, c1.z, c1.w, R1.x, R1.y};
+        const float x4[8] = {L4.x, L4.y, c4.x, c4.y, c4.z, c4.w, R4.x, R4.y};
+        float nvx[4], nvz[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float dx1 = dfw(x1[c + 1], x1[c + 2], x1[c + 3], x1[c + 4]);
+            const float dz3 = dbw(comp(t0, c), comp(t1, c), comp(t2, c), comp(t3, c));
+            const float dz2 = dfw(comp(u0, c), comp(u1, c), comp(u2, c), comp(u3, c));
+            const float dx4 = dbw(x4[c], x4[c + 1], x4[c + 2], x4[c + 3]);
+            nvx[c] = comp(g.vx, c) - (dx1 + dz3);
+            nvz[c] = comp(g.vz, c) - (dz2 + dx4);
+            if (4 * gq + c >= p.nx) { nvx[c] = 0.f; nvz[c] = 0.f; }
+        }
+        g.vx = make_float4(nvx[0], nvx[1], nvx[2], nvx[3]);
+        g.vz = make_float4(nvz[0], nvz[1], nvz[2], nvz[3]);
+    };
+    // C: D from the new v_bar -> planes; boundary rows publish D2,D4; all five gradient accumulators
+    auto phase_c = [&](EaGroup &g, int it) {
+        const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g), jq = ec_opaque(g.j);
+        const unsigned gcc = (unsigned)(jq * p.gp + 4 * gq);
+        const float4 bxs = ld4(p.mat + M_BX * ncell + gcc), bzs = ld4(p.mat + M_BZ * ncell + gcc);
+        float d1[4], d2[4], d3[4], d4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            d1[c] = comp(bxs, c) * comp(g.vx, c); d2[c] = d1[c];
+            d3[c] = comp(bzs, c) * comp(g.vz, c); d4[c] = d3[c];
+        }
+        if (g.xsl >= 0) {
+            const float *q = lpx + 4 * gq;
+            const float4 pa = ld4(q + PA * p.gp), pb = ld4(q + PB * p.gp), pk = ld4(q + PK * p.gp);
+            const float4 pah = ld4(q + PAH * p.gp), pbh = ld4(q + PBH * p.gp), pkh = ld4(q + PKH * p.gp);
+            float *sl = lxs + ec_opaque(g.xsl);
+            const float4 s1 = ld4(sl), s3 = ld4(sl + xsz);
+            float n1[4], n3[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                d1[c] = pmlT(comp(s1, c), comp(pah, c), comp(pbh, c), comp(pkh, c), d1[c], n1[c]);
+                d3[c] = pmlT(comp(s3, c), comp(pa, c), comp(pb, c), comp(pk, c), d3[c], n3[c]);
+            }
+            st4(sl, make_float4(n1[0], n1[1], n1[2], n1[3]));
+            st4(sl + xsz, make_float4(n3[0], n3[1], n3[2], n3[3]));
+        }
+        if (g.zsl >= 0) {
+            const float *z = lpz + (jq - r0);
+            const float za = z[PA * R], zb = z[PB * R], zk = z[PK * R];
+            const float zah = z[PAH * R], zbh = z[PBH * R], zkh = z[PKH * R];
+            float *sl = lzs + ec_opaque(g.zsl);
+            const float4 s2 = ld4(sl), s4 = ld4(sl + zsz);
+            float n2[4], n4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                d2[c] = pmlT(comp(s2, c), za, zb, zk, d2[c], n2[c]);
+                d4[c] = pmlT(comp(s4, c), zah, zbh, zkh, d4[c], n4[c]);
+            }
+            st4(sl, make_float4(n2[0], n2[1], n2[2], n2[3]));
+            st4(sl + zsz, make_float4(n4[0], n4[1], n4[2], n4[3]));
+        }
+        const float4 D2 = make_float4(d2[0], d2[1], d2[2], d2[3]), D4 = make_float4(d4[0], d4[1], d4[2], d4[3]);
+        st4(pln + lo, make_float4(d1[0], d1[1], d1[2], d1[3]));
+        st4(pln + fsz + lo, D2);
+        st4(pln + 2 * fsz + lo, make_float4(d3[0], d3[1], d3[2], d3[3]));
+        st4(pln + 3 * fsz + lo, D4);
+        if (do_x && !g.inner) publish(jq - r0, gq, 1, (unsigned)(2 * it + 2), it & 1, D2, D4);
+        // gradients (oracle order): Ms, Ls, mus from the old sigma_bar; bxs, bzs from the new v_bar
+        float4 bzz = g.bzz;
+        if (p.fsurf && jq == 0) bzz = zero4;
+#define EA_ACC3(dst, a, b, c_, d) dst = fmaf(a, b, fmaf(c_, d, dst))
+        EA_ACC3(g.a1.x, g.S1.x, g.bxx.x, g.S2.x, bzz.x); EA_ACC3(g.a1.y, g.S1.y, g.bxx.y, g.S2.y, bzz.y);
+        EA_ACC3(g.a1.z, g.S1.z, g.bxx.z, g.S2.z, bzz.z); EA_ACC3(g.a1.w, g.S1.w, g.bxx.w, g.S2.w, bzz.w);
+        EA_ACC3(g.a0.x, g.S2.x, g.bxx.x, g.S1.x, bzz.x); EA_ACC3(g.a0.y, g.S2.y, g.bxx.y, g.S1.y, bzz.y);
+        EA_ACC3(g.a0.z, g.S2.z, g.bxx.z, g.S1.z, bzz.z); EA_ACC3(g.a0.w, g.S2.w, g.bxx.w, g.S1.w, bzz.w);
+#undef EA_ACC3
+        g.a2.x = fmaf(g.S3.x, g.bxz.x, g.a2.x); g.a2.y = fmaf(g.S3.y, g.bxz.y, g.a2.y);
+        g.a2.z = fmaf(g.S3.z, g.bxz.z, g.a2.z); g.a2.w = fmaf(g.S3.w, g.bxz.w, g.a2.w);
+        g.a3.x = fmaf(g.S4.x, g.vx.x, g.a3.x); g.a3.y = fmaf(g.S4.y, g.vx.y, g.a3.y);
+        g.a3.z = fmaf(g.S4.z, g.vx.z, g.a3.z); g.a3.w = fmaf(g.S4.w, g.vx.w, g.a3.w);
+        g.a4.x = fmaf(g.S5.x, g.vz.x, g.a4.x); g.a4.y = fmaf(g.S5.y, g.vz.y, g.a4.y);
+        g.a4.z = fmaf(g.S5.z, g.vz.z, g.a4.z); g.a4.w = fmaf(g.S5.w, g.vz.w, g.a4.w);
+    };
+    // D: sigma_bar -= stencils(D) (+ transposed free-surface mirroring on grid rows 0 and 1)
+    auto phase_d = [&](EaGroup &g) {
+        const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g), jq = ec_opaque(g.j);
+        const float *D1 = pln + lo, *D2 = pln + fsz + lo, *D3 = pln + 2 * fsz + lo, *D4 = pln + 3 * fsz + lo;
+        const float4 c1 = ld4(D1);
+        const float2 L1 = ld2(D1 - 2), R1 = ld2(D1 + 4);
+        const float4 c3 = ld4(D3);
+        const float2 L3 = ld2(D3 - 2), R3 = ld2(D3 + 4);
+        const float4 u0 = ld4(D2 - PL), u1 = ld4(D2), u2 = ld4(D2 + PL), u3 = ld4(D2 + 2 * PL);
+        const float4 t0 = ld4(D4 - 2 * PL), t1 = ld4(D4 - PL), t2 = ld4(D4), t3 = ld4(D4 + PL);
+        const float x1[8] = {L1.x, L1.y, c1.x, c1.y, c1.z, c1.w, R1.x, R1.y};
+        const float x3[8] = {L3.x, L3.y, c3.x, c3.y, c3.z, c3.w, R3.x, R3.y};
+        float nxx[4], nzz[4], nxz[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float dx1 = dbw(x1[c], x1[c + 1], x1[c + 2], x1[c + 3]);
+            const float dz2 = dfw(comp(u0, c), comp(u1, c), comp(u2, c), comp(u3, c));
+            const float dx3 = dfw(x3[c + 1], x3[c + 2], x3[c + 3], x3[c + 4]);
+            const float dz4 = dbw(comp(t0, c), comp(t1, c), comp(t2, c), comp(t3, c));
+            nxx[c] = comp(g.bxx, c) - dx1;
+            nxz[c] = comp(g.bxz, c) - (dz2 + dx3);
+            nzz[c] = comp(g.bzz, c) - dz4;
+        }
+        if (p.fsurf && jq < 2) {
+            // grid rows 0 and 1 are local rows 2 and 3 of slab 0
+            const float4 r0d2 = ld4(pln + fsz + 2 * PL + 4 + 4 * gq), r1d2 = ld4(pln + fsz + 3 * PL + 4 + 4 * gq);
+            const float4 r0d4 = ld4(pln + 3 * fsz + 2 * PL + 4 + 4 * gq);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (jq == 0) nxz[c] = nxz[c] + fmaf(C1, comp(r0d2, c), C2 * comp(r1d2, c));
+                else { nxz[c] = nxz[c] + C2 * comp(r0d2, c); nzz[c] = nzz[c] + C2 * comp(r0d4, c); }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (4 * gq + c >= p.nx) { nxx[c] = 0.f; nxz[c] = 0.f; nzz[c] = 0.f; }
+        g.bxx = make_float4(nxx[0], nxx[1], nxx[2], nxx[3]);
+        g.bzz = make_float4(nzz[0], nzz[1], nzz[2], nzz[3]);
+        g.bxz = make_float4(nxz[0], nxz[1], nxz[2], nxz[3]);
+    };
+
+    const int nsteps = p.n_first - p.n_last + 1;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) request_S(G[q], p.n_first);
+    request_amp(p.n_first);
+    for (int it = 0; it < nsteps; ++it) {
+        const int n = p.n_first - it;
+        // ---- A ----------------------------------------------------------------------------------------
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (G[q].own) phase_a(G[q], n, it);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (p.grad_f != nullptr && w == 0) {               // inactive source taps: slab 0 writes their zeros
+            if (zero_tap) (p.grad_f + ((long long)n * p.nshot + s) * p.nsrc)[t] = 0.f;
+            for (int e = t + kEcThreads; e < p.nsrc; e += kEcThreads)
+                if (p.src_cell[(long long)s * p.nsrc + e] < 0) p.grad_f[((long long)n * p.nshot + s) * p.nsrc + e] = 0.f;
+        }
+        __syncthreads();                                   // 1: E planes complete on the own rows
+        // ---- B ----------------------------------------------------------------------------------------
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (G[q].inner) phase_b(G[q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (do_x) receive(0, (unsigned)(2 * it + 1), it & 1);
+        __syncthreads();                                   // 2: E halo rows are in LDS
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (G[q].own && !G[q].inner) phase_b(G[q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                   // 3: every read of E is done
+        // ---- receivers of this slab: v_bar += w g, through planes 0 and 1 ---------------------------
+        if (cnt > 0) {
+#pragma unroll
+            for (int q = 0; q < NG; ++q)
+                if (G[q].own) { st4(pln + ec_opaque(G[q].lo), zero4); st4(pln + fsz + ec_opaque(G[q].lo), zero4); }
+            __syncthreads();
+            if (inj_fast) {
+                if (inj_lo >= 0) {
+                    atomicAdd(pln + ec_opaque(inj_lo), inj_w * amp_x);
+                    atomicAdd(pln + fsz + ec_opaque(inj_lo), inj_w * amp_z);
+                }
+            } else {
+                const int *lst = p.slab_list + ((long long)s * p.NW + w) * p.nrec;
+                for (int e = t; e < cnt; e += kEcThreads) {
+                    const int id = lst[e];
+                    const int cell = p.rec_cell[(long long)s * p.nrec + id];
+                    const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
+                    const float ww = p.rec_w[(long long)s * p.nrec + id];
+                    const long long o = ((long long)n * p.nshot + s) * p.nrec + id;
+                    atomicAdd(pln + (i0 - r0 + 2) * PL + 4 + i1, ww * p.g_vx[o]);
+                    atomicAdd(pln + fsz + (i0 - r0 + 2) * PL + 4 + i1, ww * p.g_vz[o]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NG; ++q)
+                if (G[q].own) {
+                    const float4 ix = ld4(pln + ec_opaque(G[q].lo)), iz = ld4(pln + fsz + ec_opaque(G[q].lo));
+                    G[q].vx = make_float4(G[q].vx.x + ix.x, G[q].vx.y + ix.y, G[q].vx.z + ix.z, G[q].vx.w + ix.w);
+                    G[q].vz = make_float4(G[q].vz.x + iz.x, G[q].vz.y + iz.y, G[q].vz.z + iz.z, G[q].vz.w + iz.w);
+                }
+            request_amp(n - 1);
+        }
+        // ---- C ----------------------------------------------------------------------------------------
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (G[q].own) phase_c(G[q], it);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                   // 4: D planes complete on the own rows
+        // ---- D ----------------------------------------------------------------------------------------
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (G[q].inner) phase_d(G[q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (do_x) receive(1, (unsigned)(2 * it + 2), it & 1);
+        if (it + 1 < nsteps) {
+#pragma unroll
+            for (int q = 0; q < NG; ++q) request_S(G[q], n - 1);      // after the poll: loads retire in order
+        }
+        __syncthreads();                                   // 5: D halo rows are in LDS
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (G[q].own && !G[q].inner) phase_d(G[q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((it & 31) == 31 || it == nsteps - 1) {
+            if (__syncthreads_or(failed ? 1 : 0)) {        // 6 (+ collective time-out check)
+                if (t == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        } else {
+            __syncthreads();                               // 6: every read of D is done
+        }
+    }
+
+    // ---- state back to the layout of the per-step path ------------------------------------------------
+    float *gf = p.fields + (long long)s * p.shot_stride;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const EaGroup &g = G[q];
+        if (!g.own) continue;
+        const long long o = (long long)(g.j + 2) * p.pitch + 4 + 4 * g.g;
+        st4(gf + F_VX * p.field_stride + o, g.vx); st4(gf + F_VZ * p.field_stride + o, g.vz);
+        st4(gf + F_SXX * p.field_stride + o, g.bxx); st4(gf + F_SZZ * p.field_stride + o, g.bzz);
+        st4(gf + F_SXZ * p.field_stride + o, g.bxz);
+        const unsigned gcc = (unsigned)g.j * p.gp + 4 * g.g;
+        float *ga = p.acc + (long long)s * 5 * ncell + gcc;
+        st4(ga, g.a0); st4(ga + ncell, g.a1); st4(ga + 2 * (long long)ncell, g.a2);
+        st4(ga + 3 * (long long)ncell, g.a3); st4(ga + 4 * (long long)ncell, g.a4);
+        if (g.xsl >= 0) {
+            const int xs_off = g.xsl - g.lrw * p.wx;
+            float *qx = psi_out + (long long)s * p.psix_shot + (long long)g.j * p.wx + xs_off;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) st4(qx + k * xplane, ld4(lxs + k * xsz + g.xsl));
+        }
+        if (g.zsl >= 0) {
+            const int zs = (g.j < p.W) ? g.j : g.j - (p.nz - 2 * p.W);
+            float *qz = psi_out + p.psix_elems + (long long)s * p.psiz_shot + (long long)zs * p.gp + 4 * g.g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) st4(qz + k * zplane, ld4(lzs + k * zsz + g.zsl));
         }
     }
 }

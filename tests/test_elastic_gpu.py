@@ -69,9 +69,25 @@ def test_cluster_path_with_halo_handoff(oracle32, monkeypatch, nw, fs):
     """Force the LDS-resident cluster kernel to cut a shot into several row slabs so that the
     velocity/stress granule hand-off between workgroups is exercised: traces stay bitwise equal
     to the oracle and the snapshot stream (checked through the gradients) is unchanged."""
-    monkeypatch.setenv("MIFWI_EL_NW", str(nw))
+    monkeypatch.setenv("MIFWI_EL_NW", str(nw))          # forward and adjoint kernels alike
     case = elastic_case(seed=23, nz=61, nx=83, fw=8, ns=3, nrec=15, nt=120, free_surface=fs)
     _check_parity(oracle32, case, bitwise=True)
+
+
+def test_cluster_adjoint_receivers_everywhere(oracle32, monkeypatch):
+    """Receivers in several slabs and several per 4-cell group; two sources in one group."""
+    monkeypatch.setenv("MIFWI_EL_NW", "4")
+    case = elastic_case(seed=31, nz=48, nx=64, fw=6, ns=2, nsrc=2, nrec=64, nt=90)
+    nz, nx = 48, 64
+    rng = np.random.default_rng(5)
+    rc = rng.choice(nz * nx, size=(2, 64), replace=False).astype(np.int32)
+    rc[:, :8] = (7 * nx + 20 + np.arange(8)).astype(np.int32)      # a run of neighbours on one row
+    case["rc"] = rc.reshape(case["rc"].shape)
+    sc = case["sc"].copy().reshape(2, 2)
+    sc[:, 0] = 9 * nx + 30
+    sc[:, 1] = 9 * nx + 31                                           # same group as the first source
+    case["sc"] = sc.reshape(case["sc"].shape)
+    _check_parity(oracle32, case)
 
 
 def test_cluster_and_per_step_paths_agree(monkeypatch):
@@ -79,6 +95,7 @@ def test_cluster_and_per_step_paths_agree(monkeypatch):
     outs = []
     for flag in ("1", "0"):
         monkeypatch.setenv("MIFWI_EL_CLUSTER", flag)
+        monkeypatch.setenv("MIFWI_EL_CLUSTER_ADJ", flag)
         mat, f, rvx, rvz = _run_hip(case)
         torch.autograd.backward([rvx, rvz], [torch.sign(rvx.detach()), torch.sign(rvz.detach())])
         outs.append((rvx.detach().clone(), rvz.detach().clone(), mat.grad.clone(), f.grad.clone()))
