@@ -23,6 +23,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def sized_cpu_sample(run, nt0, nt_full, budget_s, bytes_per_step, mem_cap=6e9):
+    """Time `run(nt)` on a sample sized to about `budget_s` seconds of CPU work: calibrate on nt0
+    steps, then repeat a pass of up to the full step count (capped by snapshot memory) until the
+    budget is used.  Returns (steps per pass, passes, seconds)."""
+    el0 = run(nt0)
+    nt = int(nt0 * budget_s / max(el0, 1e-3))
+    nt = max(nt0, min(nt, nt_full, int(mem_cap / bytes_per_step)))
+    reps = max(1, min(200, int(round(budget_s / max(el0 * nt / nt0, 1e-3)))))
+    el = 0.0
+    for _ in range(reps):
+        el += run(nt)
+    return nt, reps, el
+
+
 def synth_vp(nz, nx, seed, water_rows=26):
     """1500 + 2500 z/nz + Gaussian-smoothed (sigma=5) N(0,150^2), clipped to
     [1500,4500], water layer on top."""
@@ -106,8 +120,9 @@ class AcousticMarmousi:
         tb = np.mean([e[2].elapsed_time(e[3]) for e in self._ev]) * 1e-3
         return tf / self.nt, tb / max(1, self.nt - 1)
 
-    def cpu_baseline(self, budget_s=20.0):
-        """The C oracle (scalar port, OpenMP over shots) on a bounded sample of this workload."""
+    def cpu_baseline(self, budget_s=15.0):
+        """The C oracle (scalar port, OpenMP over shots) on a bounded sample of this workload:
+        a short calibration run sizes the sample to about `budget_s` seconds of CPU work."""
         import oracle
         from oracle import helpers as H
         o = oracle.load("f32")
@@ -119,21 +134,24 @@ class AcousticMarmousi:
         q0 = H.damp_profile_1d(N0, P, h) * h * h / (2 * dt)
         q1 = H.damp_profile_1d(N1, P, h) * h * h / (2 * dt)
         ns = min(self.ns, cores)
-        nt = 200
-        f = np.zeros((nt, ns, 1), dtype=np.float32)
-        f[:, :, 0] = (H.ricker_deepwave(self.freq, nt, dt, 1.0 / self.freq) * h * h)[:, None]
         sc, sw = H.cell_taps(np.full((ns, 1), P), (np.linspace(0, self.nx - 1, ns)[:, None]
                                                    .astype(int) + P), N1)
         rc, rw = H.cell_taps(np.full((ns, self.nx), P), np.arange(self.nx)[None, :]
                              .repeat(ns, 0) + P, N1)
-        t0 = time.time()
-        rec, G = o.acoustic_forward(r, q0, q1, f, sc, sw, rc, rw, save=True)
-        o.acoustic_backward(r, q0, q1, sc, sw, rc, rw, rec, G)
-        el = time.time() - t0
-        return {"value": self.nz * self.nx * nt * ns / el / 1e6, "unit": "Mcells*steps/s",
-                "cores": cores, "kind": "port",
-                "sample": "%d shots x %d steps of this workload, forward+adjoint, C oracle "
-                          "(oracle/acoustic.c, OpenMP over shots), %.1f s" % (ns, nt, el)}
+
+        def run(nt):
+            f = np.zeros((nt, ns, 1), dtype=np.float32)
+            f[:, :, 0] = (H.ricker_deepwave(self.freq, nt, dt, 1.0 / self.freq) * h * h)[:, None]
+            t0 = time.time()
+            rec, G = o.acoustic_forward(r, q0, q1, f, sc, sw, rc, rw, save=True)
+            o.acoustic_backward(r, q0, q1, sc, sw, rc, rw, rec, G)
+            return time.time() - t0
+
+        nt, reps, el = sized_cpu_sample(run, 100, self.nt, budget_s, bytes_per_step=4.0 * N0 * N1 * ns)
+        return {"value": self.nz * self.nx * nt * ns * reps / el / 1e6, "unit": "Mcells*steps/s",
+                "cores": min(cores, ns), "kind": "port",
+                "sample": "%d passes of %d shots x %d steps of this workload, forward+adjoint, C oracle "
+                          "(oracle/acoustic.c, OpenMP over shots), %.1f s" % (reps, ns, nt, el)}
 
 
 def synth_elastic(nz, nx, seed, water_rows=26):
@@ -156,7 +174,7 @@ class ElasticMarmousi:
     nz, nx, h, dt, nt, freq = 100, 300, 20.0, 0.002, 3000, 5.0
     shots_per_gpu = 32
     pml = 10
-    fwd_bytes, adj_bytes = 80.0, 80.0    # two-launch forward 80 B, adjoint 80 B
+    fwd_bytes, adj_bytes = 60.0, 80.0    # fused forward 60 B, adjoint + correlation 80 B
 
     def __init__(self, dev, rank, world, nt=None, shots=None, grid=None):
         import torch
@@ -231,7 +249,7 @@ class ElasticMarmousi:
         tb = np.mean([e[2].elapsed_time(e[3]) for e in self._ev]) * 1e-3
         return tf / self.nt, tb / self.nt
 
-    def cpu_baseline(self, budget_s=20.0):
+    def cpu_baseline(self, budget_s=15.0):
         import oracle
         from oracle import helpers as H
         o = oracle.load("f32")
@@ -240,20 +258,24 @@ class ElasticMarmousi:
         mat = H.elastic_materials(vp, vs, rho, self.dt, self.h)
         pz = H.cpml_profiles(self.nz, self.pml, self.h, self.dt, 1500.0, 5.0)
         px = H.cpml_profiles(self.nx, self.pml, self.h, self.dt, 1500.0, 5.0)
-        ns, nt = min(self.ns, cores), 100
-        f = np.zeros((nt, ns, 1), dtype=np.float32)
-        f[:, :, 0] = (H.ricker_deepwave(self.freq, nt, self.dt, 1.0 / self.freq) * 1e6)[:, None]
+        ns = min(self.ns, cores)
         sc = self.sc.numpy()[:ns]
         rc = self.rc.numpy()[:ns]
-        t0 = time.time()
-        vx, vz, S = o.elastic_forward(mat, pz, px, f, sc, np.ones(sc.shape), rc, np.ones(rc.shape),
-                                      save=True)
-        o.elastic_backward(mat, pz, px, sc, np.ones(sc.shape), rc, np.ones(rc.shape), vx, vz, S)
-        el = time.time() - t0
-        return {"value": self.nz * self.nx * nt * ns / el / 1e6, "unit": "Mcells*steps/s",
-                "cores": cores, "kind": "port",
-                "sample": "%d shots x %d steps of this workload, forward+adjoint, C oracle "
-                          "(oracle/elastic.c, OpenMP over shots), %.1f s" % (ns, nt, el)}
+
+        def run(nt):
+            f = np.zeros((nt, ns, 1), dtype=np.float32)
+            f[:, :, 0] = (H.ricker_deepwave(self.freq, nt, self.dt, 1.0 / self.freq) * 1e6)[:, None]
+            t0 = time.time()
+            vx, vz, S = o.elastic_forward(mat, pz, px, f, sc, np.ones(sc.shape), rc, np.ones(rc.shape),
+                                          save=True)
+            o.elastic_backward(mat, pz, px, sc, np.ones(sc.shape), rc, np.ones(rc.shape), vx, vz, S)
+            return time.time() - t0
+
+        nt, reps, el = sized_cpu_sample(run, 50, self.nt, budget_s, bytes_per_step=20.0 * self.nz * self.nx * ns)
+        return {"value": self.nz * self.nx * nt * ns * reps / el / 1e6, "unit": "Mcells*steps/s",
+                "cores": min(cores, ns), "kind": "port",
+                "sample": "%d passes of %d shots x %d steps of this workload, forward+adjoint, C oracle "
+                          "(oracle/elastic.c, OpenMP over shots), %.1f s" % (reps, ns, nt, el)}
 
 
 class ElasticSEAM(ElasticMarmousi):
@@ -266,6 +288,22 @@ class ElasticSEAM(ElasticMarmousi):
 
 WORKLOADS = {"acoustic_marmousi": AcousticMarmousi, "elastic_marmousi": ElasticMarmousi,
              "elastic_seam": ElasticSEAM}
+
+
+def measured_traffic(workload, kernel, cells):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json, written by tools/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes), normalised like `achieved` to one time step of all shots.
+    None when no PMC summary exists for this workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh).get(workload, {}).get(kernel)
+    except (OSError, ValueError):
+        return None
+    if not rec:
+        return None
+    return rec["bytes_per_cell_step"] * cells
 
 
 def run_workload(name, args, dev, rank, world, want_cpu):
@@ -312,6 +350,7 @@ def run_workload(name, args, dev, rank, world, want_cpu):
                             "achieved_GBs": wl.adj_bytes * cells / t_b / 1e9},
     }
     dom = "adjoint+imaging" if t_b >= t_f else "forward+save"
+    traffic = measured_traffic(wl.name, dom, cells)
     out = {
         "metric": "grid-cells*timesteps/sec (forward+adjoint gradient pass)",
         "value": value, "unit": "Mcells*steps/s", "n_gpus": world, "steps": args.steps,
@@ -323,7 +362,7 @@ def run_workload(name, args, dev, rank, world, want_cpu):
         "roofline": {"bound": "hbm", "kernel": dom,
                      "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS,
-                     "traffic": None},
+                     "traffic": traffic},
         "kernels": kern,
     }
     if want_cpu:
