@@ -61,7 +61,8 @@ class AcousticMarmousi:
     def __init__(self, dev, rank, world, nt=None, shots=None):
         import torch
         import physicsbasedfwi2_amd.compat.deepwave as deepwave
-        self.torch, self.deepwave, self.dev = torch, deepwave, dev
+        from physicsbasedfwi2_amd import misfit
+        self.torch, self.deepwave, self.dev, self.misfit = torch, deepwave, dev, misfit
         if nt:
             self.nt = nt
         ns = shots or self.shots_per_gpu
@@ -103,8 +104,7 @@ class AcousticMarmousi:
         ev[0].record()
         rec = prop(self.wav, self.x_s, self.x_r, self.dt)
         ev[1].record()
-        pmax, _ = rec.abs().max(dim=0, keepdim=True)
-        loss = torch.nn.functional.l1_loss(rec / (pmax + 1e-10), self.obs)
+        loss = self.misfit.l1_trace_normalized(rec, self.obs)     # fused HIP misfit + adjoint source
         (grec,) = torch.autograd.grad(loss, rec, retain_graph=True)
         ev[2].record()
         rec.backward(grec)
@@ -178,8 +178,8 @@ class ElasticMarmousi:
 
     def __init__(self, dev, rank, world, nt=None, shots=None, grid=None):
         import torch
-        from physicsbasedfwi2_amd import elastic, profiles
-        self.torch, self.elastic, self.dev = torch, elastic, dev
+        from physicsbasedfwi2_amd import elastic, misfit, profiles
+        self.torch, self.elastic, self.dev, self.misfit = torch, elastic, dev, misfit
         if nt:
             self.nt = nt
         if os.environ.get("TUNE_PML"):
@@ -233,8 +233,7 @@ class ElasticMarmousi:
         rvx, rvz = self.elastic.propagate(mat, self.f, self.pz, self.px, self.sc, self.sw, self.rc,
                                           self.rw, self.pml)
         ev[1].record()
-        dx, dz = rvx - self.ox, rvz - self.oz
-        loss = 0.5 * (dx * dx).sum() + 0.5 * (dz * dz).sum()
+        loss = self.misfit.l2_half(rvx, self.ox) + self.misfit.l2_half(rvz, self.oz)
         gx, gz = torch.autograd.grad(loss, [rvx, rvz], retain_graph=True)
         ev[2].record()
         torch.autograd.backward([rvx, rvz], [gx, gz])

@@ -185,6 +185,25 @@ int mifwi_elastic_backward(mifwi_elastic_plan *plan, const float *mat, const flo
                            float *grad_mat, float *grad_f, float *work, int32_t n_hi, int32_t n_lo,
                            int32_t flags, void *stream);
 
+/* ======================================================================================
+ * Fused data MISFIT + adjoint source (what sits between the propagator call and .backward())
+ *
+ * Replaces:
+ *   L1_TRACE_NORM  models/networks.py:5418-5419 (observed side), 5467-5476, 5491 (predicted side):
+ *                  d = pred - direct;  dn = d / (max_t |d| + 1e-10);  loss = mean |dn - obs|
+ *   L2             seisgan/fwi/layers.py:176-178; DENISE lnorm = 2 (models/networks.py:7758):
+ *                  loss = 1/2 sum (pred - obs)^2
+ * pred, obs, direct (NULL = none; L1 only), adj_out (NULL = loss only): [nt][ntrace] with
+ * trace = shot*nrec + receiver, the propagators' own output layout.  adj_out = dloss/dpred
+ * (including the path through each trace's maximum).  loss_out: one device float.
+ * work: mifwi_misfit_work_elems(kind, nt, ntrace) floats, 8-byte aligned.
+ * ==================================================================================== */
+enum { MIFWI_MISFIT_L1_TRACE_NORM = 0, MIFWI_MISFIT_L2 = 1 };
+
+int64_t mifwi_misfit_work_elems(int32_t kind, int64_t nt, int64_t ntrace);
+int mifwi_misfit(int device, int32_t kind, const float *pred, const float *obs, const float *direct,
+                 int64_t nt, int64_t ntrace, float *loss_out, float *adj_out, float *work, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,7 +69,12 @@ SIGNATURES = {
     "mifwi_elastic_forward": (ctypes.c_int, [_P] * 13 + [ctypes.c_int32] * 3 + [_P]),
     "mifwi_elastic_backward": (ctypes.c_int, [_P] * 11 + [ctypes.c_int32] + [_P] * 3 +
                                [ctypes.c_int32] * 3 + [_P]),
+    "mifwi_misfit_work_elems": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64]),
+    "mifwi_misfit": (ctypes.c_int, [ctypes.c_int, ctypes.c_int32] + [_P] * 3 + [ctypes.c_int64] * 2 +
+                     [_P] * 4),
 }
+MISFIT_L1_TRACE_NORM = 0
+MISFIT_L2 = 1
 
 _lib = None
 

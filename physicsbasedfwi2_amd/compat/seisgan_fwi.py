@@ -18,7 +18,7 @@ Deliberate difference: the model gradient is the exact discrete adjoint of the f
 import numpy as np
 import torch
 
-from .. import acoustic, profiles
+from .. import acoustic, misfit, profiles
 from .._lib import MifwiError
 
 
@@ -112,8 +112,7 @@ class _FWILossFn(torch.autograd.Function):
                                      cfg.c0, cfg.c1)
             syn = torch.zeros_like(rec)
             syn[1:cfg.nt - 1] = rec[0:cfg.nt - 2]
-            res = syn - cfg.true_ds
-            objective = 0.5 * (res * res).sum()
+            objective = misfit.l2_half(syn, cfg.true_ds)      # layers.py:176-178, fused on the GPU
             (g_pad,) = torch.autograd.grad(objective, m_pad)
         gradient = g_pad[p:-p, p:-p] if p > 0 else g_pad
         holder.smooth_ds = syn.detach().sum(dim=1).cpu().numpy()

@@ -14,7 +14,7 @@ def _header_functions():
     src = open(os.path.join(ROOT, "include", "mifwi.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"(?:int|const char \*)\s*\*?\s*(mifwi_\w+)\s*\(([^;]*?)\)\s*;", src, re.S):
+    for m in re.finditer(r"(?:int64_t|int|const char \*)\s*\*?\s*(mifwi_\w+)\s*\(([^;]*?)\)\s*;", src, re.S):
         args = m.group(2).strip()
         n = 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
         out[m.group(1)] = n
