@@ -5,7 +5,7 @@
 // Why (profiles/): on the grids the reference actually runs (100x300, 150x294,
 // 190x324 ...) a time step launched as kernels is bound by launch boundaries and memory round trips
 // (V 12 us + S 14 us for 0.96 M cells), not by HBM.  Here a shot is cut into NW row slabs, one
-// 1024-thread workgroup (one CU, ~105 KB of LDS) per slab, NW x shots <= CU count so that every
+// 512-thread workgroup (one CU, ~105 KB of LDS) per slab, NW x shots <= CU count so that every
 // workgroup is resident; per step the only global traffic is the snapshot stream (20 B/cell) and
 // the two halo hand-offs (velocities after V, stresses after S), done as self-validating 8-byte
 // {epoch,value} granules with agent-scope stores/loads (cdna_hip_programming.md, G16 form R2):
@@ -14,8 +14,8 @@
 // Arithmetic per cell = el_step_v / el_step_s (bitwise identical seismograms).
 #pragma once
 
-constexpr int kEcThreads = 512;       // 8 waves/CU: a 256-VGPR budget keeps a group's materials, memory
-                                      // variables and pending snapshot terms in registers without spilling
+constexpr int kEcThreads = 512;       // 8 waves/CU: the 256-VGPR budget holds two 4-cell groups' materials and
+                                      // memory variables (adjoint: fields, accumulators, snapshot terms)
 constexpr unsigned kEcMaxSpin = 400000;
 
 struct EcParams {
