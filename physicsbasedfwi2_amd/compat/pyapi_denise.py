@@ -72,11 +72,13 @@ class Receivers(_Points):
 class Sources(_Points):
     """api.Sources(xsrc, ysrc, fsource): one shot per source; ``f`` = centre frequency [Hz]."""
 
-    def __init__(self, x, y, f, td=0.0, amp=1.0):
+    def __init__(self, x, y, f, td=0.0, amp=1.0, wavelets=None):
         super().__init__(x, y)
         self.f = np.broadcast_to(np.asarray(f, dtype=np.float64), self.x.shape).copy()
         self.td = np.broadcast_to(np.asarray(td, dtype=np.float64), self.x.shape).copy()
         self.amp = np.broadcast_to(np.asarray(amp, dtype=np.float64), self.x.shape).copy()
+        # QUELLART = 3 (source time functions "from file"): [nshot, nt] or [nt] samples at the run's DT
+        self.wavelets = None if wavelets is None else np.asarray(wavelets, dtype=np.float64)
 
 
 def ricker_denise(fc, nt, dt, td=0.0):
@@ -86,6 +88,33 @@ def ricker_denise(fc, nt, dt, td=0.0):
     ts = 1.0 / fc
     tau = np.pi * (t - 1.5 * ts - td) / (1.5 * ts)
     return (1.0 - 4.0 * tau * tau) * np.exp(-2.0 * tau * tau)
+
+
+def spike_denise(nt, dt, fc1, fc2, order=5, td=0.0):
+    """QUELLART = 6: a unit spike at t = td, band-limited with the Butterworth response between
+    FC_SPIKE_1 (high-pass corner, <= 0: none) and FC_SPIKE_2 (low-pass corner), order ORDER_SPIKE.
+    DENISE's own filter is causal; the magnitude response is the same (conventions: DESIGN.md 2)."""
+    w = np.zeros(nt, dtype=np.float64)
+    w[min(nt - 1, max(0, int(round(td / dt))))] = 1.0 / dt
+    return butterworth(torch.tensor(w), dt, max(0.0, float(fc1)), float(fc2), int(order)).numpy()
+
+
+def gradient_taper(ny, dh, gradt1=21, gradt2=25, gradt3=490, gradt4=500, exponent=0.0):
+    """SWS_TAPER_GRAD_HOR = 1: depth window applied to every gradient, row 0 = surface.  Zero above
+    grid row GRADT1, cosine ramp to one at GRADT2, one down to GRADT3, cosine ramp to zero at GRADT4
+    (rows counted from 1 as in DENISE.inp; a ramp beyond the grid is simply not reached), times the
+    depth preconditioner (row * DH) ** EXP_TAPER_GRAD_HOR.  DENISE's taper_grad.c is not available
+    here: this is the documented stand-in (the reference mutes rows 0:25 and rescales every gradient
+    to max(model)/max(grad) afterwards, networks.py:7808-7862, so only the shape matters)."""
+    j = np.arange(1, ny + 1, dtype=np.float64)
+    w = np.ones(ny, dtype=np.float64)
+    up = (j - gradt1) / max(1.0, float(gradt2 - gradt1))
+    w = np.where(j <= gradt1, 0.0, np.where(j < gradt2, 0.5 * (1.0 - np.cos(np.pi * up)), w))
+    dn = (j - gradt3) / max(1.0, float(gradt4 - gradt3))
+    w = np.where(j >= gradt4, 0.0, np.where(j > gradt3, w * 0.5 * (1.0 + np.cos(np.pi * dn)), w))
+    if exponent:
+        w = w * (j * dh) ** float(exponent)
+    return w.astype(np.float32)
 
 
 def butterworth(x, dt, fc_low=0.0, fc_high=0.0, order=6):
@@ -186,6 +215,7 @@ class Denise:
         self.RHOLOWERLIM = 1000.0
         self.SWS_TAPER_GRAD_HOR = 0
         self.EXP_TAPER_GRAD_HOR = 2.0
+        self.GRADT1, self.GRADT2, self.GRADT3, self.GRADT4 = 21, 25, 490, 500
         self.fwi_stages = []
         self._observed = None
         self._gradients = None
@@ -226,8 +256,8 @@ class Denise:
 
     # -- numerics -----------------------------------------------------------------------------------
     def _setup(self, model, src, rec):
-        if self.PHYSICS != 1:
-            raise MifwiError("only PHYSICS=1 (P-SV elastic) is implemented")
+        if self.PHYSICS not in (1, 2):
+            raise MifwiError("PHYSICS=%s not implemented (1 = P-SV elastic, 2 = acoustic)" % self.PHYSICS)
         dev = torch.device(self.device) if self.device is not None else \
             torch.device("cuda", torch.cuda.current_device())
         h = model.dx
@@ -248,8 +278,23 @@ class Denise:
         if self.QUELLART == 1:
             wav = np.stack([ricker_denise(src.f[i], nt, dt, src.td[i]) * src.amp[i]
                             for i in range(ns)], axis=1)
+        elif self.QUELLART == 3:
+            if src.wavelets is None:
+                raise MifwiError("QUELLART=3 needs Sources(..., wavelets=[nshot, nt] samples at DT)")
+            w = np.broadcast_to(np.atleast_2d(src.wavelets), (ns, np.atleast_2d(src.wavelets).shape[1]))
+            wav = np.zeros((nt, ns))
+            k = min(nt, w.shape[1])
+            wav[:k] = (w[:, :k] * src.amp[:, None]).T
+        elif self.QUELLART == 6:
+            wav = np.stack([spike_denise(nt, dt, self.FC_SPIKE_1, self.FC_SPIKE_2, self.ORDER_SPIKE,
+                                         src.td[i]) * src.amp[i] for i in range(ns)], axis=1)
         else:
-            raise MifwiError("QUELLART=%s not implemented (1 = Ricker)" % self.QUELLART)
+            raise MifwiError("QUELLART=%s not implemented (1 Ricker, 3 samples, 6 band-limited spike)"
+                             % self.QUELLART)
+        if self.QUELLTYPB not in (1, 2) or (self.QUELLTYPB == 2 and self.PHYSICS != 2):
+            raise MifwiError("QUELLTYPB=%s: only the explosive source is implemented" % self.QUELLTYPB)
+        if self.SEISMO != 1:
+            raise MifwiError("SEISMO=%s: only particle-velocity seismograms are implemented" % self.SEISMO)
         # explosive source: moment-rate density added to sxx and szz
         f = torch.tensor(wav * (dt / (h * h)), dtype=torch.float32).view(nt, ns, 1)
         fw = int(self.FW)
@@ -262,8 +307,10 @@ class Denise:
 
     def _materials(self, model, dev, dt, h, requires_grad, fsurf=False):
         # undo the caller's flipud: internally row 0 is the surface
+        # PHYSICS = 2 (acoustic): the same velocity-stress solver in a fluid, Vs = 0 everywhere
+        vs = model.vs if self.PHYSICS == 1 else np.zeros_like(model.vs)
         prm = [torch.tensor(np.flipud(a).copy(), device=dev, requires_grad=requires_grad)
-               for a in (model.vp, model.vs, model.rho)]
+               for a in (model.vp, vs, model.rho)]
         return prm, elastic.staggered_materials(prm[0], prm[1], prm[2], dt, h, free_surface=fsurf)
 
     def forward(self, model, src, rec):
@@ -310,11 +357,16 @@ class Denise:
         if self.QUELLTYPB != 2:
             loss = loss + misfit.l2_half(fl(vx), fl(ox))
         loss.backward()
-        self.loss = float(loss)
+        self.loss = float(loss.detach())
         with open("loss_curve_grad.out", "w") as fh:
             fh.write("%e\n" % self.loss)
         # re-apply the caller's flipud convention on the way out
-        gvp, gvs, grho = (np.flipud(p.grad.detach().cpu().numpy()).copy() for p in prm)
+        grads = [p.grad.detach() for p in prm]
+        if int(self.SWS_TAPER_GRAD_HOR) == 1:
+            w = torch.tensor(gradient_taper(model.ny, h, self.GRADT1, self.GRADT2, self.GRADT3, self.GRADT4,
+                                            self.EXP_TAPER_GRAD_HOR), device=dev)[:, None]
+            grads = [g * w for g in grads]
+        gvp, gvs, grho = (np.flipud(g.cpu().numpy()).copy() for g in grads)
         self._gradients = {"rho": grho, "vp": gvp, "vs": gvs}
         self.DT_used = dt
         return self.loss

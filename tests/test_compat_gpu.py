@@ -168,3 +168,39 @@ def test_seisgan_fwiloss_matches_oracle(oracle32):
     gm = gm / np.abs(gm).max()
     assert rel_l2(x.grad[0, 0].cpu().numpy(), gm) < 2e-3
     assert float(x.grad.abs().max()) == pytest.approx(1.0)
+
+
+def test_denise_source_kinds_physics2_and_gradient_taper(tmp_path, monkeypatch):
+    """QUELLART 3 (samples) fed with the QUELLART 1 wavelet reproduces it; QUELLART 6 runs;
+    PHYSICS = 2 equals the elastic solver in a fluid; SWS_TAPER_GRAD_HOR multiplies every gradient
+    by the documented depth window."""
+    api, d, (vp, vs, rho), dx, src, rec = _denise_setup(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    model = api.Model(np.flipud(vp), np.flipud(vs), np.flipud(rho), dx)
+    sx1, sy1 = d.forward(model, src, rec)
+    nt = sx1.shape[2]
+    d.QUELLART = 3
+    src3 = api.Sources(src.x, src.y, 8.0, wavelets=api.ricker_denise(8.0, nt, 0.002))
+    sx3, sy3 = d.forward(model, src3, rec)
+    assert np.array_equal(sx1, sx3) and np.array_equal(sy1, sy3)
+    d.QUELLART, d.FC_SPIKE_1, d.FC_SPIKE_2 = 6, 3.0, 10.0
+    sx6, _ = d.forward(model, src, rec)
+    assert np.isfinite(sx6).all() and np.abs(sx6).max() > 0
+    # acoustic = fluid
+    d.QUELLART, d.PHYSICS = 1, 2
+    ax, ay = d.forward(model, src, rec)
+    d.PHYSICS = 1
+    fluid = api.Model(np.flipud(vp), np.zeros_like(vs), np.flipud(rho), dx)
+    fx, fy = d.forward(fluid, src, rec)
+    assert np.array_equal(ax, fx) and np.array_equal(ay, fy)
+    # gradient taper
+    d.set_observed(0.9 * np.transpose(sx1, (0, 2, 1)), 0.9 * np.transpose(sy1, (0, 2, 1)))
+    d.grad(model, src, rec)
+    g0 = d.get_fwi_gradients(["seis"])
+    d.SWS_TAPER_GRAD_HOR, d.EXP_TAPER_GRAD_HOR, d.GRADT3, d.GRADT4 = 1, 2.0, 50, 58
+    d.grad(model, src, rec)
+    g1 = d.get_fwi_gradients(["seis"])
+    w = api.gradient_taper(vp.shape[0], dx, 21, 25, 50, 58, 2.0)[:, None]
+    for a, b in zip(g0, g1):
+        assert np.allclose(np.flipud(b), np.flipud(a) * w, rtol=1e-6, atol=0)
+    assert not np.any(np.flipud(g1[1])[:21]) and not np.any(np.flipud(g1[1])[57:])

@@ -94,3 +94,21 @@ def test_cpml_tables_agree_and_are_sane():
     assert a[0, 0] < a[0, 5] < 0                      # damping grows towards the edge
     top_free = P.cpml_tables(120, 10, 20.0, 0.002, 3000.0, 5.0, low=False)
     assert (top_free[0, :60] == 0).all() and (top_free[0, 110:] < 0).all()
+
+
+def test_denise_shim_wavelet_and_taper_conventions():
+    """Host-side conventions of the pyapi_denise shim that need no GPU: the band-limited spike
+    (QUELLART = 6) has the Butterworth magnitude response, the gradient window has the documented
+    shape."""
+    import physicsbasedfwi2_amd.compat.pyapi_denise as api
+    nt, dt = 1000, 0.002
+    s = api.spike_denise(nt, dt, -5.0, 15.0, 5, 0.2)
+    spec = np.abs(np.fft.rfft(s, 2 * nt))
+    f = np.fft.rfftfreq(2 * nt, dt)
+    k15 = np.argmin(np.abs(f - 15.0))
+    assert abs(spec[k15] / spec[0] - 1 / np.sqrt(2)) < 2e-2 and spec[np.argmin(np.abs(f - 60.0))] < 1e-2 * spec[0]
+    w = api.gradient_taper(100, 20.0, 21, 25, 90, 98, 0.0)
+    assert not w[:21].any() and w[24:89].min() == 1.0 and not w[97:].any()
+    assert np.all(np.diff(w[20:25]) > 0) and np.all(np.diff(w[89:98]) < 0)
+    w2 = api.gradient_taper(100, 20.0, 21, 25, 490, 500, 2.0)
+    assert np.allclose(w2[30:], ((np.arange(31, 101)) * 20.0) ** 2)
