@@ -838,7 +838,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
         if (pl->d.nz / nw < 4) break;
         const long long lds = (5LL * (rows + 4) * pl->PL + 6LL * pl->gp + 6LL * rows + 8) * sizeof(float);
         if (lds > 150 * 1024) continue;
-        if ((long long)rows * pl->ng > 2 * kEcThreads || 8 * pl->gp > 5 * kEcThreads) continue;
+        if ((long long)rows * pl->ng > 2 * kEcThreads || kEcRowFields * pl->gp > kEcGr * kEcThreads) continue;
         const int per_launch = 8 * (ncu / (8 * nw));
         if (per_launch < 8) break;
         pl->cluster = 1; pl->NW = nw; pl->cl_shots = per_launch; pl->cl_lds = (int)lds;
@@ -871,7 +871,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
             const long long lds = (4LL * (rows + 4) * pl->PL + 6LL * pl->gp + 6LL * ((rows + 3) & ~3) +
                                    4LL * rows * pl->wx + 4LL * zmax * pl->gp) * sizeof(float);
             if (lds > 150 * 1024) continue;
-            if ((long long)rows * pl->ng > 2 * kEcThreads || 8 * pl->gp > 5 * kEcThreads) continue;
+            if ((long long)rows * pl->ng > 2 * kEcThreads || kEcRowFields * pl->gp > kEcGr * kEcThreads) continue;
             const int per_launch = 8 * (ncu / (8 * nw));
             if (per_launch < 8) break;
             pl->cl_adj = 1; pl->adj_NW = nw; pl->adj_shots = per_launch; pl->adj_lds = (int)lds;
@@ -884,7 +884,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
                     pl->cl_adj = 0;
     }
     const int nwmax = std::max(pl->cluster ? pl->NW : 0, pl->cl_adj ? pl->adj_NW : 0);
-    if (nwmax > 0) pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * nwmax * 4 * 8 * pl->gp + 64, 64);
+    if (nwmax > 0) pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * nwmax * 4 * kEcRowFields * pl->gp + 64, 64);
     if (pl->cl_adj)
         pl->list_elems = mifwi::round_up64((long long)pl->d.nshot * pl->adj_NW * (1 + pl->d.nrec), 64);
 }

@@ -49,12 +49,27 @@ __device__ __forceinline__ void ec_slab_rows(int nz, int NW, int w, int &r0, int
     r0 = w * base + (w < rem ? w : rem);
 }
 
-// granule index inside one exchange slot: [field 0..1][side 0=up,1=down][row 0..1][k 0..3][group]
-// (cell 4*group + k): the lanes of a publishing wave hold consecutive groups, so each of their store
-// instructions writes whole lines (8-byte stores 32 bytes apart are several times slower to land)
-__device__ __forceinline__ int ec_gran(int gp, int ng, int fld, int side, int row, int group, int k)
+// One exchange slot = kEcRowFields rows of gp granules.  A z-stencil reads the backward-differenced
+// field (vz, sxz; adjoint E3, D4: "A") on rows j-2..j+1 and the forward-differenced one (vx, szz;
+// adjoint E2, D2: "B") on rows j-1..j+2, so a slab needs A on 2 rows above / 1 below and B on 1 row
+// above / 2 below: six row-fields per hand-off, not eight.
+//   row-field  field  owner's row   lands in the neighbour's LDS row
+//      0         A       0           R'+2   (first bottom halo row of the slab above)
+//      1         B       0           R'+2
+//      2         B       1           R'+3
+//      3         A       R-2         0      (top halo rows of the slab below)
+//      4         A       R-1         1
+//      5         B       R-1         1
+// Inside a row the order is [k 0..3][group] (cell 4*group + k): the lanes of a publishing wave hold
+// consecutive groups, so each of their store instructions writes whole lines (8-byte stores 32 bytes
+// apart are several times slower to land).
+constexpr int kEcRowFields = 6;
+constexpr int kEcGr = 5;              // granules a thread receives per hand-off: 6*gp <= kEcGr*kEcThreads
+
+__device__ __forceinline__ int ec_rf_field(int rf) { return (rf == 0 || rf == 3 || rf == 4) ? 1 : 0; }   // 1 = A
+__device__ __forceinline__ int ec_rf_lds_row(int rf, int R)
 {
-    return ((fld * 2 + side) * 2 + row) * gp + k * ng + group;
+    return rf == 0 || rf == 1 ? R + 2 : rf == 2 ? R + 3 : rf == 3 ? 0 : 1;
 }
 
 // Uniform value the compiler must treat as unknown at this point: stops it from hoisting every
@@ -318,24 +333,24 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     __syncthreads();
 
     // ---- hand-off assignments (constant): granule e = t + k*kEcThreads of an 8*gp slot -------------
-    constexpr int kGr = 5;
+    constexpr int kGr = kEcGr;
     int rcv_lo[kGr];                     // LDS offset inside the field (<0: none)
     unsigned rcv_meta = 0;               // per k: bit0 field, bit1 from-upper-neighbour
 #pragma unroll
     for (int k = 0; k < kGr; ++k) {
         const int e = t + k * kEcThreads;
         rcv_lo[k] = -1;
-        if (e < 8 * p.gp) {
-            const int cq = e % p.gp, q = e / p.gp;
+        if (e < kEcRowFields * p.gp) {
+            const int cq = e % p.gp, rf = e / p.gp;
             const int col = 4 * (cq % p.ng) + cq / p.ng;         // granule order is [k][group]
-            const int row = q & 1, side = (q >> 1) & 1, fld = q >> 2;
-            if (cq < 4 * p.ng && !((side == 0 && w == 0) || (side == 1 && w == p.NW - 1))) {
-                rcv_lo[k] = ((side == 0) ? row : R + 2 + row) * PL + 4 + col;
-                rcv_meta |= (unsigned)(fld | (side == 0 ? 2 : 0)) << (2 * k);
+            const bool from_above = rf >= 3;                      // top halo <- the slab above's last rows
+            if (cq < 4 * p.ng && !(from_above ? w == 0 : w == p.NW - 1)) {
+                rcv_lo[k] = ec_rf_lds_row(rf, R) * PL + 4 + col;
+                rcv_meta |= (unsigned)(ec_rf_field(rf) | (from_above ? 2 : 0)) << (2 * k);
             }
         }
     }
-    const long long xslot = 8LL * p.gp;                       // granules per slot
+    const long long xslot = (long long)kEcRowFields * p.gp;   // granules per slot
     unsigned long long *xw = p.xbuf + ((long long)s * p.NW + w) * 4 * xslot;      // [kind][parity][slot]
     const bool do_x = p.NW > 1 && !(p.dbg & 1);
     bool failed = false;
@@ -351,8 +366,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 #pragma unroll
         for (int k = 0; k < kGr; ++k) {
             const int e = t + k * kEcThreads;
-            // my top halo = the upper neighbour's "down" rows (side 1), my bottom halo = the lower one's "up" rows
-            src[k] = ((rcv_meta >> (2 * k)) & 2u) ? xu + (e + 2 * p.gp) : xd + (e - 2 * p.gp);
+            src[k] = (((rcv_meta >> (2 * k)) & 2u) ? xu : xd) + e;        // same row-field index on both sides
             v[k] = 0;
         }
         for (unsigned spins = 0;; ++spins) {
@@ -383,20 +397,20 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     auto publish = [&](const int lrw, const int gq, int kind, unsigned epoch, int parity, const float4 &o0, const float4 &o1) {
         unsigned long long *x = xw + (kind * 2 + parity) * xslot;
         const unsigned long long tag = (unsigned long long)epoch << 32;
-        const float av[4] = {o0.x, o0.y, o0.z, o0.w}, bv[4] = {o1.x, o1.y, o1.z, o1.w};
+        const float bv[4] = {o0.x, o0.y, o0.z, o0.w}, av[4] = {o1.x, o1.y, o1.z, o1.w};   // o0 = B, o1 = A
+        auto put = [&](int rf, const float (&v)[4]) {
 #pragma unroll
-        for (int sd = 0; sd < 2; ++sd) {
-            // side 0 ("up"): my first two rows go to the upper neighbour; side 1: my last two rows
-            const int row = (sd == 0) ? lrw : lrw - (R - 2);
-            if (row < 0 || row > 1) continue;
-            if ((sd == 0 && w == 0) || (sd == 1 && w == p.NW - 1)) continue;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                __hip_atomic_store(x + (unsigned)ec_gran(p.gp, p.ng, 0, sd, row, gq, k), tag | __float_as_uint(av[k]),
+            for (int k = 0; k < 4; ++k)
+                __hip_atomic_store(x + (unsigned)(rf * p.gp + k * p.ng + gq), tag | __float_as_uint(v[k]),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(x + (unsigned)ec_gran(p.gp, p.ng, 1, sd, row, gq, k), tag | __float_as_uint(bv[k]),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        };
+        if (w > 0) {
+            if (lrw == 0) { put(0, av); put(1, bv); }
+            if (lrw == 1) put(2, bv);
+        }
+        if (w < p.NW - 1) {
+            if (lrw == R - 2) put(3, av);
+            if (lrw == R - 1) { put(4, av); put(5, bv); }
         }
     };
     // source term of step n for a group: fetched one step ahead (a global load in the update itself
@@ -722,24 +736,24 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     __syncthreads();
 
     // ---- hand-off assignments (as in the forward kernel) ------------------------------------------
-    constexpr int kGr = 5;
+    constexpr int kGr = kEcGr;
     int rcv_lo[kGr];
     unsigned rcv_meta = 0;               // per k: bit0 field, bit1 from-upper-neighbour
 #pragma unroll
     for (int k = 0; k < kGr; ++k) {
         const int e = t + k * kEcThreads;
         rcv_lo[k] = -1;
-        if (e < 8 * p.gp) {
-            const int cq = e % p.gp, q = e / p.gp;
-            const int col = 4 * (cq % p.ng) + cq / p.ng;
-            const int row = q & 1, side = (q >> 1) & 1, fld = q >> 2;
-            if (cq < 4 * p.ng && !((side == 0 && w == 0) || (side == 1 && w == p.NW - 1))) {
-                rcv_lo[k] = ((side == 0) ? row : R + 2 + row) * PL + 4 + col;
-                rcv_meta |= (unsigned)(fld | (side == 0 ? 2 : 0)) << (2 * k);
+        if (e < kEcRowFields * p.gp) {
+            const int cq = e % p.gp, rf = e / p.gp;
+            const int col = 4 * (cq % p.ng) + cq / p.ng;         // granule order is [k][group]
+            const bool from_above = rf >= 3;                      // top halo <- the slab above's last rows
+            if (cq < 4 * p.ng && !(from_above ? w == 0 : w == p.NW - 1)) {
+                rcv_lo[k] = ec_rf_lds_row(rf, R) * PL + 4 + col;
+                rcv_meta |= (unsigned)(ec_rf_field(rf) | (from_above ? 2 : 0)) << (2 * k);
             }
         }
     }
-    const long long xslot = 8LL * p.gp;
+    const long long xslot = (long long)kEcRowFields * p.gp;
     unsigned long long *xw = p.xbuf + ((long long)s * p.NW + w) * 4 * xslot;
     const bool do_x = p.NW > 1 && !(p.dbg & 1);
     bool failed = false;
@@ -752,7 +766,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
 #pragma unroll
         for (int k = 0; k < kGr; ++k) {
             const int e = t + k * kEcThreads;
-            src[k] = ((rcv_meta >> (2 * k)) & 2u) ? xu + (e + 2 * p.gp) : xd + (e - 2 * p.gp);
+            src[k] = (((rcv_meta >> (2 * k)) & 2u) ? xu : xd) + e;        // same row-field index on both sides
             v[k] = 0;
         }
         for (unsigned spins = 0;; ++spins) {
@@ -783,19 +797,20 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
                        const float4 &o1) {
         unsigned long long *x = xw + (kind * 2 + parity) * xslot;
         const unsigned long long tag = (unsigned long long)epoch << 32;
-        const float av[4] = {o0.x, o0.y, o0.z, o0.w}, bv[4] = {o1.x, o1.y, o1.z, o1.w};
+        const float bv[4] = {o0.x, o0.y, o0.z, o0.w}, av[4] = {o1.x, o1.y, o1.z, o1.w};   // o0 = B, o1 = A
+        auto put = [&](int rf, const float (&v)[4]) {
 #pragma unroll
-        for (int sd = 0; sd < 2; ++sd) {
-            const int row = (sd == 0) ? lrw : lrw - (R - 2);
-            if (row < 0 || row > 1) continue;
-            if ((sd == 0 && w == 0) || (sd == 1 && w == p.NW - 1)) continue;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                __hip_atomic_store(x + (unsigned)ec_gran(p.gp, p.ng, 0, sd, row, gq, k), tag | __float_as_uint(av[k]),
+            for (int k = 0; k < 4; ++k)
+                __hip_atomic_store(x + (unsigned)(rf * p.gp + k * p.ng + gq), tag | __float_as_uint(v[k]),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(x + (unsigned)ec_gran(p.gp, p.ng, 1, sd, row, gq, k), tag | __float_as_uint(bv[k]),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        };
+        if (w > 0) {
+            if (lrw == 0) { put(0, av); put(1, bv); }
+            if (lrw == 1) put(2, bv);
+        }
+        if (w < p.NW - 1) {
+            if (lrw == R - 2) put(3, av);
+            if (lrw == R - 1) { put(4, av); put(5, bv); }
         }
     };
     const long long sshot = (long long)s * 5 * ncell;
