@@ -47,3 +47,36 @@ def condition_elastic_gradients(g_vp, g_vs, g_rho, vp, vs, rho, mute_rows=25, rh
         r = np.max(m) / np.max(gg)
         outs.append(1.0 * torch.from_numpy(gg.copy()).float() * r * fac)
     return outs
+
+
+def gaussian_smooth(g, sigma, truncate=4.0):
+    """``scipy.ndimage.gaussian_filter(g, sigma)`` with its defaults (order 0, mode='reflect',
+    truncate 4.0) as two separable 1-D correlations in torch, on whatever device ``g`` lives
+    (networks.py:10526 smooths the RealData Vp gradient with sigma = 3).  ``g`` is [nz, nx]."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = torch.arange(-radius, radius + 1, device=g.device, dtype=torch.float64)
+    k = torch.exp(-0.5 * (x / float(sigma)) ** 2)
+    k = (k / k.sum()).to(g.dtype)
+    out = g[None, None]
+    for dim, pad in ((2, (0, 0, radius, radius)), (3, (radius, radius, 0, 0))):
+        n = out.shape[dim]
+        # scipy's 'reflect' is torch's 'symmetric' (edge sample repeated): build it by index
+        idx = torch.arange(-radius, n + radius, device=g.device)
+        idx = torch.where(idx < 0, -idx - 1, idx)
+        idx = torch.where(idx >= n, 2 * n - 1 - idx, idx).clamp_(0, n - 1)
+        ext = out.index_select(dim, idx)
+        w = k.view(1, 1, -1, 1) if dim == 2 else k.view(1, 1, 1, -1)
+        out = torch.nn.functional.conv2d(ext, w)
+    return out[0, 0]
+
+
+def condition_elastic_gradients_on_device(g_vp, g_vs, g_rho, vp, vs, rho, mute_rows=25, rho_factor=0.1):
+    """:func:`condition_elastic_gradients` without leaving the device: torch tensors in (gradients
+    as returned by ``Denise.get_fwi_gradients``, i.e. flipud-ed; models in the same orientation as
+    the reference's ``vp, vs, rho``), torch tensors out."""
+    outs = []
+    for g, m, fac in ((g_vp, vp, 1.0), (g_vs, vs, 1.0), (g_rho, rho, rho_factor)):
+        gg = torch.flip(torch.as_tensor(g), dims=(0,)).float().clone()
+        gg[0:mute_rows, :] = 0.0
+        outs.append(gg * (torch.as_tensor(m).max().to(gg.device) / gg.max()) * fac)
+    return outs

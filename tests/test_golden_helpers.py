@@ -112,3 +112,20 @@ def test_denise_shim_wavelet_and_taper_conventions():
     assert np.all(np.diff(w[20:25]) > 0) and np.all(np.diff(w[89:98]) < 0)
     w2 = api.gradient_taper(100, 20.0, 21, 25, 490, 500, 2.0)
     assert np.allclose(w2[30:], ((np.arange(31, 101)) * 20.0) ** 2)
+
+
+def test_gaussian_smooth_matches_scipy_and_device_conditioning_matches_host():
+    import torch
+    from scipy.ndimage import gaussian_filter
+    from physicsbasedfwi2_amd import conditioning as C
+    rng = np.random.default_rng(9)
+    g = rng.standard_normal((37, 53))
+    for sigma in (3.0, 1.3):
+        ours = C.gaussian_smooth(torch.tensor(g), sigma).numpy()
+        assert np.abs(ours - gaussian_filter(g, sigma=sigma)).max() < 1e-12      # networks.py:10526
+    vp, vs, rho = (rng.random((40, 30)).astype(np.float32) * s + o for s, o in ((2000, 1500), (1000, 0), (800, 1800)))
+    gs = [rng.standard_normal((40, 30)).astype(np.float32) for _ in range(3)]
+    host = C.condition_elastic_gradients(*gs, vp, vs, rho)
+    dev = C.condition_elastic_gradients_on_device(*(torch.tensor(a) for a in gs), *(torch.tensor(a) for a in (vp, vs, rho)))
+    for a, b in zip(host, dev):
+        assert torch.allclose(a, b, rtol=1e-6, atol=0)
