@@ -96,6 +96,7 @@ struct EcCtx {
 };
 
 // V update (reads stresses from LDS, writes the group's velocities in place)
+template <bool EDGE>   // EDGE: the group may sit on grid rows 0/1 (free-surface mirroring); interior rows never do
 __device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const int lo, const int gq, const int lrw, float4 &S4, float4 &S5, float4 &o0,
                                             float4 &o1)
 {
@@ -109,7 +110,7 @@ __device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const in
     const float4 a3 = ld4(sxz + PL);
     float4 b0 = ld4(szz - PL);
     const float4 b1 = ld4(szz), b2 = ld4(szz + PL), b3 = ld4(szz + 2 * PL);
-    if (c.fsurf && G.j < 2) {
+    if (EDGE && c.fsurf && G.j < 2) {
         if (G.j == 0) {
             a1 = make_float4(-a2.x, -a2.y, -a2.z, -a2.w);
             a0 = make_float4(-a3.x, -a3.y, -a3.z, -a3.w);
@@ -165,6 +166,7 @@ __device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const in
 
 // S update (reads velocities from LDS, writes the group's stresses in place); `amp` = source term
 // of this step for the group's source cell (cell G.src & 3 of the group), 0 when there is none
+template <bool EDGE>
 __device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const int lo, const int gq, const int lrw, const float4 &amp, float4 &S1, float4 &S2,
                                             float4 &S3, float4 &o0, float4 &o1)
 {
@@ -220,7 +222,7 @@ __device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const in
         rxz[k] = fmaf(comp(G.mMu, k), s3v[k], comp(oxz, k));
         rxx[k] += comp(amp, k); rzz[k] += comp(amp, k);       // source term of the cell (0 without one)
     }
-    if (c.fsurf && G.j == 0) { rzz[0] = rzz[1] = rzz[2] = rzz[3] = 0.f; }
+    if (EDGE && c.fsurf && G.j == 0) { rzz[0] = rzz[1] = rzz[2] = rzz[3] = 0.f; }
     S1 = make_float4(e1[0], e1[1], e1[2], e1[3]); S2 = make_float4(e2[0], e2[1], e2[2], e2[3]);
     S3 = make_float4(s3v[0], s3v[1], s3v[2], s3v[3]);
     o0 = make_float4(rzz[0], rzz[1], rzz[2], rzz[3]);            // published: szz, sxz
@@ -448,7 +450,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         float4 S4, S5, o0, o1;
         // per-step opaque: the addresses derived from these are recomputed, not hoisted out of the loop
         const int gq = ec_opaque(g.g), jq = ec_opaque(g.j), lrw = jq - r0, lo = (lrw + 2) * PL + 4 + 4 * gq;
-        ec_update_v(g, c, lo, gq, lrw, S4, S5, o0, o1);
+        if (edge) ec_update_v<true>(g, c, lo, gq, lrw, S4, S5, o0, o1);
+        else ec_update_v<false>(g, c, lo, gq, lrw, S4, S5, o0, o1);
         if (edge && do_x && !(p.dbg & 16)) publish(lrw, gq, 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
         if (SAVE && !(p.dbg & 2)) {
             float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(jq * p.gp + 4 * gq);
@@ -458,7 +461,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     auto do_s = [&](EcGroup &g, int q, int n, int it, bool edge) {
         float4 S1, S2, S3, o0, o1;
         const int gq = ec_opaque(g.g), jq = ec_opaque(g.j), lrw = jq - r0, lo = (lrw + 2) * PL + 4 + 4 * gq;
-        ec_update_s(g, c, lo, gq, lrw, source_amp(g, q, n), S1, S2, S3, o0, o1);
+        const float4 amp = source_amp(g, q, n);
+        if (edge) ec_update_s<true>(g, c, lo, gq, lrw, amp, S1, S2, S3, o0, o1);
+        else ec_update_s<false>(g, c, lo, gq, lrw, amp, S1, S2, S3, o0, o1);
         if (edge && do_x && !(p.dbg & 16)) publish(lrw, gq, 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
         if (SAVE && !(p.dbg & 2)) {
             float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(jq * p.gp + 4 * gq);
@@ -988,7 +993,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         g.a4.z = fmaf(g.S5.z, g.vz.z, g.a4.z); g.a4.w = fmaf(g.S5.w, g.vz.w, g.a4.w);
     };
     // D: sigma_bar -= stencils(D) (+ transposed free-surface mirroring on grid rows 0 and 1)
-    auto phase_d = [&](EaGroup &g) {
+    auto phase_d = [&](EaGroup &g, const bool edge) {
         const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g), jq = ec_opaque(g.j);
         const float *D1 = pln + lo, *D2 = pln + fsz + lo, *D3 = pln + 2 * fsz + lo, *D4 = pln + 3 * fsz + lo;
         const float4 c1 = ld4(D1);
@@ -1010,7 +1015,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             nxz[c] = comp(g.bxz, c) - (dz2 + dx3);
             nzz[c] = comp(g.bzz, c) - dz4;
         }
-        if (p.fsurf && jq < 2) {
+        if (edge && p.fsurf && jq < 2) {
             // grid rows 0 and 1 are local rows 2 and 3 of slab 0
             const float4 r0d2 = ld4(pln + fsz + 2 * PL + 4 + 4 * gq), r1d2 = ld4(pln + fsz + 3 * PL + 4 + 4 * gq);
             const float4 r0d4 = ld4(pln + 3 * fsz + 2 * PL + 4 + 4 * gq);
@@ -1103,7 +1108,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         // ---- D ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].inner) phase_d(G[q]);
+            if (G[q].inner) phase_d(G[q], false);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (do_x) receive(1, (unsigned)(2 * it + 2), it & 1);
@@ -1114,7 +1119,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         __syncthreads();                                   // 5: D halo rows are in LDS
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].own && !G[q].inner) phase_d(G[q]);
+            if (G[q].own && !G[q].inner) phase_d(G[q], true);
             __builtin_amdgcn_sched_barrier(0);
         }
         if ((it & 31) == 31 || it == nsteps - 1) {
