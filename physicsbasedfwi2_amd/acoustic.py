@@ -88,9 +88,10 @@ class _AcousticFn(torch.autograd.Function):
                                                                       tuple(geom.src_cell.shape)))
         nrec, ntap = geom.rec_cell.shape[1], geom.rec_cell.shape[2]
         ncell = n0 * n1
-        for name, c in (("src_cell", geom.src_cell), ("rec_cell", geom.rec_cell)):
-            if c.numel() and (int(c.max()) >= ncell):
-                raise MifwiError("%s holds a cell outside the %dx%d grid" % (name, n0, n1))
+        # one host round trip validates every tap (an out-of-grid cell would fault the kernels)
+        tops = [c.max() for c in (geom.src_cell, geom.rec_cell) if c.numel()]
+        if tops and int(torch.stack(tops).max()) >= ncell:
+            raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (n0, n1))
         with torch.cuda.device(dev):
             plan = AcousticPlan(n0, n1, nt, ns, nsrc, nrec, ntap, c0, c1, dev.index,
                                 shots_per_group)

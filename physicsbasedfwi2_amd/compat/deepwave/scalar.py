@@ -12,6 +12,7 @@ pin against): the absorbing layer is the reference's in-tree spon
 (seisgan/fwi/pde/seismic/model.py:6-29), `pml_width` cells wide (default 20), the model is
 edge-replicated into it, and rec[n] samples the field before step n.
 """
+import functools
 import math
 
 import torch
@@ -52,6 +53,13 @@ def _upsample(f, ratio):
     return torch.fft.irfft(out, n=n_up, dim=0) * ratio
 
 
+@functools.lru_cache(maxsize=32)
+def _sponge(n, width, d, h, dt, device):
+    """Damping profile of one axis as a device tensor (a new Propagator is built every iteration,
+    networks.py:5449: everything that only depends on the geometry is cached)."""
+    return torch.from_numpy(profiles.sponge_q(n, width, d, h, dt)).float().to(device)
+
+
 class Propagator(torch.nn.Module):
     def __init__(self, model, dx, pml_width=None, survey_pad=None, vpmax=None):
         super().__init__()
@@ -85,10 +93,10 @@ class Propagator(torch.nn.Module):
         r = (vp_pad * (dti / h)) ** 2
         f = source_amplitudes.to(device=dev, dtype=torch.float32) * (h * h)
         f = _upsample(f, ratio)
-        q0 = torch.from_numpy(profiles.sponge_q(n0, P, dz, h, dti)).float()
-        q1 = torch.from_numpy(profiles.sponge_q(n1, P, dx, h, dti)).float()
-        sc, sw = profiles.cells_truncate(source_locations.detach().cpu(), self.spacing, P, n1)
-        rc, rw = profiles.cells_truncate(receiver_locations.detach().cpu(), self.spacing, P, n1)
+        q0, q1 = _sponge(n0, P, dz, h, dti, str(dev)), _sponge(n1, P, dx, h, dti, str(dev))
+        # coordinates -> cells where the coordinates live (no host round trip when they are on the GPU)
+        sc, sw = profiles.cells_truncate(source_locations.detach(), self.spacing, P, n1)
+        rc, rw = profiles.cells_truncate(receiver_locations.detach(), self.spacing, P, n1)
         rec = acoustic.propagate(r, f, q0, q1, sc, sw, rc, rw, (h / dz) ** 2, (h / dx) ** 2,
                                  shots_per_group=self.shots_per_group)
         return rec[::ratio] if ratio > 1 else rec
