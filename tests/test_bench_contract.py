@@ -1,0 +1,50 @@
+"""bench.py's output contract, checked on the CPU: the helper that sizes the CPU-baseline sample,
+the PMC-traffic lookup, and the schema of the last committed bench line (profiles/)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_cpu_sample_sizing_fills_the_budget_within_the_caps():
+    calls = []
+
+    def run(nt):
+        calls.append(nt)
+        return 0.001 * nt                      # 1 ms per step
+
+    nt, reps, el = bench.sized_cpu_sample(run, 100, 2000, 15.0, bytes_per_step=1e6, mem_cap=5e8)
+    assert nt == 500 and calls[0] == 100       # memory cap: 5e8 / 1e6 steps
+    assert 25 <= reps <= 35 and abs(el - reps * 0.5) < 1e-9
+    nt, reps, el = bench.sized_cpu_sample(run, 100, 300, 0.05, bytes_per_step=1.0)
+    assert nt == 100 and reps == 1             # calibration already exceeds the budget
+
+
+def test_traffic_lookup_reads_the_committed_pmc_summary():
+    cells = 960000
+    t = bench.measured_traffic(bench.ElasticMarmousi.name, "adjoint+imaging", cells)
+    with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+        ref = json.load(fh)[bench.ElasticMarmousi.name]["adjoint+imaging"]["bytes_per_cell_step"]
+    assert t == ref * cells and bench.measured_traffic("no_such_workload", "x", 1) is None
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    with open(os.path.join(ROOT, "profiles", "r01_bench_default_output.json")) as fh:
+        d = json.load(fh)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["config"]["workload"] == bench.AcousticMarmousi.name and "model" not in d["config"]
+    assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "C oracle" in c["sample"]
+    # whole-job throughput = cells*steps of all shots / wall time
+    wl = bench.AcousticMarmousi
+    units = wl.nz * wl.nx * wl.nt * wl.shots_per_gpu * d["steps"]
+    assert abs(d["value"] - units / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6) <= 1e-6 * d["value"]
