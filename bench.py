@@ -113,6 +113,13 @@ class AcousticMarmousi:
             self._ev = getattr(self, "_ev", []) + [ev]
         return self.vp.grad, loss
 
+    def kernel_family(self):
+        from physicsbasedfwi2_amd.acoustic import AcousticPlan
+        P = self.pml
+        nw = AcousticPlan(self.nz + 2 * P, self.nx + 2 * P, self.nt, self.ns, 1, self.nx, 1, 1.0, 1.0,
+                          self.dev.index or 0).cluster_slabs()
+        return "single-launch time loop, %d row slabs per shot" % nw if nw else "one launch per step"
+
     def kernel_times(self):
         """avg per-launch duration (s) of the forward(+save) and adjoint(+imaging) kernels from
         the HIP events recorded on the launch stream around the two time loops."""
@@ -242,6 +249,14 @@ class ElasticMarmousi:
             self._ev.append(ev)
         return torch.stack([p.grad for p in self.prm]), loss
 
+    def kernel_family(self):
+        from physicsbasedfwi2_amd.elastic import ElasticPlan
+        pl = ElasticPlan(self.nz, self.nx, self.nt, self.ns, 1, self.nrec, 1, self.pml, self.dev.index or 0)
+        f, a = pl.cluster_slabs(False), pl.cluster_slabs(True)
+        return "forward: %s; adjoint: %s" % tuple(
+            "single-launch time loop, %d row slabs per shot" % n if n else "one launch per half step"
+            for n in (f, a))
+
     def kernel_times(self):
         """avg duration (s) of one forward step (V+S launches) and one adjoint step (S^T+V^T)."""
         tf = np.mean([e[0].elapsed_time(e[1]) for e in self._ev]) * 1e-3
@@ -357,7 +372,8 @@ def run_workload(name, args, dev, rank, world, want_cpu):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": wl.name, "shots_per_gpu": wl.ns, "nt": wl.nt,
-                   "grid": [wl.nz, wl.nx], "parallelism": "shots x%d" % world},
+                   "grid": [wl.nz, wl.nx], "parallelism": "shots x%d" % world,
+                   "kernel_family": wl.kernel_family()},
         "roofline": {"bound": "hbm", "kernel": dom,
                      "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS,

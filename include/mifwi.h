@@ -185,6 +185,12 @@ int mifwi_elastic_backward(mifwi_elastic_plan *plan, const float *mat, const flo
                            float *grad_mat, float *grad_f, float *work, int32_t n_hi, int32_t n_lo,
                            int32_t flags, void *stream);
 
+/* Which kernel family a plan selected: the number of row slabs a shot is cut
+ * into by the single-launch "cluster" time loop, or 0 when the plan runs one launch per (half)
+ * step.  `adjoint` = 0 asks about the forward loop, 1 about the adjoint loop.                  */
+int mifwi_acoustic_plan_cluster_slabs(const mifwi_acoustic_plan *plan, int32_t adjoint);
+int mifwi_elastic_plan_cluster_slabs(const mifwi_elastic_plan *plan, int32_t adjoint);
+
 /* ======================================================================================
  * Fused data MISFIT + adjoint source (what sits between the propagator call and .backward())
  *

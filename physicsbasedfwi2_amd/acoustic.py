@@ -35,6 +35,10 @@ class AcousticPlan:
     def handle(self):
         return self._h
 
+    def cluster_slabs(self, adjoint=False):
+        """Row slabs per shot of the single-launch time loop (0: one launch per step)."""
+        return int(self._lib.mifwi_acoustic_plan_cluster_slabs(self._h, int(bool(adjoint))))
+
     def close(self):
         if self._h:
             self._lib.mifwi_acoustic_plan_destroy(self._h)

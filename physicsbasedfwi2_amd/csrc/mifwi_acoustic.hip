@@ -942,7 +942,8 @@ void cluster_setup(mifwi_acoustic_plan *pl)
     pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * pl->NW * 8 * pl->gp + 64, 64);   // granules + err word
     pl->list_elems = mifwi::round_up64((long long)pl->d.nshot * pl->NW * (1 + (long long)pl->d.nrec), 64);
     for (const void *fn : {(const void *)ac_cluster<0>, (const void *)ac_cluster<1>, (const void *)ac_cluster<2>})
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pl->cl_lds) != hipSuccess) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mifwi::kClusterLdsLimit) != hipSuccess) {
+            (void)hipGetLastError();           // not sticky: the plan simply uses one launch per step
             pl->cluster = 0;
             return;
         }
@@ -1041,6 +1042,12 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
     }
     *plan = pl;
     return MIFWI_OK;
+}
+
+int mifwi_acoustic_plan_cluster_slabs(const mifwi_acoustic_plan *plan, int32_t adjoint)
+{
+    (void)adjoint;                       // one slab count serves both loops
+    return plan && plan->cluster ? plan->NW : 0;
 }
 
 int mifwi_acoustic_plan_destroy(mifwi_acoustic_plan *plan)

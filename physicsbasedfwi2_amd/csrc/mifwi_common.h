@@ -43,6 +43,11 @@ inline int check_device(int device)
     return MIFWI_OK;
 }
 
+// Dynamic-LDS ceiling requested for every cluster kernel.  The attribute is per function, not per
+// plan: plans of different grids coexist (forward of one model, backward of another), so each
+// plan asks for the common cap and passes its own (smaller) size at launch.
+constexpr int kClusterLdsLimit = 150 * 1024;      // = the eligibility bound of every cluster plan
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

@@ -848,8 +848,10 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
     if (pl->cluster) {
         for (const void *fn : {(const void *)el_cluster_fwd<false, 1>, (const void *)el_cluster_fwd<true, 1>,
                                (const void *)el_cluster_fwd<false, 2>, (const void *)el_cluster_fwd<true, 2>})
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pl->cl_lds) != hipSuccess)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mifwi::kClusterLdsLimit) != hipSuccess) {
+                (void)hipGetLastError();       // not sticky: fall back to one launch per half step
                 pl->cluster = 0;
+            }
     }
     // adjoint: four E/D planes + the adjoint memory variables of the slab's C-PML cells in LDS; the
     // gradient accumulators are per shot, so it needs shot groups of one (not used when the caller
@@ -880,8 +882,10 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
         }
         if (pl->cl_adj)
             for (const void *fn : {(const void *)el_cluster_adj<1>, (const void *)el_cluster_adj<2>})
-                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pl->adj_lds) != hipSuccess)
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mifwi::kClusterLdsLimit) != hipSuccess) {
+                    (void)hipGetLastError();
                     pl->cl_adj = 0;
+                }
     }
     const int nwmax = std::max(pl->cluster ? pl->NW : 0, pl->cl_adj ? pl->adj_NW : 0);
     if (nwmax > 0) pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * nwmax * 4 * kEcRowFields * pl->gp + 64, 64);
@@ -978,6 +982,12 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     }
     *plan = pl;
     return MIFWI_OK;
+}
+
+int mifwi_elastic_plan_cluster_slabs(const mifwi_elastic_plan *plan, int32_t adjoint)
+{
+    if (!plan) return 0;
+    return adjoint ? (plan->cl_adj ? plan->adj_NW : 0) : (plan->cluster ? plan->NW : 0);
 }
 
 int mifwi_elastic_plan_destroy(mifwi_elastic_plan *plan)

@@ -34,6 +34,23 @@ def _elastic(case, need_grad=True):
     return mat, f, rvx, rvz
 
 
+def test_plans_select_the_single_launch_family_on_the_reference_grids(monkeypatch):
+    """A silent fall-back to one launch per step would keep every parity test green: check the
+    selection itself (C2 with its sponge, C3, the 170x396 and 190x324 elastic grids)."""
+    from physicsbasedfwi2_amd.acoustic import AcousticPlan
+    from physicsbasedfwi2_amd.elastic import ElasticPlan
+    assert AcousticPlan(214, 540, 100, 29, 1, 500, 1, 1.0, 1.0, 0).cluster_slabs() >= 1
+    assert AcousticPlan(214, 540, 100, 29, 1, 500, 4, 1.0, 1.0, 0).cluster_slabs() == 0   # bilinear taps
+    for nz, nx in ((100, 300), (150, 294), (170, 396), (190, 324)):
+        pl = ElasticPlan(nz, nx, 100, 6, 1, 200, 1, 10, 0)
+        assert pl.cluster_slabs(False) >= 1 and pl.cluster_slabs(True) >= 1, (nz, nx)
+    assert ElasticPlan(400, 1974, 10, 2, 1, 200, 1, 10, 0).cluster_slabs(False) == 0
+    monkeypatch.setenv("MIFWI_EL_CLUSTER", "0")
+    monkeypatch.setenv("MIFWI_EL_CLUSTER_ADJ", "0")
+    pl = ElasticPlan(100, 300, 100, 6, 1, 200, 1, 10, 0)
+    assert pl.cluster_slabs(False) == 0 and pl.cluster_slabs(True) == 0
+
+
 def test_c2_acoustic_both_kernel_families_agree_and_are_deterministic(monkeypatch):
     case = acoustic_case(seed=41, n0=174, n1=500, nb=20, nt=300, ns=29, nrec=500)
     outs = []
@@ -99,3 +116,30 @@ def test_c3_elastic_adjoint_dot_product_identity():
     lhs = float((rvx.detach().double() * gx.double()).sum() + (rvz.detach().double() * gz.double()).sum())
     rhs = float((f.detach().double() * f.grad.double()).sum())
     assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs))
+
+
+def test_interleaved_plans_of_different_grids():
+    """forward A, forward B, backward A, backward B with different LDS footprints: the dynamic-LDS
+    attribute of the cluster kernels is per function, so one plan must not shrink it for another."""
+    big = acoustic_case(seed=61, n0=120, n1=300, nb=12, nt=80, ns=3, nrec=40)
+    small = acoustic_case(seed=62, n0=30, n1=40, nb=6, nt=80, ns=2, nrec=9)
+    ref = {}
+    for name, case in (("big", big), ("small", small)):
+        r, f, rec = _acoustic(case)
+        rec.backward(torch.sign(rec.detach()))
+        ref[name] = (rec.detach().clone(), r.grad.clone())
+    ra, fa, reca = _acoustic(big)
+    rb, fb, recb = _acoustic(small)
+    reca.backward(torch.sign(reca.detach()))
+    recb.backward(torch.sign(recb.detach()))
+    assert torch.equal(reca.detach(), ref["big"][0]) and torch.equal(ra.grad, ref["big"][1])
+    assert torch.equal(recb.detach(), ref["small"][0]) and torch.equal(rb.grad, ref["small"][1])
+    ecase_a = elastic_case(seed=63, nz=90, nx=300, fw=10, ns=2, nrec=30, nt=60)
+    ecase_b = elastic_case(seed=64, nz=40, nx=60, fw=6, ns=2, nrec=9, nt=60)
+    ma, _, ax, az = _elastic(ecase_a)
+    mb, _, bx, bz = _elastic(ecase_b)
+    torch.autograd.backward([ax, az], [torch.sign(ax.detach()), torch.sign(az.detach())])
+    torch.autograd.backward([bx, bz], [torch.sign(bx.detach()), torch.sign(bz.detach())])
+    ma2, _, ax2, az2 = _elastic(ecase_a)
+    torch.autograd.backward([ax2, az2], [torch.sign(ax2.detach()), torch.sign(az2.detach())])
+    assert torch.equal(ax, ax2) and torch.equal(ma.grad, ma2.grad)
