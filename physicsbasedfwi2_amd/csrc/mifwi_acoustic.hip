@@ -1009,6 +1009,9 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
     if (d->ntap != 1 && d->ntap != 4) return mifwi::fail(MIFWI_EINVAL, "ntap must be 1 or 4");
     int rc = mifwi::check_device(device);
     if (rc) return rc;
+    // function attributes and CU counts queried during set-up belong to THIS device (one process per
+    // GPU sees all eight devices)
+    MIFWI_HIP_TRY(hipSetDevice(device));
     mifwi_acoustic_plan *pl = new mifwi_acoustic_plan;
     pl->d = *d;
     pl->device = device;

@@ -935,6 +935,9 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     if (d->pml_width < 0) return mifwi::fail(MIFWI_EINVAL, "pml_width < 0");
     int rc = mifwi::check_device(device);
     if (rc) return rc;
+    // function attributes and CU counts queried during set-up belong to THIS device (one process per
+    // GPU sees all eight devices)
+    MIFWI_HIP_TRY(hipSetDevice(device));
     mifwi_elastic_plan *pl = new mifwi_elastic_plan;
     pl->d = *d;
     pl->device = device;
