@@ -397,6 +397,10 @@ def main():
     ap.add_argument("--shots", type=int, default=0, help="override shots per GPU (debug only)")
     ap.add_argument("--grid", default="", help="NZxNX override for the elastic workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1 (gloo: rehearsal of the multi-rank path)")
+    ap.add_argument("--device-index", type=int, default=-1,
+                    help="HIP device of this rank (default LOCAL_RANK; rehearsals put every rank on 0)")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the secondary (elastic) workload of the default invocation")
     args = ap.parse_args()
@@ -410,10 +414,15 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    if args.device_index >= 0:
+        local = args.device_index
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     want_cpu = (not args.no_cpu_baseline) and world == 1
     primary = args.workload or "acoustic_marmousi"
