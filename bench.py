@@ -343,11 +343,18 @@ def run_workload(name, args, dev, rank, world, want_cpu):
     for _ in range(args.warmup):
         one_step(False)
     barrier()
+    losses, gsums = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step(True)
+        grad, loss = one_step(True)
+        losses.append(loss.detach())            # device scalars: no sync inside the timed region
+        gsums.append(grad.detach().double().abs().sum())
     barrier()
     el = time.perf_counter() - t0
+    # same inputs every step: the gradient pass must reproduce itself bit for bit
+    losses = [float(v) for v in losses]
+    gsums = [float(v) for v in gsums]
+    deterministic = all(v == losses[0] for v in losses) and all(v == gsums[0] for v in gsums)
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -374,6 +381,7 @@ def run_workload(name, args, dev, rank, world, want_cpu):
         "config": {"workload": wl.name, "shots_per_gpu": wl.ns, "nt": wl.nt,
                    "grid": [wl.nz, wl.nx], "parallelism": "shots x%d" % world,
                    "kernel_family": wl.kernel_family()},
+        "check": {"loss": losses[0], "grad_abs_sum": gsums[0], "bitwise_repeatable": deterministic},
         "roofline": {"bound": "hbm", "kernel": dom,
                      "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS,
@@ -431,7 +439,7 @@ def main():
         # the north-star roofline target is stated on the elastic stencil: report it alongside
         also = run_workload("elastic_marmousi", args, dev, rank, world, want_cpu)
         if rank == 0:
-            out["also"] = [{k: also[k] for k in ("config", "value", "unit", "ms_per_step",
+            out["also"] = [{k: also[k] for k in ("config", "value", "unit", "ms_per_step", "check",
                                                  "roofline", "kernels", "cpu_baseline")
                             if k in also}]
     if rank == 0:

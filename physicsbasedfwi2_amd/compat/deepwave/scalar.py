@@ -53,6 +53,30 @@ def _upsample(f, ratio):
     return torch.fft.irfft(out, n=n_up, dim=0) * ratio
 
 
+class _EdgePad(torch.autograd.Function):
+    """Edge-replicating pad of a [nz, nx] model by P cells.  torch's replicate-pad backward sums the
+    layer's gradient into the edge cells with atomics (run-to-run different rounding); this one folds
+    the layer in with ordered slice sums, so the model gradient is bit-for-bit repeatable."""
+
+    @staticmethod
+    def forward(ctx, x, P):
+        ctx.P = P
+        return F.pad(x[None, None], (P, P, P, P), mode="replicate")[0, 0] if P > 0 else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        P = ctx.P
+        if P == 0:
+            return g, None
+        rows = g[P:-P].clone()
+        rows[0] += g[:P].sum(dim=0)
+        rows[-1] += g[-P:].sum(dim=0)
+        out = rows[:, P:-P].clone()
+        out[:, 0] += rows[:, :P].sum(dim=1)
+        out[:, -1] += rows[:, -P:].sum(dim=1)
+        return out, None
+
+
 @functools.lru_cache(maxsize=32)
 def _sponge(n, width, d, h, dt, device):
     """Damping profile of one axis as a device tensor (a new Propagator is built every iteration,
@@ -88,7 +112,7 @@ class Propagator(torch.nn.Module):
         ratio = max(1, int(math.ceil(abs(dt) / dt_max - 1e-9)))
         dti = dt / ratio
 
-        vp_pad = F.pad(vp[None, None].float(), (P, P, P, P), mode="replicate")[0, 0]
+        vp_pad = _EdgePad.apply(vp.float(), P)
         n0, n1 = vp_pad.shape
         r = (vp_pad * (dti / h)) ** 2
         f = source_amplitudes.to(device=dev, dtype=torch.float32) * (h * h)
