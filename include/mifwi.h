@@ -107,6 +107,18 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *plan, const float *r, const floa
                            float *rec_out, float *snap, float *work, int32_t n_begin,
                            int32_t n_end, int32_t flags, void *stream);
 
+/* Born / linearised modelling (seisgan/fwi/pde/seismic/acoustic/operators.py:168-207,
+ * wavesolver.py:174-209): first-order change of the seismograms, drec = J dr, around the forward
+ * run whose snapshots are passed in.  The perturbation field obeys the forward recursion with the
+ * distributed source G^n dr and no point source; J is the exact transpose partner of the gradient
+ * mifwi_acoustic_backward returns (<J dr, g> = <dr, grad_r(g)>).
+ *   dr [n0][gp] perturbation of r;  snap as written by mifwi_acoustic_forward (step n at
+ *   snap + (n-snap_first)*nshot*n0*gp);  drec_out [nt][nshot][nrec];  work = work_forward_elems   */
+int mifwi_acoustic_born(mifwi_acoustic_plan *plan, const float *r, const float *q0, const float *q1,
+                        const float *dr, const int32_t *rec_cell, const float *rec_w, const float *snap,
+                        int32_t snap_first, float *drec_out, float *work, int32_t n_begin, int32_t n_end,
+                        int32_t flags, void *stream);
+
 /* Exact discrete adjoint + imaging for k = k_hi down to k_lo (a full run is k_hi = nt-1,
  * k_lo = 1 with MIFWI_ZERO_STATE | MIFWI_FINALIZE).  Step k needs snapshot G^{k-1}, found at
  * snap + (k-1-snap_first)*nshot*n0*gp.

@@ -86,6 +86,23 @@ class Oracle:
             raise MemoryError("oracle_acoustic_forward failed")
         return (rec, G) if save else rec
 
+    def acoustic_born(self, r, q0, q1, dr, G, rec_cell, rec_w, c0=1.0, c1=1.0):
+        """Linearised seismograms J dr [nt,ns,nrec] for a perturbation dr [n0,n1] of r, around the
+        forward run that produced G [nt,ns,n0,n1]."""
+        r = self._r(r); q0 = self._r(q0); q1 = self._r(q1); dr = self._r(dr); G = self._r(G)
+        rec_cell = self._i(rec_cell); rec_w = self._r(rec_w)
+        n0, n1 = r.shape
+        nt, ns = G.shape[0], G.shape[1]
+        nrec, ntap = rec_cell.shape[1], rec_cell.shape[2]
+        cfg = self.AcCfg(n0, n1, nt, ns, 0, nrec, ntap, c0, c1)
+        out = np.zeros((nt, ns, nrec), dtype=self.dtype)
+        st = self.lib.oracle_acoustic_born(ctypes.byref(cfg), self._p(r), self._p(q0), self._p(q1),
+                                           self._p(dr), self._p(G), self._p(rec_cell), self._p(rec_w),
+                                           self._p(out))
+        if st != 0:
+            raise MemoryError("oracle_acoustic_born failed")
+        return out
+
     def acoustic_backward(self, r, q0, q1, src_cell, src_w, rec_cell, rec_w, g, G,
                           c0=1.0, c1=1.0, want_grad_f=True):
         r = self._r(r); q0 = self._r(q0); q1 = self._r(q1); g = self._r(g); G = self._r(G)

@@ -230,4 +230,50 @@ int oracle_acoustic_backward(const oracle_acoustic_cfg *c, const real *r, const 
     return status;
 }
 
+/* Born / linearised modelling (seisgan/fwi/pde/seismic/acoustic/operators.py:168-207,
+ * wavesolver.py:174-209): the first-order change of the seismograms for a model perturbation.
+ * Differentiating the recursion above with respect to r gives the SAME recursion for du with the
+ * distributed source  G^n * dr  (G^n = d u^{n+1}/d r, saved by the forward pass) and no point source:
+ *   drec[n] = R du^n ;   du^{n+1} = step(du^n, du^{n-1}) + G^n dr.
+ * dr [n0][n1];  G [nt][nshot][n0][n1];  drec_out [nt][nshot][nrec].
+ * It is the exact transpose partner of oracle_acoustic_backward:  <J dr, g> = <dr, grad_r(g)>.     */
+int oracle_acoustic_born(const oracle_acoustic_cfg *c, const real *r, const real *q0, const real *q1,
+                         const real *dr, const real *G, const int *rec_cell, const real *rec_w,
+                         real *drec_out)
+{
+    const int n0 = c->n0, n1 = c->n1, ns = c->nshot;
+    const size_t ncell = (size_t)n0 * n1;
+    const size_t npad = (size_t)(n0 + 2 * HALO) * (n1 + 2 * HALO);
+    int status = 0;
+#pragma omp parallel for schedule(dynamic)
+    for (int s = 0; s < ns; ++s) {
+        real *ua = (real *)calloc(npad, sizeof(real));
+        real *ub = (real *)calloc(npad, sizeof(real));
+        if (!ua || !ub) { status = 1; free(ua); free(ub); continue; }
+        real *ucur = ua, *uprev = ub;
+        for (int n = 0; n < c->nt; ++n) {
+            for (int ir = 0; ir < c->nrec; ++ir) {
+                real acc = 0;
+                for (int t = 0; t < c->ntap; ++t) {
+                    const size_t e = ((size_t)s * c->nrec + ir) * c->ntap + t;
+                    const int cell = rec_cell[e];
+                    if (cell >= 0) acc = FMA(rec_w[e], ucur[pidx(c, cell / n1, cell % n1)], acc);
+                }
+                drec_out[((size_t)n * ns + s) * c->nrec + ir] = acc;
+            }
+            step_shot(c, r, q0, q1, ucur, uprev, NULL);
+            const real *Gn = G + ((size_t)n * ns + s) * ncell;
+            for (int i0 = 0; i0 < n0; ++i0)
+                for (int i1 = 0; i1 < n1; ++i1) {
+                    const size_t cidx = (size_t)i0 * n1 + i1;
+                    const size_t k = pidx(c, i0, i1);
+                    uprev[k] = FMA(dr[cidx], Gn[cidx], uprev[k]);
+                }
+            real *tmp = ucur; ucur = uprev; uprev = tmp;
+        }
+        free(ua); free(ub);
+    }
+    return status;
+}
+
 int oracle_real_bytes(void) { return (int)sizeof(real); }

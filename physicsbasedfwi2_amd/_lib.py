@@ -69,6 +69,7 @@ SIGNATURES = {
     "mifwi_elastic_forward": (ctypes.c_int, [_P] * 13 + [ctypes.c_int32] * 3 + [_P]),
     "mifwi_elastic_backward": (ctypes.c_int, [_P] * 11 + [ctypes.c_int32] + [_P] * 3 +
                                [ctypes.c_int32] * 3 + [_P]),
+    "mifwi_acoustic_born": (ctypes.c_int, [_P] * 8 + [ctypes.c_int32] + [_P] * 2 + [ctypes.c_int32] * 3 + [_P]),
     "mifwi_acoustic_plan_cluster_slabs": (ctypes.c_int, [_P, ctypes.c_int32]),
     "mifwi_elastic_plan_cluster_slabs": (ctypes.c_int, [_P, ctypes.c_int32]),
     "mifwi_misfit_work_elems": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64]),

@@ -221,3 +221,53 @@ def propagate(r, f, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
     f = f.to(device=r.device)
     return _AcousticFn.apply(r, f, q0, q1, geom, float(c0), float(c1), int(shots_per_group),
                              int(snapshot_budget))
+
+
+def born(r, f, dr, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
+         snapshot_budget=DEFAULT_SNAPSHOT_BUDGET):
+    """Born / linearised modelling (``AcousticWaveSolver.born``, wavesolver.py:174-209;
+    ``BornOperator``, operators.py:168-207): returns ``(rec, drec)`` where ``rec`` are the seismograms
+    of the background model ``r`` and ``drec = J dr`` their first-order change for the perturbation
+    ``dr`` (same parametrisation and shape as ``r``).  ``J`` is the exact transpose partner of the
+    gradient autograd returns for :func:`propagate`.  No autograd through this call."""
+    _require_cuda(r, "r")
+    dev = r.device
+    lib = _lib.load()
+    geom = _Geometry(src_cell, src_w, rec_cell, rec_w, dev)
+    n0, n1 = r.shape
+    nt, ns, nsrc = f.shape
+    nrec, ntap = geom.rec_cell.shape[1], geom.rec_cell.shape[2]
+    if tuple(dr.shape) != (n0, n1):
+        raise MifwiError("dr must have the shape of r")
+    tops = [c.max() for c in (geom.src_cell, geom.rec_cell) if c.numel()]
+    if tops and int(torch.stack(tops).max()) >= n0 * n1:
+        raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (n0, n1))
+    with torch.cuda.device(dev), torch.no_grad():
+        plan = AcousticPlan(n0, n1, nt, ns, nsrc, nrec, ntap, float(c0), float(c1), dev.index, 0)
+        lay = plan.layout
+        gp = lay.gp
+        if 4 * nt * ns * lay.coef_elems > snapshot_budget:
+            plan.close()
+            raise MifwiError("born() keeps the forward snapshots resident: %d steps do not fit the budget" % nt)
+        r_p = torch.zeros((n0, gp), device=dev, dtype=torch.float32)
+        r_p[:, :n1] = r.detach()
+        dr_p = torch.zeros((n0, gp), device=dev, dtype=torch.float32)
+        dr_p[:, :n1] = dr.detach().to(dev)
+        q0_d = q0.to(device=dev, dtype=torch.float32).contiguous()
+        q1_p = torch.zeros(gp, device=dev, dtype=torch.float32)
+        q1_p[:n1] = q1.to(device=dev, dtype=torch.float32)
+        f_d = f.detach().to(device=dev, dtype=torch.float32).contiguous()
+        rec = torch.empty((nt, ns, nrec), device=dev, dtype=torch.float32)
+        drec = torch.empty((nt, ns, nrec), device=dev, dtype=torch.float32)
+        work = torch.empty(lay.work_forward_elems, device=dev, dtype=torch.float32)
+        snap = torch.empty((nt, ns, n0, gp), device=dev, dtype=torch.float32)
+        _lib.check(lib.mifwi_acoustic_forward(plan.handle, _lib.ptr(r_p), _lib.ptr(q0_d), _lib.ptr(q1_p),
+                                              _lib.ptr(f_d), _lib.ptr(geom.src_cell), _lib.ptr(geom.src_w),
+                                              _lib.ptr(geom.rec_cell), _lib.ptr(geom.rec_w), _lib.ptr(rec),
+                                              _lib.ptr(snap), _lib.ptr(work), 0, nt, _lib.ZERO_STATE, _stream()))
+        _lib.check(lib.mifwi_acoustic_born(plan.handle, _lib.ptr(r_p), _lib.ptr(q0_d), _lib.ptr(q1_p),
+                                           _lib.ptr(dr_p), _lib.ptr(geom.rec_cell), _lib.ptr(geom.rec_w),
+                                           _lib.ptr(snap), 0, _lib.ptr(drec), _lib.ptr(work), 0, nt,
+                                           _lib.ZERO_STATE, _stream()))
+        plan.close()
+    return rec, drec

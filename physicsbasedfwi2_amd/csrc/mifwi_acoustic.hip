@@ -41,6 +41,7 @@ struct AcParams {
     float *prev;                 // u^{n-1} -> u^{n+1}
     float *G;                    // snapshot slice of this step [nshot][n0][gp] (SAVE: w, IMAGE: r)
     float *acc;                  // [ngroups][n0][gp]
+    const float *born_dr;        // Born pass (IMAGE launches only): [n0][gp] model perturbation, or NULL
     // injection into the new field
     int ninj, ntap_inj, inj_mode;    // mode 0: += a*r, G += a ; mode 1: += a*r*inv
     const int *inj_cell;
@@ -121,8 +122,9 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
                 rr[rz] = *reinterpret_cast<const float4 *>(p.r + (long long)j * p.gp + 4 * g);
                 q0v[rz] = p.q0[j];
                 if (IMAGE)
-                    acc[rz] = *reinterpret_cast<const float4 *>(
-                        p.acc + ((long long)blockIdx.z * p.n0 + j) * p.gp + 4 * g);
+                    acc[rz] = p.born_dr ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                        : *reinterpret_cast<const float4 *>(
+                                              p.acc + ((long long)blockIdx.z * p.n0 + j) * p.gp + 4 * g);
             } else {
                 rr[rz] = make_float4(0.f, 0.f, 0.f, 0.f);
                 q0v[rz] = 0.f;
@@ -183,10 +185,12 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
                     const float2 R = *reinterpret_cast<const float2 *>(rowp + 4);
                     float *prow = prev + (long long)(j + 2) * p.pitch + col;
                     const float4 up = *reinterpret_cast<const float4 *>(prow);
-                    float4 Gv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 Gv = make_float4(0.f, 0.f, 0.f, 0.f), drv = Gv;
                     if (IMAGE)
                         Gv = *reinterpret_cast<const float4 *>(
                             p.G + ((long long)s * p.n0 + j) * p.gp + 4 * g);
+                    if (IMAGE && p.born_dr)
+                        drv = *reinterpret_cast<const float4 *>(p.born_dr + (long long)j * p.gp + 4 * g);
                     const float xs[8] = {L.x, L.y, w2.x, w2.y, w2.z, w2.w, R.x, R.y};
                     float un[4], gk[4];
 #pragma unroll
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
                                 v += a * (rv * inv);
                             }
                         }
+                        if (IMAGE && p.born_dr) v = fmaf(comp(drv, c), comp(Gv, c), v);   // Born source G^n dr
                         if (4 * g + c >= p.n1) v = 0.f;     // keep the right halo at zero
                         un[c] = v;
                     }
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
                         *reinterpret_cast<float4 *>(p.G + ((long long)s * p.n0 + j) * p.gp +
                                                     4 * g) =
                             make_float4(gk[0], gk[1], gk[2], gk[3]);
-                    if (IMAGE) {
+                    if (IMAGE && !p.born_dr) {
                         acc[rz].x = fmaf(un[0], Gv.x, acc[rz].x);
                         acc[rz].y = fmaf(un[1], Gv.y, acc[rz].y);
                         acc[rz].z = fmaf(un[2], Gv.z, acc[rz].z);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
         if (has_inj) __syncthreads();               // LDS image is reused by the next shot
     }
 
-    if (IMAGE && active) {
+    if (IMAGE && active && !p.born_dr) {
 #pragma unroll
         for (int rz = 0; rz < RZ; ++rz) {
             const int j = j0 + rz;
@@ -337,6 +342,7 @@ struct ClParams {
     int g_first;
     long long g_step;
     float *acc;                  // adjoint: [nshot][n0][gp]
+    const float *born_dr;        // Born pass (MODE 3): [n0][gp] model perturbation
     // few-point list handled by the cell owners (forward: sources -> injection + G term)
     int nsrc, ntap;
     const int *src_cell;
@@ -456,7 +462,7 @@ __device__ __forceinline__ int cl_opaque(int x)
     return x;
 }
 
-template <int MODE>   // 0: forward, 1: forward + snapshots, 2: adjoint + imaging
+template <int MODE>   // 0: forward, 1: forward + snapshots, 2: adjoint + imaging, 3: Born (source G^n dr)
 __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -503,6 +509,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             const float q0 = p.q0[j];
             if (q0 != 0.f || q1.x != 0.f || q1.y != 0.f || q1.z != 0.f || q1.w != 0.f) dampmask |= 1u << i;
             if (adj) acc[i] = *reinterpret_cast<const float4 *>(p.acc + ((long long)s * p.n0 + j) * p.gp + 4 * g);
+            if (MODE == 3) acc[i] = *reinterpret_cast<const float4 *>(p.born_dr + (long long)j * p.gp + 4 * g);
         }
     }
     // ---- per-thread sparse points (at most one of each kind per thread in this path) ------------
@@ -642,7 +649,10 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             if (src_slot >= 0) amp_next = (p.f + ((long long)n_ * p.nshot + s) * p.nsrc)[cl_opaque(src_e)];
         } else {
             if (inj_off >= 0) amp_next = (p.grad_rec + ((long long)n_ * p.nshot + s) * p.nrec)[cl_opaque(inj_id)];
-            const float *Gq = p.G + (long long)((n_ - 1) - p.g_first) * p.g_step + plane;
+        }
+        if (adj || MODE == 3) {
+            // adjoint: G^{n-1} for the imaging condition; Born: G^n, the source term of this step
+            const float *Gq = p.G + (long long)((adj ? n_ - 1 : n_) - p.g_first) * p.g_step + plane;
 #pragma unroll
             for (int i = 0; i < kClMaxNG; ++i)
                 if (i < nown) Gbuf[i] = *reinterpret_cast<const float4 *>(Gq + goff_of(cl_opaque(jg[i])));
@@ -728,6 +738,10 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                                 if (cc == (i1 & 3)) { un[cc] += a * comp(rr[i], cc); if (MODE == 1) gk[cc] += a; }
                         }
                     }
+                }
+                if (MODE == 3) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) un[cc] = fmaf(comp(acc[i], cc), comp(Gbuf[i], cc), un[cc]);
                 }
                 *reinterpret_cast<float4 *>(prv + lo_i) = make_float4(un[0], un[1], un[2], un[3]);
                 if (MODE == 1) Gbuf[i] = make_float4(gk[0], gk[1], gk[2], gk[3]);
@@ -941,7 +955,8 @@ void cluster_setup(mifwi_acoustic_plan *pl)
     if (!pl->cluster) return;
     pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * pl->NW * 8 * pl->gp + 64, 64);   // granules + err word
     pl->list_elems = mifwi::round_up64((long long)pl->d.nshot * pl->NW * (1 + (long long)pl->d.nrec), 64);
-    for (const void *fn : {(const void *)ac_cluster<0>, (const void *)ac_cluster<1>, (const void *)ac_cluster<2>})
+    for (const void *fn : {(const void *)ac_cluster<0>, (const void *)ac_cluster<1>, (const void *)ac_cluster<2>,
+                           (const void *)ac_cluster<3>})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mifwi::kClusterLdsLimit) != hipSuccess) {
             (void)hipGetLastError();           // not sticky: the plan simply uses one launch per step
             pl->cluster = 0;
@@ -1126,6 +1141,51 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *pl, const float *r, const float 
         } else {
             launch_step<false, false>(pl, p, st);
         }
+    }
+    MIFWI_HIP_TRY(hipGetLastError());
+    return MIFWI_OK;
+}
+
+int mifwi_acoustic_born(mifwi_acoustic_plan *pl, const float *r, const float *q0, const float *q1,
+                        const float *dr, const int32_t *rec_cell, const float *rec_w, const float *snap,
+                        int32_t snap_first, float *drec_out, float *work, int32_t n_begin, int32_t n_end,
+                        int32_t flags, void *stream)
+{
+    if (!pl || !r || !q0 || !q1 || !dr || !snap || !work || !drec_out || !rec_cell || !rec_w)
+        return mifwi::fail(MIFWI_EINVAL, "null argument");
+    const mifwi_acoustic_desc &d = pl->d;
+    if (n_begin < 0 || n_end > d.nt || n_begin > n_end)
+        return mifwi::fail(MIFWI_EINVAL, "bad step range [%d,%d) for nt=%d", n_begin, n_end, d.nt);
+    if (snap_first > n_begin)
+        return mifwi::fail(MIFWI_EINVAL, "snapshots start at step %d but step %d is needed", snap_first, n_begin);
+    int rc = mifwi::check_device(pl->device);
+    if (rc) return rc;
+    MIFWI_HIP_TRY(hipSetDevice(pl->device));
+    hipStream_t st = (hipStream_t)stream;
+    float *ua = work, *ub = work + pl->field_elems;
+    if (flags & MIFWI_ZERO_STATE)
+        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * 2 * pl->field_elems, st));
+    const long long snap_step = (long long)d.nshot * pl->coef_elems;
+    if (pl->cluster && n_end > n_begin) {
+        float *xbuf = work + 2 * pl->field_elems + mifwi::round_up64(4LL * d.nshot, 64);
+        ClParams c = cluster_params(pl, r, q0, q1, ua, ub, xbuf);
+        c.n_first = n_begin; c.n_last = n_end;
+        c.nsrc = 0; c.src_cell = nullptr; c.src_w = nullptr; c.f = nullptr;      // no point source
+        c.rec_cell = rec_cell; c.rec_w = rec_w; c.rec_out = d.nrec > 0 ? drec_out : nullptr;
+        c.G = const_cast<float *>(snap); c.g_first = snap_first; c.g_step = snap_step;
+        c.born_dr = dr;
+        return cluster_run<3>(pl, c, xbuf, st);
+    }
+    AcParams p = base_params(pl, r, q0, q1);
+    p.ninj = 0;
+    p.nsmp = d.nrec; p.ntap_smp = d.ntap; p.smp_mode = 0; p.smp_cell = rec_cell; p.smp_w = rec_w;
+    p.born_dr = dr;
+    for (int n = n_begin; n < n_end; ++n) {
+        p.cur = (n & 1) ? ub : ua;
+        p.prev = (n & 1) ? ua : ub;
+        p.smp_out = d.nrec > 0 ? drec_out + (long long)n * d.nshot * d.nrec : nullptr;
+        p.G = const_cast<float *>(snap) + (long long)(n - snap_first) * snap_step;
+        launch_step<false, true>(pl, p, st);
     }
     MIFWI_HIP_TRY(hipGetLastError());
     return MIFWI_OK;

@@ -199,3 +199,33 @@ def test_cluster_and_per_step_paths_agree(monkeypatch):
     assert torch.equal(outs[0][0], outs[1][0])
     assert rel_l2(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy()) <= TOL_GRAD
     assert rel_l2(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()) <= TOL_GRAD
+
+
+@pytest.mark.parametrize("family,ntap", [("1", 1), ("0", 1), ("0", 4)])
+def test_born_operator_matches_oracle_and_transposes_the_gradient(oracle32, monkeypatch, family, ntap):
+    """mifwi_acoustic_born (operators.py:168-207) in both kernel families: seismogram perturbation
+    vs the oracle, and <J dr, g> = <dr, grad_r(g)> with the gradient of the autograd path."""
+    from physicsbasedfwi2_amd import acoustic
+    monkeypatch.setenv("MIFWI_AC_CLUSTER", family)
+    if family == "1":
+        monkeypatch.setenv("MIFWI_AC_NW", "3")
+    case = acoustic_case(seed=23, n0=48, n1=70, nb=8, nt=110, ns=2, nrec=13, ntap=ntap)
+    o = oracle32
+    rng = np.random.default_rng(4)
+    dr = (rng.standard_normal(case["r"].shape) * case["r"] * 0.05).astype(np.float32)
+    rec_o, G = o.acoustic_forward(case["r"], case["q0"], case["q1"], case["f"], case["sc"], case["sw"],
+                                  case["rc"], case["rw"], case["c0"], case["c1"], save=True)
+    jdr_o = o.acoustic_born(case["r"], case["q0"], case["q1"], dr, G, case["rc"], case["rw"], case["c0"], case["c1"])
+    dev = torch.device("cuda:0")
+    args = [torch.tensor(case[k]) for k in ("q0", "q1", "sc", "sw", "rc", "rw")]
+    r_t = torch.tensor(case["r"], dtype=torch.float32, device=dev)
+    f_t = torch.tensor(case["f"], dtype=torch.float32, device=dev)
+    rec, jdr = acoustic.born(r_t, f_t, torch.tensor(dr, device=dev), *args, case["c0"], case["c1"])
+    assert rel_l2(rec.cpu().numpy(), rec_o) <= TOL_TRACE
+    assert np.abs(jdr_o).max() > 0 and rel_l2(jdr.cpu().numpy(), jdr_o) <= 2e-6
+    r2, f2, rec2 = _run_hip(case)
+    g = torch.sign(jdr) + 0.5
+    rec2.backward(g)
+    lhs = float((jdr.double() * g.double()).sum())
+    rhs = float((torch.tensor(dr, device=dev).double() * r2.grad.double()).sum())
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs))

@@ -111,6 +111,29 @@ def test_acoustic_adjoint_dot_product(oracle64):
     assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
 
 
+def test_acoustic_born_is_the_derivative_and_the_transpose_of_the_gradient(oracle64):
+    """Born operator (operators.py:168-207): J dr equals the central finite difference of the forward
+    map to O(eps^2), and <J dr, g> = <dr, J^T g> with J^T the gradient operator (operators.py:127-165)."""
+    o = oracle64
+    c = acoustic_case(seed=9, nsrc=1, ntap=4, nt=120)
+    geo = (c["sc"], c["sw"], c["rc"], c["rw"], c["c0"], c["c1"])
+    rng = np.random.default_rng(2)
+    dr = rng.standard_normal(c["r"].shape) * c["r"] * 0.05
+    rec, G = o.acoustic_forward(c["r"], c["q0"], c["q1"], c["f"], *geo, save=True)
+    jdr = o.acoustic_born(c["r"], c["q0"], c["q1"], dr, G, c["rc"], c["rw"], c["c0"], c["c1"])
+    errs = []
+    for eps in (1e-2, 1e-3):
+        fp = o.acoustic_forward(c["r"] + eps * dr, c["q0"], c["q1"], c["f"], *geo)
+        fm = o.acoustic_forward(c["r"] - eps * dr, c["q0"], c["q1"], c["f"], *geo)
+        errs.append(rel_l2((fp - fm) / (2 * eps), jdr))
+    assert np.abs(jdr).max() > 0 and errs[1] < 1e-6 and errs[0] / errs[1] > 50      # second order in eps
+    g = rng.standard_normal(rec.shape)
+    gr, _ = o.acoustic_backward(c["r"], c["q0"], c["q1"], c["sc"], c["sw"], c["rc"], c["rw"], g, G,
+                                c["c0"], c["c1"])
+    lhs, rhs = np.sum(jdr * g), np.sum(dr * gr)
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
+
+
 def test_acoustic_reciprocity(oracle64):
     o = oracle64
     c = acoustic_case(seed=8, ns=1, nrec=1, nt=160)
