@@ -65,7 +65,9 @@ typedef struct {
     int32_t ntap;          /* taps per point: 1 = nearest cell, 4 = bilinear                */
     float c0, c1;          /* (h/h0)^2, (h/h1)^2 with h = min(h0,h1)                        */
     int32_t shots_per_group; /* shots marched by one thread (gradient RMW amortisation); 0 = auto */
-    int32_t reserved;
+    int32_t edge_rows;     /* optional hint: rows of absorbing layer at the top and at the bottom
+                              (0 = unknown); lets the single-launch kernels give the layer slabs
+                              of its own.  Results do not depend on it.                       */
 } mifwi_acoustic_desc;
 
 typedef struct mifwi_acoustic_plan mifwi_acoustic_plan;

@@ -21,10 +21,10 @@ class AcousticPlan:
     """RAII wrapper of ``mifwi_acoustic_plan`` (include/mifwi.h)."""
 
     def __init__(self, n0, n1, nt, nshot, nsrc, nrec, ntap, c0, c1, device_index,
-                 shots_per_group=0):
+                 shots_per_group=0, edge_rows=0):
         self._lib = _lib.load()
         self.desc = _lib.AcousticDesc(n0, n1, nt, nshot, nsrc, nrec, ntap, c0, c1,
-                                      shots_per_group, 0)
+                                      shots_per_group, int(edge_rows))
         self._h = ctypes.c_void_p()
         _lib.check(self._lib.mifwi_acoustic_plan_create(ctypes.byref(self._h), device_index,
                                                         ctypes.byref(self.desc)))
@@ -81,7 +81,7 @@ class _Geometry:
 
 class _AcousticFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, r, f, q0, q1, geom, c0, c1, shots_per_group, snapshot_budget):
+    def forward(ctx, r, f, q0, q1, geom, c0, c1, shots_per_group, snapshot_budget, edge_rows):
         _require_cuda(r, "r")
         dev = r.device
         lib = _lib.load()
@@ -98,7 +98,7 @@ class _AcousticFn(torch.autograd.Function):
             raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (n0, n1))
         with torch.cuda.device(dev):
             plan = AcousticPlan(n0, n1, nt, ns, nsrc, nrec, ntap, c0, c1, dev.index,
-                                shots_per_group)
+                                shots_per_group, edge_rows)
             lay = plan.layout
             gp = lay.gp
             r_p = torch.zeros((n0, gp), device=dev, dtype=torch.float32)
@@ -203,24 +203,25 @@ class _AcousticFn(torch.autograd.Function):
             plan.close()
             ctx.snap = None
             ctx.ckpt = None
-        return (grad_r[:, :n1].contiguous(), grad_f, None, None, None, None, None, None, None)
+        return (grad_r[:, :n1].contiguous(), grad_f, None, None, None, None, None, None, None, None)
 
 
 def propagate(r, f, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
-              shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET):
+              shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET, edge_rows=0):
     """Run the acoustic propagator (differentiable w.r.t. ``r`` and ``f``).
 
     r   [n0,n1]  = vp^2 dt^2 / h^2 on the computational (already padded) grid
     f   [nt,nshot,nsrc] source amplitudes (the injected term is  w * f[n] * r[cell])
     q0  [n0], q1 [n1]  separable damping,  q = damp h^2 / (2 dt)
     src_cell/src_w [nshot,nsrc,ntap], rec_cell/rec_w [nshot,nrec,ntap]  (cell = i0*n1+i1)
+    edge_rows: optional hint, rows of absorbing layer at the top/bottom of the grid (performance only)
     returns rec [nt,nshot,nrec] with rec[n] sampled from u^n.
     """
     _require_cuda(r, "r")
     geom = _Geometry(src_cell, src_w, rec_cell, rec_w, r.device)
     f = f.to(device=r.device)
     return _AcousticFn.apply(r, f, q0, q1, geom, float(c0), float(c1), int(shots_per_group),
-                             int(snapshot_budget))
+                             int(snapshot_budget), int(edge_rows))
 
 
 def born(r, f, dr, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,

@@ -122,5 +122,5 @@ class Propagator(torch.nn.Module):
         sc, sw = profiles.cells_truncate(source_locations.detach(), self.spacing, P, n1)
         rc, rw = profiles.cells_truncate(receiver_locations.detach(), self.spacing, P, n1)
         rec = acoustic.propagate(r, f, q0, q1, sc, sw, rc, rw, (h / dz) ** 2, (h / dx) ** 2,
-                                 shots_per_group=self.shots_per_group)
+                                 shots_per_group=self.shots_per_group, edge_rows=P)
         return rec[::ratio] if ratio > 1 else rec

@@ -332,6 +332,7 @@ struct ClParams {
     int n0, n1, ng, gp, pitch;
     long long shot_stride;
     int nshot, NW, PL;           // slabs per shot, LDS row pitch (floats)
+    int rt;                      // rows of the first / last slab (0: even split), see slab_rows
     int shot0, shot1;            // shots [shot0, shot1) are handled by this launch
     int dbg;                     // timing experiments only: 1 = skip the halo hand-off, 2 = skip snapshots
     int nt, n_first, n_last;     // forward: steps n_first..n_last-1 ; adjoint: k = n_first down to n_last
@@ -361,28 +362,49 @@ struct ClParams {
     int *err;
 };
 
-__device__ __forceinline__ void slab_rows(int n0, int NW, int w, int &r0, int &rows)
+// Row slabs of a shot.  rt == 0: n0 rows split evenly over NW slabs.  rt > 0 (NW >= 3): the first and
+// the last slab hold rt rows each - the absorbing layer, whose cells cost an IEEE division per step -
+// and the other NW-2 slabs share the rest evenly, so that the all-sponge slabs do not set the pace.
+__host__ __device__ __forceinline__ void slab_rows(int n0, int NW, int rt, int w, int &r0, int &rows)
 {
+    if (rt > 0) {
+        if (w == 0) { r0 = 0; rows = rt; return; }
+        if (w == NW - 1) { r0 = n0 - rt; rows = rt; return; }
+        const int m = n0 - 2 * rt, k = NW - 2, v = w - 1;
+        const int base = m / k, rem = m - base * k;
+        rows = base + (v < rem ? 1 : 0);
+        r0 = rt + v * base + (v < rem ? v : rem);
+        return;
+    }
     const int base = n0 / NW, rem = n0 - base * NW;
     rows = base + (w < rem ? 1 : 0);
     r0 = w * base + (w < rem ? w : rem);
 }
 
+__host__ __device__ __forceinline__ int slab_of_row(int n0, int NW, int rt, int i0)
+{
+    int m = n0, k = NW, off = 0, first = 0;
+    if (rt > 0) {
+        if (i0 < rt) return 0;
+        if (i0 >= n0 - rt) return NW - 1;
+        m = n0 - 2 * rt; k = NW - 2; off = rt; first = 1;
+    }
+    const int base = m / k, rem = m - base * k, i = i0 - off;
+    return first + ((i < rem * (base + 1)) ? i / (base + 1) : rem + (i - rem * (base + 1)) / base);
+}
+
 // lists of the receiver taps that fall into each slab (adjoint injection), one block per shot
-__global__ void cl_build_slab_lists(const int *rec_cell, int ntaps, int n0, int n1, int NW,
+__global__ void cl_build_slab_lists(const int *rec_cell, int ntaps, int n0, int n1, int NW, int rt,
                                     int *slab_cnt, int *slab_list)
 {
     const int s = blockIdx.x;
     __shared__ int cnt[64];
     if ((int)threadIdx.x < NW) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int base = n0 / NW, rem = n0 - base * NW;
     for (int e = threadIdx.x; e < ntaps; e += blockDim.x) {
         const int cell = rec_cell[(long long)s * ntaps + e];
         if (cell < 0) continue;
-        const int i0 = cell / n1;
-        // invert slab_rows: first `rem` slabs have base+1 rows
-        int w = (i0 < rem * (base + 1)) ? i0 / (base + 1) : rem + (i0 - rem * (base + 1)) / base;
+        const int w = slab_of_row(n0, NW, rt, cell / n1);
         const int pos = atomicAdd(&cnt[w], 1);
         slab_list[((long long)s * NW + w) * ntaps + pos] = e;
     }
@@ -475,7 +497,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     const int t = (int)threadIdx.x;
     constexpr bool adj = (MODE == 2);
     int r0, R;
-    slab_rows(p.n0, p.NW, w, r0, R);
+    slab_rows(p.n0, p.NW, p.rt, w, r0, R);
     const int PL = p.PL, LR = R + 4;
     float *bufA = lds, *bufB = lds + LR * PL;     // rows: 0,1 top halo | 2..R+1 own | R+2,R+3 bottom halo
     float *ldq1 = bufB + LR * PL;                 // damping tables (constant over the run): q1[gp], q0[R]
@@ -493,13 +515,35 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     auto goff_of = [&](int jg_) { return (unsigned)((jg_ >> 12) * p.gp + 4 * (jg_ & 4095)); };
     unsigned dampmask = 0;
     int nown = 0;
+    // Group -> thread assignment.  After the boundary rows (kept in slot 0 for the early hand-off) the
+    // UNDAMPED groups come first and the damped ones (sponge cells: an IEEE division per cell and
+    // step) last, so that most waves hold one kind only and run one of the two update paths instead
+    // of both.  Which thread updates a group does not change any result.  The permutation lives in
+    // the (not yet staged) plane memory.
+    int *perm = reinterpret_cast<int *>(lds);
+    __shared__ int perm_cnt[2];
+    {
+        const int nb = min(4 * p.ng, ngrp);
+        if (t < 2) perm_cnt[t] = 0;
+        __syncthreads();
+        for (int gi = t; gi < ngrp; gi += kClThreads) {
+            if (gi < nb) { perm[gi] = gi; continue; }
+            const int kr = gi / p.ng, g = gi - kr * p.ng;
+            const float4 q1 = *reinterpret_cast<const float4 *>(p.q1 + 4 * g);
+            const bool dmp = p.q0[r0 + row_of(kr)] != 0.f || q1.x != 0.f || q1.y != 0.f || q1.z != 0.f || q1.w != 0.f;
+            if (!dmp) perm[nb + atomicAdd(&perm_cnt[0], 1)] = gi;
+            else perm[ngrp - 1 - atomicAdd(&perm_cnt[1], 1)] = gi;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < kClMaxNG; ++i) {
-        const int gi = t + i * kClThreads;
+        const int gslot = t + i * kClThreads;
         loff[i] = 0; jg[i] = 0;
         rr[i] = acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gi < ngrp) {
+        if (gslot < ngrp) {
             nown = i + 1;
+            const int gi = perm[gslot];
             const int kr = gi / p.ng, g = gi - kr * p.ng;
             const int lrw = row_of(kr), j = r0 + lrw;
             loff[i] = (lrw + 2) * PL + 4 + 4 * g;
@@ -876,7 +920,7 @@ struct mifwi_acoustic_plan {
     int ng, gp, pitch, lx, rz, gs, ngroups;
     long long shot_stride, field_elems, coef_elems;
     // cluster path (LDS-resident time loop), 0 when the shot does not fit
-    int cluster, NW, PL, cl_shots, cl_lds;
+    int cluster, NW, PL, cl_shots, cl_lds, rt;
     long long xbuf_elems, list_elems;      // in floats
 };
 
@@ -933,24 +977,32 @@ AcParams base_params(const mifwi_acoustic_plan *pl, const float *r, const float 
 // ---- cluster path helpers --------------------------------------------------------------------------
 void cluster_setup(mifwi_acoustic_plan *pl)
 {
-    pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0;
+    pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0; pl->rt = 0;
     pl->xbuf_elems = 0; pl->list_elems = 0;
     if (env_int("MIFWI_AC_CLUSTER", 1) == 0 || pl->d.ntap != 1) return;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device) != hipSuccess) return;
     const int forced = env_int("MIFWI_AC_NW", 0);
-    for (int nw = 1; nw <= 32; ++nw) {
+    const int hint = env_int("MIFWI_AC_EDGE_ROWS", pl->d.edge_rows);
+    for (int nw = 1; nw <= 32 && !pl->cluster; ++nw) {
         if (forced > 0 && nw != forced) continue;
-        const int rows = mifwi::ceil_div(pl->d.n0, nw);
         if (pl->d.n0 / nw < 4) break;
-        const long long lds = (2LL * (rows + 4) * pl->PL + pl->gp + rows + 8) * sizeof(float);
-        if (lds > 150 * 1024) continue;
-        if ((long long)rows * pl->ng > (long long)kClMaxNG * kClThreads || pl->ng > 4095 ||
-            4 * pl->gp > 3 * kClThreads) continue;
         const int per_launch = 8 * (ncu / (8 * nw));       // shots per launch (multiple of 8)
         if (per_launch < 8) break;
-        pl->cluster = 1; pl->NW = nw; pl->cl_shots = per_launch; pl->cl_lds = (int)lds;
-        break;
+        // first choice: the absorbing layer gets slabs of its own (hint = its width in rows)
+        for (int uneven = 1; uneven >= 0 && !pl->cluster; --uneven) {
+            int rt = 0, rows = mifwi::ceil_div(pl->d.n0, nw);
+            if (uneven) {
+                if (hint < 4 || nw < 3 || pl->d.n0 - 2 * hint < 4 * (nw - 2)) continue;
+                rt = hint;
+                rows = std::max(rt, mifwi::ceil_div(pl->d.n0 - 2 * rt, nw - 2));
+            }
+            const long long lds = (2LL * (rows + 4) * pl->PL + pl->gp + rows + 8) * sizeof(float);
+            if (lds > 150 * 1024) continue;
+            if ((long long)rows * pl->ng > (long long)kClMaxNG * kClThreads || pl->ng > 4095 ||
+                4 * pl->gp > 3 * kClThreads) continue;
+            pl->cluster = 1; pl->NW = nw; pl->cl_shots = per_launch; pl->cl_lds = (int)lds; pl->rt = rt;
+        }
     }
     if (!pl->cluster) return;
     pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * pl->NW * 8 * pl->gp + 64, 64);   // granules + err word
@@ -970,7 +1022,7 @@ ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const flo
     ClParams c;
     memset(&c, 0, sizeof(c));
     c.n0 = pl->d.n0; c.n1 = pl->d.n1; c.ng = pl->ng; c.gp = pl->gp; c.pitch = pl->pitch;
-    c.shot_stride = pl->shot_stride; c.nshot = pl->d.nshot; c.NW = pl->NW; c.PL = pl->PL;
+    c.shot_stride = pl->shot_stride; c.nshot = pl->d.nshot; c.NW = pl->NW; c.PL = pl->PL; c.rt = pl->rt;
     c.nt = pl->d.nt; c.c0 = pl->d.c0; c.c1 = pl->d.c1; c.r = r; c.q0 = q0; c.q1 = q1;
     c.ua = ua; c.ub = ub;
     c.nsrc = pl->d.nsrc; c.ntap = 1; c.nrec = pl->d.nrec;
@@ -1235,7 +1287,7 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
         float *xbuf = reinterpret_cast<float *>(bbox) + mifwi::round_up64(4LL * d.nshot, 64);
         int *lists = reinterpret_cast<int *>(xbuf + pl->xbuf_elems);
         hipLaunchKernelGGL(cl_build_slab_lists, dim3(d.nshot), dim3(256), 0, st, rec_cell, d.nrec, d.n0, d.n1,
-                           pl->NW, lists, lists + (long long)d.nshot * pl->NW);
+                           pl->NW, pl->rt, lists, lists + (long long)d.nshot * pl->NW);
         ClParams c = cluster_params(pl, r, q0, q1, za, zb, xbuf);
         c.n_first = k_hi; c.n_last = k_lo;
         c.src_cell = src_cell; c.src_w = src_w;

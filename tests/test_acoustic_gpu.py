@@ -168,11 +168,13 @@ def test_deepwave_shim_matches_oracle(oracle32):
     assert rel_l2(vp.grad.cpu().numpy(), vpt.grad.numpy()) <= 1e-4
 
 
-@pytest.mark.parametrize("nw", [2, 3, 5])
-def test_cluster_path_with_halo_handoff(oracle32, monkeypatch, nw):
+@pytest.mark.parametrize("nw,edge", [(2, 0), (3, 0), (5, 0), (3, 9), (5, 9), (6, 12)])
+def test_cluster_path_with_halo_handoff(oracle32, monkeypatch, nw, edge):
     """Force the LDS-resident cluster kernels to cut a shot into several row slabs so that the
-    granule hand-off between workgroups is exercised; results must not change (bitwise traces)."""
+    granule hand-off between workgroups is exercised; results must not change (bitwise traces).
+    edge > 0: the first and last slab hold `edge` rows (the sponge), the others share the rest."""
     monkeypatch.setenv("MIFWI_AC_NW", str(nw))
+    monkeypatch.setenv("MIFWI_AC_EDGE_ROWS", str(edge))
     case = acoustic_case(seed=17, n0=61, n1=83, nb=9, nt=140, ns=3, nrec=15)
     o = oracle32
     rec_o, G_o = o.acoustic_forward(case["r"], case["q0"], case["q1"], case["f"], case["sc"],
