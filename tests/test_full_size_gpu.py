@@ -143,3 +143,42 @@ def test_interleaved_plans_of_different_grids():
     ma2, _, ax2, az2 = _elastic(ecase_a)
     torch.autograd.backward([ax2, az2], [torch.sign(ax2.detach()), torch.sign(az2.detach())])
     assert torch.equal(ax, ax2) and torch.equal(ma.grad, ma2.grad)
+
+
+def test_c5_seam_sized_grid_checkpointed_equals_resident():
+    """BASELINE's largest grid (1000x3000, networks.py:9638) on the one-launch-per-half-step family:
+    time-checkpointed segments reproduce the resident-snapshot gradient bit for bit, and a zero
+    residual gives a zero gradient."""
+    from physicsbasedfwi2_amd import elastic
+    nz, nx, ns, nt, fw = 1000, 3000, 2, 36, 10
+    rng = np.random.default_rng(7)
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import helpers as H
+    vp = 1500.0 + 3000.0 * np.linspace(0, 1, nz)[:, None] + 50.0 * rng.standard_normal((nz, nx))
+    vs = vp / np.sqrt(3.0); rho = 310.0 * vp ** 0.25
+    vs[:20] = 0.0; vp[:20] = 1500.0; rho[:20] = 1000.0
+    h, dt = 30.0, 0.0025
+    dev = torch.device(DEV)
+    prm = [torch.tensor(a.astype(np.float32), device=dev) for a in (vp, vs, rho)]
+    mat0 = elastic.staggered_materials(*prm, dt, h)
+    pz = torch.tensor(H.cpml_profiles(nz, fw, h, dt, 1500.0, 5.0))
+    px = torch.tensor(H.cpml_profiles(nx, fw, h, dt, 1500.0, 5.0))
+    f = torch.zeros(nt, ns, 1, device=dev)
+    f[:, :, 0] = torch.tensor(H.ricker_deepwave(8.0, nt, dt, 0.02) * 1e6, dtype=torch.float32)[:, None]
+    sc = torch.tensor([[[6 * nx + 700]], [[6 * nx + 2200]]], dtype=torch.int32)
+    rx = np.arange(100, 2900, 7)
+    rc = torch.tensor(np.tile((8 * nx + rx)[None, :, None], (ns, 1, 1)).astype(np.int32))
+    ones = lambda t: torch.ones(t.shape)
+    outs = []
+    for budget in (96 << 30, 1 << 30):
+        mat = mat0.clone().requires_grad_(True)
+        rvx, rvz = elastic.propagate(mat, f, pz, px, sc, ones(sc), rc, ones(rc), fw, snapshot_budget=budget)
+        torch.autograd.backward([rvx, rvz], [torch.sign(rvx.detach()), torch.sign(rvz.detach())])
+        outs.append((rvx.detach().clone(), mat.grad.clone()))
+    assert float(outs[0][0].abs().max()) > 0 and float(outs[0][1].abs().max()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    mat = mat0.clone().requires_grad_(True)
+    rvx, rvz = elastic.propagate(mat, f, pz, px, sc, ones(sc), rc, ones(rc), fw)
+    torch.autograd.backward([rvx, rvz], [torch.zeros_like(rvx), torch.zeros_like(rvz)])
+    assert float(mat.grad.abs().max()) == 0.0
