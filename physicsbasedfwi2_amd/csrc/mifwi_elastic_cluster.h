@@ -81,6 +81,101 @@ __device__ __forceinline__ int ec_opaque(int x)
     return x;
 }
 
+// The granule hand-off of one slab, shared by the forward and the adjoint kernel.  `kind` selects one
+// of the two exchanges of a step, `parity` the double buffer, `epoch` the tag a complete granule
+// carries.  receive() hands every arrived value to dest(field_is_A, lds_offset, value).
+struct EcHandoff {
+    unsigned long long *xw;              // this slab's slots [kind 0..1][parity 0..1][kEcRowFields*gp]
+    long long xslot;
+    int gp, ng, NW, w, R, t;
+    int rcv_lo[kEcGr];                   // LDS offset (inside a field) of my k-th granule, <0: none
+    unsigned rcv_meta;                   // per k: bit0 field A, bit1 comes from the slab above
+    int *err;
+    bool failed, no_wait;                // no_wait: timing ablation only (wrong results)
+
+    __device__ __forceinline__ void init(unsigned long long *xbuf, int s, int NW_, int w_, int R_, int PL, int gp_,
+                                         int ng_, int t_, int *err_, bool no_wait_)
+    {
+        gp = gp_; ng = ng_; NW = NW_; w = w_; R = R_; t = t_; err = err_; failed = false; no_wait = no_wait_;
+        xslot = (long long)kEcRowFields * gp;
+        xw = xbuf + ((long long)s * NW + w) * 4 * xslot;
+        rcv_meta = 0;
+#pragma unroll
+        for (int k = 0; k < kEcGr; ++k) {
+            const int e = t + k * kEcThreads;
+            rcv_lo[k] = -1;
+            if (e < kEcRowFields * gp) {
+                const int cq = e % gp, rf = e / gp;
+                const int col = 4 * (cq % ng) + cq / ng;             // granule order is [k][group]
+                const bool from_above = rf >= 3;                      // top halo <- the slab above's last rows
+                if (cq < 4 * ng && !(from_above ? w == 0 : w == NW - 1)) {
+                    rcv_lo[k] = ec_rf_lds_row(rf, R) * PL + 4 + col;
+                    rcv_meta |= (unsigned)(ec_rf_field(rf) | (from_above ? 2 : 0)) << (2 * k);
+                }
+            }
+        }
+    }
+
+    // sweep: every pass re-reads ALL of this thread's granules back to back (one memory round trip per
+    // pass, not one per granule) until every tag carries the epoch; bounded, a time-out sets `failed`
+    template <class Dest>
+    __device__ __forceinline__ void receive(int kind, unsigned epoch, int parity, Dest dest)
+    {
+        const unsigned long long *xu = xw - 4 * xslot + (kind * 2 + parity) * xslot;
+        const unsigned long long *xd = xw + 4 * xslot + (kind * 2 + parity) * xslot;
+        const unsigned long long *src[kEcGr];
+        unsigned long long v[kEcGr];
+#pragma unroll
+        for (int k = 0; k < kEcGr; ++k) {
+            src[k] = (((rcv_meta >> (2 * k)) & 2u) ? xu : xd) + (t + k * kEcThreads);   // same index on both sides
+            v[k] = 0;
+        }
+        for (unsigned spins = 0;; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < kEcGr; ++k)
+                if (rcv_lo[k] >= 0) v[k] = __hip_atomic_load(src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < kEcGr; ++k)
+                if (rcv_lo[k] >= 0) ok = ok && (unsigned)(v[k] >> 32) == epoch;
+            if (ok || no_wait) break;
+            if (spins > kEcMaxSpin ||
+                ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                failed = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int k = 0; k < kEcGr; ++k)
+            if (rcv_lo[k] >= 0) dest((int)((rcv_meta >> (2 * k)) & 1u), rcv_lo[k], __uint_as_float((unsigned)v[k]));
+    }
+
+    // publish the four cells of a boundary-row group (local row lrw, group gq): b = the field a forward
+    // difference reads (vx, szz; E2, D2), a = the one a backward difference reads (vz, sxz; E3, D4)
+    __device__ __forceinline__ void publish(int lrw, int gq, int kind, unsigned epoch, int parity, const float4 &b,
+                                            const float4 &a) const
+    {
+        unsigned long long *x = xw + (kind * 2 + parity) * xslot;
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        const float bv[4] = {b.x, b.y, b.z, b.w}, av[4] = {a.x, a.y, a.z, a.w};
+        auto put = [&](int rf, const float (&v)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                __hip_atomic_store(x + (unsigned)(rf * gp + k * ng + gq), tag | __float_as_uint(v[k]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (w > 0) {
+            if (lrw == 0) { put(0, av); put(1, bv); }
+            if (lrw == 1) put(2, bv);
+        }
+        if (w < NW - 1) {
+            if (lrw == R - 2) put(3, av);
+            if (lrw == R - 1) { put(4, av); put(5, bv); }
+        }
+    }
+};
+
 // per-thread state of one owned group of 4 cells (registers for the whole run)
 struct EcGroup {
     bool own, inner;
@@ -334,86 +429,17 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     }
     __syncthreads();
 
-    // ---- hand-off assignments (constant): granule e = t + k*kEcThreads of an 8*gp slot -------------
-    constexpr int kGr = kEcGr;
-    int rcv_lo[kGr];                     // LDS offset inside the field (<0: none)
-    unsigned rcv_meta = 0;               // per k: bit0 field, bit1 from-upper-neighbour
-#pragma unroll
-    for (int k = 0; k < kGr; ++k) {
-        const int e = t + k * kEcThreads;
-        rcv_lo[k] = -1;
-        if (e < kEcRowFields * p.gp) {
-            const int cq = e % p.gp, rf = e / p.gp;
-            const int col = 4 * (cq % p.ng) + cq / p.ng;         // granule order is [k][group]
-            const bool from_above = rf >= 3;                      // top halo <- the slab above's last rows
-            if (cq < 4 * p.ng && !(from_above ? w == 0 : w == p.NW - 1)) {
-                rcv_lo[k] = ec_rf_lds_row(rf, R) * PL + 4 + col;
-                rcv_meta |= (unsigned)(ec_rf_field(rf) | (from_above ? 2 : 0)) << (2 * k);
-            }
-        }
-    }
-    const long long xslot = (long long)kEcRowFields * p.gp;   // granules per slot
-    unsigned long long *xw = p.xbuf + ((long long)s * p.NW + w) * 4 * xslot;      // [kind][parity][slot]
+    // ---- halo hand-off: kind 0 = velocities after V, kind 1 = stresses after S ------------------
+    EcHandoff X;
+    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, (p.dbg & 4) != 0);
     const bool do_x = p.NW > 1 && !(p.dbg & 1);
-    bool failed = false;
-
-    // receive one exchange: kind 0 = velocities (fields vx,vz), kind 1 = stresses (szz,sxz)
     auto receive = [&](int kind, unsigned epoch, int parity) {
-        const unsigned long long *xu = xw - 4 * xslot + (kind * 2 + parity) * xslot;
-        const unsigned long long *xd = xw + 4 * xslot + (kind * 2 + parity) * xslot;
-        // sweep: every pass re-reads ALL of this thread's granules back to back (one memory round trip
-        // per pass, not one per granule) until every tag carries the epoch
-        const unsigned long long *src[kGr];
-        unsigned long long v[kGr];
-#pragma unroll
-        for (int k = 0; k < kGr; ++k) {
-            const int e = t + k * kEcThreads;
-            src[k] = (((rcv_meta >> (2 * k)) & 2u) ? xu : xd) + e;        // same row-field index on both sides
-            v[k] = 0;
-        }
-        for (unsigned spins = 0;; ++spins) {
-            bool ok = true;
-#pragma unroll
-            for (int k = 0; k < kGr; ++k)
-                if (rcv_lo[k] >= 0) v[k] = __hip_atomic_load(src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int k = 0; k < kGr; ++k)
-                if (rcv_lo[k] >= 0) ok = ok && (unsigned)(v[k] >> 32) == epoch;
-            if (ok || (p.dbg & 4)) break;                     // dbg 4: timing ablation only (wrong results)
-            if (spins > kEcMaxSpin ||
-                ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                failed = true;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-#pragma unroll
-        for (int k = 0; k < kGr; ++k) {
-            if (rcv_lo[k] < 0) continue;
-            const unsigned m = (rcv_meta >> (2 * k)) & 3u;
-            const int fld = (kind == 0) ? ((m & 1u) ? F_VZ : F_VX) : ((m & 1u) ? F_SXZ : F_SZZ);
-            c.Lf[fld][rcv_lo[k]] = __uint_as_float((unsigned)v[k]);
-        }
+        X.receive(kind, epoch, parity, [&](int is_a, int off, float v) {
+            c.Lf[kind == 0 ? (is_a ? F_VZ : F_VX) : (is_a ? F_SXZ : F_SZZ)][off] = v;
+        });
     };
-    // publish the four cells of a boundary-row group for the two fields of an exchange
-    auto publish = [&](const int lrw, const int gq, int kind, unsigned epoch, int parity, const float4 &o0, const float4 &o1) {
-        unsigned long long *x = xw + (kind * 2 + parity) * xslot;
-        const unsigned long long tag = (unsigned long long)epoch << 32;
-        const float bv[4] = {o0.x, o0.y, o0.z, o0.w}, av[4] = {o1.x, o1.y, o1.z, o1.w};   // o0 = B, o1 = A
-        auto put = [&](int rf, const float (&v)[4]) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                __hip_atomic_store(x + (unsigned)(rf * p.gp + k * p.ng + gq), tag | __float_as_uint(v[k]),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        if (w > 0) {
-            if (lrw == 0) { put(0, av); put(1, bv); }
-            if (lrw == 1) put(2, bv);
-        }
-        if (w < p.NW - 1) {
-            if (lrw == R - 2) put(3, av);
-            if (lrw == R - 1) { put(4, av); put(5, bv); }
-        }
+    auto publish = [&](int lrw, int gq, int kind, unsigned epoch, int parity, const float4 &o0, const float4 &o1) {
+        X.publish(lrw, gq, kind, epoch, parity, o0, o1);
     };
     // source term of step n for a group: fetched one step ahead (a global load in the update itself
     // would put a memory round trip on the workgroup's critical path every step)
@@ -525,7 +551,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
             __builtin_amdgcn_sched_barrier(0);
         }
         if ((it & 31) == 31 || it == nsteps - 1) {
-            if (__syncthreads_or(failed ? 1 : 0)) {        // D (+ collective time-out check)
+            if (__syncthreads_or(X.failed ? 1 : 0)) {        // D (+ collective time-out check)
                 if (t == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -740,83 +766,17 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     for (int e = t; e < fsz; e += kEcThreads) { pln[e] = 0.f; pln[fsz + e] = 0.f; pln[2 * fsz + e] = 0.f; pln[3 * fsz + e] = 0.f; }
     __syncthreads();
 
-    // ---- hand-off assignments (as in the forward kernel) ------------------------------------------
-    constexpr int kGr = kEcGr;
-    int rcv_lo[kGr];
-    unsigned rcv_meta = 0;               // per k: bit0 field, bit1 from-upper-neighbour
-#pragma unroll
-    for (int k = 0; k < kGr; ++k) {
-        const int e = t + k * kEcThreads;
-        rcv_lo[k] = -1;
-        if (e < kEcRowFields * p.gp) {
-            const int cq = e % p.gp, rf = e / p.gp;
-            const int col = 4 * (cq % p.ng) + cq / p.ng;         // granule order is [k][group]
-            const bool from_above = rf >= 3;                      // top halo <- the slab above's last rows
-            if (cq < 4 * p.ng && !(from_above ? w == 0 : w == p.NW - 1)) {
-                rcv_lo[k] = ec_rf_lds_row(rf, R) * PL + 4 + col;
-                rcv_meta |= (unsigned)(ec_rf_field(rf) | (from_above ? 2 : 0)) << (2 * k);
-            }
-        }
-    }
-    const long long xslot = (long long)kEcRowFields * p.gp;
-    unsigned long long *xw = p.xbuf + ((long long)s * p.NW + w) * 4 * xslot;
+    // ---- halo hand-off: kind 0 = E2 (plane 1), E3 (plane 2); kind 1 = D2 (plane 1), D4 (plane 3) ----
+    EcHandoff X;
+    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, false);
     const bool do_x = p.NW > 1 && !(p.dbg & 1);
-    bool failed = false;
-    // kind 0: planes 1,2 (E2,E3); kind 1: planes 1,3 (D2,D4)
     auto receive = [&](int kind, unsigned epoch, int parity) {
-        const unsigned long long *xu = xw - 4 * xslot + (kind * 2 + parity) * xslot;
-        const unsigned long long *xd = xw + 4 * xslot + (kind * 2 + parity) * xslot;
-        const unsigned long long *src[kGr];
-        unsigned long long v[kGr];
-#pragma unroll
-        for (int k = 0; k < kGr; ++k) {
-            const int e = t + k * kEcThreads;
-            src[k] = (((rcv_meta >> (2 * k)) & 2u) ? xu : xd) + e;        // same row-field index on both sides
-            v[k] = 0;
-        }
-        for (unsigned spins = 0;; ++spins) {
-            bool ok = true;
-#pragma unroll
-            for (int k = 0; k < kGr; ++k)
-                if (rcv_lo[k] >= 0) v[k] = __hip_atomic_load(src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int k = 0; k < kGr; ++k)
-                if (rcv_lo[k] >= 0) ok = ok && (unsigned)(v[k] >> 32) == epoch;
-            if (ok) break;
-            if (spins > kEcMaxSpin ||
-                ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                failed = true;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-#pragma unroll
-        for (int k = 0; k < kGr; ++k) {
-            if (rcv_lo[k] < 0) continue;
-            const unsigned m = (rcv_meta >> (2 * k)) & 3u;
-            const int plane = (m & 1u) ? (kind == 0 ? 2 : 3) : 1;
-            pln[plane * fsz + rcv_lo[k]] = __uint_as_float((unsigned)v[k]);
-        }
+        X.receive(kind, epoch, parity, [&](int is_a, int off, float v) {
+            pln[(is_a ? (kind == 0 ? 2 : 3) : 1) * fsz + off] = v;
+        });
     };
-    auto publish = [&](const int lrw, const int gq, int kind, unsigned epoch, int parity, const float4 &o0,
-                       const float4 &o1) {
-        unsigned long long *x = xw + (kind * 2 + parity) * xslot;
-        const unsigned long long tag = (unsigned long long)epoch << 32;
-        const float bv[4] = {o0.x, o0.y, o0.z, o0.w}, av[4] = {o1.x, o1.y, o1.z, o1.w};   // o0 = B, o1 = A
-        auto put = [&](int rf, const float (&v)[4]) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                __hip_atomic_store(x + (unsigned)(rf * p.gp + k * p.ng + gq), tag | __float_as_uint(v[k]),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        if (w > 0) {
-            if (lrw == 0) { put(0, av); put(1, bv); }
-            if (lrw == 1) put(2, bv);
-        }
-        if (w < p.NW - 1) {
-            if (lrw == R - 2) put(3, av);
-            if (lrw == R - 1) { put(4, av); put(5, bv); }
-        }
+    auto publish = [&](int lrw, int gq, int kind, unsigned epoch, int parity, const float4 &o0, const float4 &o1) {
+        X.publish(lrw, gq, kind, epoch, parity, o0, o1);
     };
     const long long sshot = (long long)s * 5 * ncell;
     auto request_S = [&](EaGroup &g, int n) {
@@ -1123,7 +1083,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             __builtin_amdgcn_sched_barrier(0);
         }
         if ((it & 31) == 31 || it == nsteps - 1) {
-            if (__syncthreads_or(failed ? 1 : 0)) {        // 6 (+ collective time-out check)
+            if (__syncthreads_or(X.failed ? 1 : 0)) {        // 6 (+ collective time-out check)
                 if (t == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
