@@ -564,6 +564,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     int smp_off = -1, smp_e = -1;                        // sampling of `cur`
     float smp_w = 0.f;
     int inj_off = -1, inj_id = -1;                       // adjoint injection into LDS
+    bool inj_edge = false;
     float inj_scale = 0.f;
     bool slow_sparse = false;                            // more points than one per thread: rescan per step
     if (!adj) {
@@ -606,6 +607,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             const float q = p.q0[i0] + p.q1[i1];
             const float inv = 1.0f / (1.0f + q * rv);
             inj_off = (i0 - r0 + 2) * PL + 4 + i1;
+            inj_edge = (i0 - r0 < 2) || (i0 - r0 >= R - 2);       // lies in a row the neighbours wait for
             inj_id = id;
             inj_scale = rv * inv;
             smp_w = p.rec_w[(long long)s * p.nrec + id];          // reused as the tap weight
@@ -680,6 +682,10 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     const bool do_x = p.NW > 1 && !(p.dbg & 1);
     // forward: all four boundary rows live in slot 0 when a row has at most kClThreads/4 groups
     const bool early_pub = !adj && do_x && 4 * p.ng <= kClThreads;
+    // adjoint: the same, once the receivers that sit IN the boundary rows have been injected (the other
+    // receivers are injected after the interior slots, as before)
+    const bool early_adj = adj && do_x && 4 * p.ng <= kClThreads && !slow_sparse;
+    const bool edge_recv_any = early_adj && __syncthreads_or((inj_off >= 0 && inj_edge) ? 1 : 0) != 0;
 
     // software prefetch of the next step's global operands (issued before this step's stores, so
     // that they do not queue behind them): source / adjoint-source amplitude and, in the adjoint,
@@ -791,10 +797,14 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 if (MODE == 1) Gbuf[i] = make_float4(gk[0], gk[1], gk[2], gk[3]);
             }
             __builtin_amdgcn_sched_barrier(0);   // one group at a time: keeps the register peak below 128
-            if (early_pub && i == 0) {
-                // forward: every boundary row is complete after slot 0 -> publish now, so that the
-                // hand-off travels while the interior (slots 1..) is computed
+            if ((early_pub || early_adj) && i == 0) {
+                // every boundary row is complete after slot 0 -> publish now, so that the hand-off
+                // travels while the interior (slots 1..) is computed
                 __syncthreads();
+                if (edge_recv_any) {             // workgroup-uniform
+                    if (inj_off >= 0 && inj_edge) atomicAdd(&prv[cl_opaque(inj_off)], (smp_w * amp) * inj_scale);
+                    __syncthreads();
+                }
 #pragma unroll
                 for (int kk = 0; kk < kGr; ++kk)
                     if (rcv_lo[kk] >= 0)
@@ -807,7 +817,8 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         if (adj) {
             // ---- adjoint sources: receiver taps of this slab, z^k[cell] += (w g) (r inv) -------
             if (!slow_sparse) {
-                if (inj_off >= 0) atomicAdd(&prv[cl_opaque(inj_off)], (smp_w * amp) * inj_scale);
+                if (inj_off >= 0 && !(early_adj && inj_edge))
+                    atomicAdd(&prv[cl_opaque(inj_off)], (smp_w * amp) * inj_scale);
             } else {
                 const int cnt = p.slab_cnt[s * p.NW + w];
                 const int *lst = p.slab_list + ((long long)s * p.NW + w) * p.nrec;
@@ -834,7 +845,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 }
             }
         }
-        if (do_x && !early_pub) {
+        if (do_x && !early_pub && !early_adj) {
 #pragma unroll
             for (int kk = 0; kk < kGr; ++kk)
                 if (rcv_lo[kk] >= 0)
