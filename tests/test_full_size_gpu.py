@@ -182,3 +182,35 @@ def test_c5_seam_sized_grid_checkpointed_equals_resident():
     rvx, rvz = elastic.propagate(mat, f, pz, px, sc, ones(sc), rc, ones(rc), fw)
     torch.autograd.backward([rvx, rvz], [torch.zeros_like(rvx), torch.zeros_like(rvz)])
     assert float(mat.grad.abs().max()) == 0.0
+
+
+def test_full_length_runs_agree_between_families(monkeypatch):
+    """BASELINE's full time axes (C2: 2000 steps, 29 shots; C3: 3000 steps, 32 shots): ~10^5 halo
+    hand-offs per workgroup in the single-launch kernels, compared sample by sample with the
+    one-launch-per-step family."""
+    case = acoustic_case(seed=81, n0=174, n1=500, nb=20, nt=2000, ns=29, nrec=500)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MIFWI_AC_CLUSTER", flag)
+        r, f, rec = _acoustic(case)
+        rec.backward(torch.sign(rec.detach()))
+        outs.append((rec.detach().clone(), r.grad.clone()))
+        del r, f, rec
+        torch.cuda.empty_cache()
+    assert torch.isfinite(outs[0][0]).all() and torch.equal(outs[0][0], outs[1][0])
+    assert rel_l2(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy()) <= 5e-5
+    del outs
+    torch.cuda.empty_cache()
+    ecase = elastic_case(seed=83, nz=100, nx=300, fw=10, ns=32, nrec=276, nt=3000)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MIFWI_EL_CLUSTER", flag)
+        monkeypatch.setenv("MIFWI_EL_CLUSTER_ADJ", flag)
+        mat, f, rvx, rvz = _elastic(ecase)
+        torch.autograd.backward([rvx, rvz], [torch.sign(rvx.detach()), torch.sign(rvz.detach())])
+        outs.append((rvx.detach().clone(), rvz.detach().clone(), mat.grad.clone()))
+        del mat, f, rvx, rvz
+        torch.cuda.empty_cache()
+    assert torch.isfinite(outs[0][0]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel_l2(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()) <= 5e-5
