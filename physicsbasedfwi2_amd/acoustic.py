@@ -220,8 +220,39 @@ def propagate(r, f, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
     _require_cuda(r, "r")
     geom = _Geometry(src_cell, src_w, rec_cell, rec_w, r.device)
     f = f.to(device=r.device)
+    ntap = geom.src_cell.shape[2]
+    if ntap > 1 and _flatten_taps_pays(r, f, geom, c0, c1, edge_rows):
+        # Bilinear taps (the Devito-shaped protocol) as independent single-cell points: every tap becomes
+        # a source / receiver of its own, which makes the single-launch time loop eligible; the taps of a
+        # point are recombined by differentiable torch ops (sum over the tap axis, repeat of f).
+        ns, nsrc = geom.src_cell.shape[:2]
+        nrec = geom.rec_cell.shape[1]
+        flat = _Geometry(geom.src_cell.reshape(ns, nsrc * ntap, 1), geom.src_w.reshape(ns, nsrc * ntap, 1),
+                         geom.rec_cell.reshape(ns, nrec * ntap, 1), geom.rec_w.reshape(ns, nrec * ntap, 1),
+                         r.device)
+        rec = _AcousticFn.apply(r, f.repeat_interleave(ntap, dim=2), q0, q1, flat, float(c0), float(c1),
+                                int(shots_per_group), int(snapshot_budget), int(edge_rows))
+        return rec.reshape(rec.shape[0], ns, nrec, ntap).sum(dim=3)
     return _AcousticFn.apply(r, f, q0, q1, geom, float(c0), float(c1), int(shots_per_group),
                              int(snapshot_budget), int(edge_rows))
+
+
+def _flatten_taps_pays(r, f, geom, c0, c1, edge_rows):
+    """True when the flattened (single-tap) problem runs on the single-launch kernels' fast paths."""
+    import os
+    if os.environ.get("MIFWI_AC_FLATTEN_TAPS", "1") == "0":
+        return False
+    ns, nsrc, ntap = geom.src_cell.shape
+    nrec = geom.rec_cell.shape[1]
+    if nrec * ntap > 1024 or nsrc * ntap > 64:
+        return False
+    n0, n1 = r.shape
+    with torch.cuda.device(r.device):
+        plan = AcousticPlan(n0, n1, f.shape[0], ns, nsrc * ntap, nrec * ntap, 1, float(c0), float(c1),
+                            r.device.index, 0, int(edge_rows))
+        ok = plan.cluster_slabs() > 0
+        plan.close()
+    return ok
 
 
 def born(r, f, dr, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,

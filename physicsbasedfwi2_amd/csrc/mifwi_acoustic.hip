@@ -995,13 +995,18 @@ void cluster_setup(mifwi_acoustic_plan *pl)
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device) != hipSuccess) return;
     const int forced = env_int("MIFWI_AC_NW", 0);
     const int hint = env_int("MIFWI_AC_EDGE_ROWS", pl->d.edge_rows);
-    for (int nw = 1; nw <= 32 && !pl->cluster; ++nw) {
+    // Slab count: a step costs a fixed part (barriers, one hand-off flight) plus the groups a thread
+    // updates, times the launches the shot batch needs (measured: ~(4.7 + groups/thread) per launch on
+    // C1/C2).  Few shots -> many thin slabs use the idle CUs; a full batch -> the fewest slabs that fit.
+    double best = 1e30;
+    for (int nw = 1; nw <= 32; ++nw) {
         if (forced > 0 && nw != forced) continue;
         if (pl->d.n0 / nw < 4) break;
+        if (forced <= 0 && nw > 1 && pl->d.n0 / nw < 6) break;      // thinner slabs are all boundary rows
         const int per_launch = 8 * (ncu / (8 * nw));       // shots per launch (multiple of 8)
         if (per_launch < 8) break;
-        // first choice: the absorbing layer gets slabs of its own (hint = its width in rows)
-        for (int uneven = 1; uneven >= 0 && !pl->cluster; --uneven) {
+        // both splits are priced: the absorbing layer in slabs of its own (hint = its width), or even
+        for (int uneven = 1; uneven >= 0; --uneven) {
             int rt = 0, rows = mifwi::ceil_div(pl->d.n0, nw);
             if (uneven) {
                 if (hint < 4 || nw < 3 || pl->d.n0 - 2 * hint < 4 * (nw - 2)) continue;
@@ -1012,7 +1017,14 @@ void cluster_setup(mifwi_acoustic_plan *pl)
             if (lds > 150 * 1024) continue;
             if ((long long)rows * pl->ng > (long long)kClMaxNG * kClThreads || pl->ng > 4095 ||
                 4 * pl->gp > 3 * kClThreads) continue;
-            pl->cluster = 1; pl->NW = nw; pl->cl_shots = per_launch; pl->cl_lds = (int)lds; pl->rt = rt;
+            // rows of the slowest slab, a sponge row counted 1.5 times (a division per cell and step)
+            const double units = uneven ? std::max(1.5 * rt, (double)mifwi::ceil_div(pl->d.n0 - 2 * rt, nw - 2))
+                                        : rows + 0.5 * std::min(std::max(hint, 0), rows);
+            const double cost = mifwi::ceil_div(pl->d.nshot, per_launch) * (4.7 + units * pl->ng / kClThreads);
+            if (cost < best - 1e-9) {
+                best = cost;
+                pl->cluster = 1; pl->NW = nw; pl->cl_shots = per_launch; pl->cl_lds = (int)lds; pl->rt = rt;
+            }
         }
     }
     if (!pl->cluster) return;

@@ -832,18 +832,26 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device) != hipSuccess) return;
     const int forced = env_int("MIFWI_EL_NW", 0);
+    // Slab count (both loops): cost of a step ~ fixed part (barriers, two hand-off flights) + groups per
+    // thread, times the launches the shot batch needs (measured on 100x300: 6 shots 8.7 us at 8 slabs,
+    // 7.2 us at 20).  Few shots -> many thin slabs; a full batch -> the fewest slabs that fit.
+    double best = 1e30;
     for (int nw = 1; nw <= 32 && want_fwd; ++nw) {
         if (forced > 0 && nw != forced) continue;
         const int rows = mifwi::ceil_div(pl->d.nz, nw);
         if (pl->d.nz / nw < 4) break;
+        if (forced <= 0 && nw > 1 && pl->d.nz / nw < 5) break;
         const long long lds = (5LL * (rows + 4) * pl->PL + 6LL * pl->gp + 6LL * rows + 8) * sizeof(float);
         if (lds > 150 * 1024) continue;
         if ((long long)rows * pl->ng > 2 * kEcThreads || kEcRowFields * pl->gp > kEcGr * kEcThreads) continue;
         const int per_launch = 8 * (ncu / (8 * nw));
         if (per_launch < 8) break;
-        pl->cluster = 1; pl->NW = nw; pl->cl_shots = per_launch; pl->cl_lds = (int)lds;
-        pl->cl_ng = mifwi::ceil_div(rows * pl->ng, kEcThreads);
-        break;
+        const double cost = mifwi::ceil_div(pl->d.nshot, per_launch) * (4.8 + (double)rows * pl->ng / kEcThreads);
+        if (cost < best - 1e-9) {
+            best = cost;
+            pl->cluster = 1; pl->NW = nw; pl->cl_shots = per_launch; pl->cl_lds = (int)lds;
+            pl->cl_ng = mifwi::ceil_div(rows * pl->ng, kEcThreads);
+        }
     }
     if (pl->cluster) {
         for (const void *fn : {(const void *)el_cluster_fwd<false, 1>, (const void *)el_cluster_fwd<true, 1>,
@@ -858,9 +866,11 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
     // asked for a group size)
     const int forced_adj = env_int("MIFWI_EL_ADJ_NW", forced);
     if (env_int("MIFWI_EL_CLUSTER_ADJ", 1) != 0 && pl->d.shots_per_group <= 0) {
+        double best_adj = 1e30;
         for (int nw = 1; nw <= 32; ++nw) {
             if (forced_adj > 0 && nw != forced_adj) continue;
             if (pl->d.nz / nw < 4) break;
+            if (forced_adj <= 0 && nw > 1 && pl->d.nz / nw < 5) break;
             const int rows = mifwi::ceil_div(pl->d.nz, nw);
             int zmax = 0;
             for (int w = 0; w < nw && pl->W > 0; ++w) {
@@ -876,9 +886,12 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
             if ((long long)rows * pl->ng > 2 * kEcThreads || kEcRowFields * pl->gp > kEcGr * kEcThreads) continue;
             const int per_launch = 8 * (ncu / (8 * nw));
             if (per_launch < 8) break;
-            pl->cl_adj = 1; pl->adj_NW = nw; pl->adj_shots = per_launch; pl->adj_lds = (int)lds;
-            pl->adj_ng = mifwi::ceil_div(rows * pl->ng, kEcThreads); pl->adj_zrows = zmax;
-            break;
+            const double cost = mifwi::ceil_div(pl->d.nshot, per_launch) * (4.8 + (double)rows * pl->ng / kEcThreads);
+            if (cost < best_adj - 1e-9) {
+                best_adj = cost;
+                pl->cl_adj = 1; pl->adj_NW = nw; pl->adj_shots = per_launch; pl->adj_lds = (int)lds;
+                pl->adj_ng = mifwi::ceil_div(rows * pl->ng, kEcThreads); pl->adj_zrows = zmax;
+            }
         }
         if (pl->cl_adj)
             for (const void *fn : {(const void *)el_cluster_adj<1>, (const void *)el_cluster_adj<2>})
