@@ -840,7 +840,6 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
         if (forced > 0 && nw != forced) continue;
         const int rows = mifwi::ceil_div(pl->d.nz, nw);
         if (pl->d.nz / nw < 4) break;
-        if (forced <= 0 && nw > 1 && pl->d.nz / nw < 5) break;
         const long long lds = (5LL * (rows + 4) * pl->PL + 6LL * pl->gp + 6LL * rows + 8) * sizeof(float);
         if (lds > 150 * 1024) continue;
         if ((long long)rows * pl->ng > 2 * kEcThreads || kEcRowFields * pl->gp > kEcGr * kEcThreads) continue;
@@ -870,7 +869,6 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
         for (int nw = 1; nw <= 32; ++nw) {
             if (forced_adj > 0 && nw != forced_adj) continue;
             if (pl->d.nz / nw < 4) break;
-            if (forced_adj <= 0 && nw > 1 && pl->d.nz / nw < 5) break;
             const int rows = mifwi::ceil_div(pl->d.nz, nw);
             int zmax = 0;
             for (int w = 0; w < nw && pl->W > 0; ++w) {
