@@ -93,9 +93,10 @@ class _ElasticFn(torch.autograd.Function):
             raise MifwiError("f is [nt,%d,%d] but src_cell is %s" % (ns, nsrc,
                                                                       tuple(geom.src_cell.shape)))
         nrec, ntap = geom.rec_cell.shape[1], geom.rec_cell.shape[2]
-        for name, c in (("src_cell", geom.src_cell), ("rec_cell", geom.rec_cell)):
-            if c.numel() and int(c.max()) >= nz * nx:
-                raise MifwiError("%s holds a cell outside the %dx%d grid" % (name, nz, nx))
+        # one host round trip validates every tap (an out-of-grid cell would fault the kernels)
+        tops = [c.max() for c in (geom.src_cell, geom.rec_cell) if c.numel()]
+        if tops and int(torch.stack(tops).max()) >= nz * nx:
+            raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (nz, nx))
         with torch.cuda.device(dev):
             plan = ElasticPlan(nz, nx, nt, ns, nsrc, nrec, ntap, pml_width, dev.index,
                                shots_per_group, free_surface)
