@@ -401,8 +401,8 @@ def run_workload(name, args, dev, rank, world, want_cpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--nt", type=int, default=0, help="override time steps (debug only)")
     ap.add_argument("--shots", type=int, default=0, help="override shots per GPU (debug only)")
