@@ -231,3 +231,41 @@ def test_born_operator_matches_oracle_and_transposes_the_gradient(oracle32, monk
     lhs = float((jdr.double() * g.double()).sum())
     rhs = float((torch.tensor(dr, device=dev).double() * r2.grad.double()).sum())
     assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs))
+
+
+def test_deepwave_shim_substeps_when_dt_exceeds_the_stability_limit(oracle32):
+    """dt = 4 ms on a 10 m grid with 3.5 km/s needs an internal step of dt/ratio: the wavelet is
+    resampled band-limited, the propagator runs ratio*nt steps and the traces are decimated."""
+    import math
+    import physicsbasedfwi2_amd.compat.deepwave as deepwave
+    from physicsbasedfwi2_amd import profiles
+    from physicsbasedfwi2_amd.compat.deepwave import scalar as shim
+    from oracle import helpers as H
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(33)
+    nz, nx, dx, dt, nt, P = 28, 40, 10.0, 0.004, 60, 10
+    vp_np = (1500.0 + 2000.0 * rng.random((nz, nx))).astype(np.float32)
+    ns, nr = 2, 12
+    x_s = torch.zeros(ns, 1, 2); x_s[:, 0, 1] = torch.tensor([90.0, 300.0]); x_s[:, 0, 0] = 40.0
+    x_r = torch.zeros(ns, nr, 2); x_r[:, :, 1] = (torch.arange(nr).float() * 30.0)[None, :]; x_r[:, :, 0] = 20.0
+    wav = deepwave.wavelets.ricker(6.0, nt, dt, 1 / 6.0).reshape(-1, 1, 1).repeat(1, ns, 1)
+    vp = torch.tensor(vp_np, device=dev, requires_grad=True)
+    rec = deepwave.scalar.Propagator({"vp": vp}, dx, pml_width=P)(wav.to(dev), x_s.to(dev), x_r.to(dev), dt)
+    assert rec.shape == (nt, ns, nr)
+    ratio = max(1, int(math.ceil(dt / (shim.CFL_SAFETY * profiles.scalar_cfl_limit([dx, dx], float(vp_np.max()))) - 1e-9)))
+    assert ratio >= 2
+    dti = dt / ratio
+    vpp = np.pad(vp_np, P, mode="edge").astype(np.float64)
+    r_np = ((vpp * (dti / dx)) ** 2).astype(np.float32)
+    N0, N1 = r_np.shape
+    q0 = H.damp_profile_1d(N0, P, dx) * dx * dx / (2 * dti)
+    q1 = H.damp_profile_1d(N1, P, dx) * dx * dx / (2 * dti)
+    sc, sw = H.cell_taps(np.trunc(x_s[..., 0].numpy() / dx).astype(int) + P,
+                         np.trunc(x_s[..., 1].numpy() / dx).astype(int) + P, N1)
+    rc, rw = H.cell_taps(np.trunc(x_r[..., 0].numpy() / dx).astype(int) + P,
+                         np.trunc(x_r[..., 1].numpy() / dx).astype(int) + P, N1)
+    f_up = shim._upsample(wav * (dx * dx), ratio).numpy().astype(np.float32)
+    rec_o = oracle32.acoustic_forward(r_np, q0, q1, f_up, sc, sw, rc, rw)[::ratio]
+    assert np.abs(rec_o).max() > 0 and rel_l2(rec.detach().cpu().numpy(), rec_o) <= 1e-5
+    rec.square().sum().backward()
+    assert torch.isfinite(vp.grad).all() and float(vp.grad.abs().max()) > 0
