@@ -74,6 +74,12 @@ def test_cluster_path_with_halo_handoff(oracle32, monkeypatch, nw, fs):
     _check_parity(oracle32, case, bitwise=True)
 
 
+def test_cluster_path_without_absorbing_layer(oracle32, monkeypatch):
+    """No C-PML at all (W = 0: no memory variables, no strip tables) on several slabs."""
+    monkeypatch.setenv("MIFWI_EL_NW", "4")
+    _check_parity(oracle32, elastic_case(seed=39, nz=50, nx=66, fw=0, water=0, nt=90), bitwise=True)
+
+
 def test_cluster_path_on_the_widest_reference_grid_width(oracle32):
     """nx = 396 (the 170x396 grid of networks.py:8224): 99 groups per row, ten-row slabs."""
     case = elastic_case(seed=37, nz=64, nx=396, fw=10, ns=2, nrec=50, nt=100)
