@@ -435,7 +435,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     const bool do_x = p.NW > 1 && !(p.dbg & 1);
     auto receive = [&](int kind, unsigned epoch, int parity) {
         X.receive(kind, epoch, parity, [&](int is_a, int off, float v) {
-            c.Lf[kind == 0 ? (is_a ? F_VZ : F_VX) : (is_a ? F_SXZ : F_SZZ)][off] = v;
+            // plane address by arithmetic: indexing the pointer array with a run-time field would push the
+            // whole array into scratch memory (every access a vector-memory load)
+            (lds + (kind == 0 ? (is_a ? F_VZ : F_VX) : (is_a ? F_SXZ : F_SZZ)) * fsz)[off] = v;
         });
     };
     auto publish = [&](int lrw, int gq, int kind, unsigned epoch, int parity, const float4 &o0, const float4 &o1) {
@@ -805,16 +807,26 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         if (p.fsurf && jq == 0) bzz = zero4;              // adjoint of szz(0,.) is discarded
         if (p.grad_f != nullptr && g.src >= 0) {
             float *out = p.grad_f + ((long long)n * p.nshot + s) * p.nsrc;
+            // sxx + szz of the four cells, selected with compile-time lane indices: a run-time index into a
+            // float4 would move the whole field into scratch memory (vector-memory traffic in the time loop)
+            const float pr[4] = {g.bxx.x + bzz.x, g.bxx.y + bzz.y, g.bxx.z + bzz.z, g.bxx.w + bzz.w};
             if (!slow) {
-                const int c = g.src & 3;
-                out[g.src >> 2] = fmaf(g.src_wt, comp(g.bxx, c) + comp(bzz, c), 0.f);
+                float v = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c == (g.src & 3)) v = pr[c];
+                out[g.src >> 2] = fmaf(g.src_wt, v, 0.f);
             } else {                                      // several sources in this group: rescan
                 for (int e = 0; e < p.nsrc; ++e) {
                     const int cell = p.src_cell[(long long)s * p.nsrc + e];
                     if (cell < 0) continue;
                     const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
-                    if (i0 == jq && (i1 >> 2) == gq)
-                        out[e] = fmaf(p.src_w[(long long)s * p.nsrc + e], comp(g.bxx, i1 & 3) + comp(bzz, i1 & 3), 0.f);
+                    if (i0 != jq || (i1 >> 2) != gq) continue;
+                    float v = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c == (i1 & 3)) v = pr[c];
+                    out[e] = fmaf(p.src_w[(long long)s * p.nsrc + e], v, 0.f);
                 }
             }
         }
