@@ -803,8 +803,11 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         const unsigned gcc = (unsigned)(jq * p.gp + 4 * gq);
         const float4 Ls = ld4(p.mat + M_L * ncell + gcc), Ms = ld4(p.mat + M_M * ncell + gcc);
         const float4 mus = ld4(p.mat + M_MU * ncell + gcc);
-        float4 bzz = g.bzz;
-        if (p.fsurf && jq == 0) bzz = zero4;              // adjoint of szz(0,.) is discarded
+        // adjoint of szz(0,.) is discarded.  Component-wise selects: a whole-vector select was compiled
+        // into a two-entry table in scratch memory (a vector-memory load per use)
+        const bool top = p.fsurf && jq == 0;
+        const float4 bzz = make_float4(top ? 0.f : g.bzz.x, top ? 0.f : g.bzz.y, top ? 0.f : g.bzz.z,
+                                       top ? 0.f : g.bzz.w);
         if (p.grad_f != nullptr && g.src >= 0) {
             float *out = p.grad_f + ((long long)n * p.nshot + s) * p.nsrc;
             // sxx + szz of the four cells, selected with compile-time lane indices: a run-time index into a
@@ -949,8 +952,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         st4(pln + 3 * fsz + lo, D4);
         if (do_x && !g.inner) publish(jq - r0, gq, 1, (unsigned)(2 * it + 2), it & 1, D2, D4);
         // gradients (oracle order): Ms, Ls, mus from the old sigma_bar; bxs, bzs from the new v_bar
-        float4 bzz = g.bzz;
-        if (p.fsurf && jq == 0) bzz = zero4;
+        const bool top = p.fsurf && jq == 0;
+        const float4 bzz = make_float4(top ? 0.f : g.bzz.x, top ? 0.f : g.bzz.y, top ? 0.f : g.bzz.z,
+                                       top ? 0.f : g.bzz.w);
 #define EA_ACC3(dst, a, b, c_, d) dst = fmaf(a, b, fmaf(c_, d, dst))
         EA_ACC3(g.a1.x, g.S1.x, g.bxx.x, g.S2.x, bzz.x); EA_ACC3(g.a1.y, g.S1.y, g.bxx.y, g.S2.y, bzz.y);
         EA_ACC3(g.a1.z, g.S1.z, g.bxx.z, g.S2.z, bzz.z); EA_ACC3(g.a1.w, g.S1.w, g.bxx.w, g.S2.w, bzz.w);
