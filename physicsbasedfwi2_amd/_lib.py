@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmifwi.so")
+# MIFWI_LIB: load another build of the library (A/B timing of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("MIFWI_LIB") or os.path.join(_HERE, "libmifwi.so")
 
 MIFWI_OK = 0
 ZERO_STATE = 1
