@@ -125,3 +125,29 @@ def test_bad_arguments_fail_loudly():
         acoustic.propagate(torch.zeros(8, 8), torch.zeros(3, 1, 1), torch.zeros(8), torch.zeros(8),
                            torch.zeros(1, 1, 1, dtype=torch.int32), torch.ones(1, 1, 1),
                            torch.zeros(1, 1, 1, dtype=torch.int32), torch.ones(1, 1, 1))
+
+
+@pytest.mark.parametrize("family", ["1", "0"])
+def test_no_receivers_or_no_sources(monkeypatch, family):
+    """Empty point sets: shapes [ns, 0, ntap] must not fault and give empty / zero results."""
+    monkeypatch.setenv("MIFWI_AC_CLUSTER", family)
+    monkeypatch.setenv("MIFWI_EL_CLUSTER", family)
+    monkeypatch.setenv("MIFWI_EL_CLUSTER_ADJ", family)
+    case = acoustic_case(seed=91, n0=30, n1=40, nb=4, nt=20, ns=2, nrec=3)
+    none_r = dict(case, rc=case["rc"][:, :0], rw=case["rw"][:, :0])
+    r, f, rec = _ac(none_r, need_grad=False)
+    assert tuple(rec.shape) == (20, 2, 0)
+    none_s = dict(case, sc=case["sc"][:, :0], sw=case["sw"][:, :0], f=case["f"][:, :, :0])
+    r, f, rec = _ac(none_s)
+    assert tuple(rec.shape) == (20, 2, 3) and not rec.detach().cpu().numpy().any()
+    rec.backward(torch.ones_like(rec))
+    assert torch.isfinite(r.grad).all()
+    ec = elastic_case(seed=92, nz=30, nx=40, fw=4, nt=20, ns=2, nrec=3, water=3)
+    e0 = dict(ec, rc=ec["rc"][:, :0], rw=ec["rw"][:, :0])
+    mat, ef, rvx, rvz = _el(e0, need_grad=False)
+    assert tuple(rvx.shape) == (20, 2, 0)
+    e1 = dict(ec, sc=ec["sc"][:, :0], sw=ec["sw"][:, :0], f=ec["f"][:, :, :0])
+    mat, ef, rvx, rvz = _el(e1)
+    assert not rvx.detach().cpu().numpy().any()
+    torch.autograd.backward([rvx, rvz], [torch.ones_like(rvx), torch.ones_like(rvz)])
+    assert torch.isfinite(mat.grad).all()
