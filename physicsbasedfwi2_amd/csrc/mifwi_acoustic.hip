@@ -484,7 +484,10 @@ __device__ __forceinline__ int cl_opaque(int x)
     return x;
 }
 
-template <int MODE>   // 0: forward, 1: forward + snapshots, 2: adjoint + imaging, 3: Born (source G^n dr)
+// SLOW = false: at most one source per shot and at most kClThreads receivers / sources (decided by the
+// host from the sizes): every sparse point has a thread of its own and the rescanning paths are not even
+// compiled in - they cost ~8 % of the C2 gradient pass in SGPR/VGPR spills alone.  SLOW = true: general.
+template <int MODE, bool SLOW>   // MODE 0: forward, 1: forward + snapshots, 2: adjoint + imaging, 3: Born (source G^n dr)
 __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     int inj_off = -1, inj_id = -1;                       // adjoint injection into LDS
     bool inj_edge = false;
     float inj_scale = 0.f;
-    bool slow_sparse = false;                            // more points than one per thread: rescan per step
+    constexpr bool slow_sparse = SLOW;                   // more points than one per thread: rescan per step
     if (!adj) {
         for (int e = 0; e < p.nsrc; ++e) {
             const int cell = p.src_cell[(long long)s * p.nsrc + e];
@@ -577,12 +580,10 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
 #pragma unroll
             for (int i = 0; i < kClMaxNG; ++i)
                 if (i < nown && goff(i) == want) {
-                    if (src_slot >= 0) slow_sparse = true;
                     src_slot = i; src_comp = i1 & 3; src_e = e;
                     src_wt = p.src_w[(long long)s * p.nsrc + e];
                 }
         }
-        if (p.nrec > kClThreads) slow_sparse = true;
         if (p.rec_out != nullptr && t < p.nrec) {
             const int cell = p.rec_cell[(long long)s * p.nrec + t];
             smp_e = t;
@@ -598,7 +599,6 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         }
     } else {
         const int cnt = p.slab_cnt[s * p.NW + w];
-        if (cnt > kClThreads || p.nsrc > kClThreads) slow_sparse = true;
         if (t < cnt) {
             const int id = p.slab_list[((long long)s * p.NW + w) * p.nrec + t];
             const int cell = p.rec_cell[(long long)s * p.nrec + id];
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             }
         }
     }
-    slow_sparse = __syncthreads_or(slow_sparse ? 1 : 0) != 0;
+    __syncthreads();
 
     for (int e = t; e < p.gp; e += kClThreads) ldq1[e] = p.q1[e];
     for (int e = t; e < R; e += kClThreads) ldq0[e] = p.q0[r0 + e];
@@ -1030,8 +1030,10 @@ void cluster_setup(mifwi_acoustic_plan *pl)
     if (!pl->cluster) return;
     pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * pl->NW * 8 * pl->gp + 64, 64);   // granules + err word
     pl->list_elems = mifwi::round_up64((long long)pl->d.nshot * pl->NW * (1 + (long long)pl->d.nrec), 64);
-    for (const void *fn : {(const void *)ac_cluster<0>, (const void *)ac_cluster<1>, (const void *)ac_cluster<2>,
-                           (const void *)ac_cluster<3>})
+    for (const void *fn : {(const void *)ac_cluster<0, false>, (const void *)ac_cluster<1, false>,
+                           (const void *)ac_cluster<2, false>, (const void *)ac_cluster<3, false>,
+                           (const void *)ac_cluster<0, true>, (const void *)ac_cluster<1, true>,
+                           (const void *)ac_cluster<2, true>, (const void *)ac_cluster<3, true>})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mifwi::kClusterLdsLimit) != hipSuccess) {
             (void)hipGetLastError();           // not sticky: the plan simply uses one launch per step
             pl->cluster = 0;
@@ -1063,7 +1065,13 @@ int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStrea
         c.shot0 = s0;
         c.shot1 = std::min(pl->d.nshot, s0 + pl->cl_shots);
         const int nsl8 = mifwi::ceil_div(c.shot1 - s0, 8);
-        hipLaunchKernelGGL((ac_cluster<MODE>), dim3(8 * pl->NW * nsl8), dim3(kClThreads), pl->cl_lds, st, c);
+        // general (rescanning) variant only when a thread may own several sparse points
+        const bool general = MODE == 2 ? (c.nrec > kClThreads || c.nsrc > kClThreads)
+                                       : (c.nsrc > 1 || c.nrec > kClThreads);
+        if (general)
+            hipLaunchKernelGGL((ac_cluster<MODE, true>), dim3(8 * pl->NW * nsl8), dim3(kClThreads), pl->cl_lds, st, c);
+        else
+            hipLaunchKernelGGL((ac_cluster<MODE, false>), dim3(8 * pl->NW * nsl8), dim3(kClThreads), pl->cl_lds, st, c);
     }
     MIFWI_HIP_TRY(hipGetLastError());
     int err = 0;
