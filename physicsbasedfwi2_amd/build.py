@@ -44,4 +44,4 @@ def build(force=False, verbose=False, extra_flags=()):
 
 if __name__ == "__main__":
     build(force="-f" in sys.argv, verbose=True,
-          extra_flags=[a for a in sys.argv[1:] if a.startswith("-R") or a.startswith("-save")])
+          extra_flags=[a for a in sys.argv[1:] if a.startswith(("-R", "-save", "-D"))])

@@ -679,7 +679,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     const int nsteps = adj ? (p.n_first - p.n_last + 1) : (p.n_last - p.n_first);
     const long long plane = (long long)s * p.n0 * p.gp;
     bool failed = false;
-    const bool do_x = p.NW > 1 && !(p.dbg & 1);
+    const bool do_x = p.NW > 1 && !(kDbg(p) & 1);
     // forward: all four boundary rows live in slot 0 when a row has at most kClThreads/4 groups
     const bool early_pub = !adj && do_x && 4 * p.ng <= kClThreads;
     // adjoint: the same, once the receivers that sit IN the boundary rows have been injected (the other
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         const int n = adj ? (p.n_first - it) : (p.n_first + it);
         const float amp = amp_next;
         // ---- sampling of the current field (owner slab writes) -------------------------------
-        if (p.dbg & 8) {
+        if (kDbg(p) & 8) {
         } else if (!slow_sparse) {
             // uniform row base + a 32-bit lane offset: no per-lane 64-bit address to keep (or spill)
             float *out_n = adj ? p.grad_f + ((long long)n * p.nshot + s) * p.nsrc
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         const unsigned long long *xdn = xdn0 + (epoch & 1u) * 4 * p.gp;
 #pragma unroll
         for (int i = 0; i < kClMaxNG; ++i) {
-            if (i < nown && !(p.dbg & 4)) {
+            if (i < nown && !(kDbg(p) & 4)) {
                 float un[4], gk[4];
                 float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
                 float q0 = 0.f;
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         }
         // global traffic that nobody waits for goes AFTER the hand-off (vector memory operations
         // retire in order: a poll issued behind these would wait for them)
-        if (MODE == 1 && !(p.dbg & 2)) {
+        if (MODE == 1 && !(kDbg(p) & 2)) {
 #pragma unroll
             for (int i = 0; i < kClMaxNG; ++i)
                 if (i < nown) *reinterpret_cast<float4 *>(Gn + goff_of(cl_opaque(jg[i]))) = Gbuf[i];

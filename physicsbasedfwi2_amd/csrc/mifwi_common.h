@@ -48,6 +48,14 @@ inline int check_device(int device)
 // plan asks for the common cap and passes its own (smaller) size at launch.
 constexpr int kClusterLdsLimit = 150 * 1024;      // = the eligibility bound of every cluster plan
 
+// Timing ablations of the single-launch kernels (skip hand-off / snapshot stream / waiting; wrong results)
+// exist only in builds with -DMIFWI_ABLATIONS; the shipped kernels do not carry the tests.
+#ifdef MIFWI_ABLATIONS
+#define kDbg(p) ((p).dbg)
+#else
+#define kDbg(p) 0
+#endif
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

@@ -431,8 +431,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 
     // ---- halo hand-off: kind 0 = velocities after V, kind 1 = stresses after S ------------------
     EcHandoff X;
-    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, (p.dbg & 4) != 0);
-    const bool do_x = p.NW > 1 && !(p.dbg & 1);
+    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, (kDbg(p) & 4) != 0);
+    const bool do_x = p.NW > 1 && !(kDbg(p) & 1);
     auto receive = [&](int kind, unsigned epoch, int parity) {
         X.receive(kind, epoch, parity, [&](int is_a, int off, float v) {
             // plane address by arithmetic: indexing the pointer array with a run-time field would push the
@@ -480,8 +480,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         const int gq = ec_opaque(g.g), jq = ec_opaque(g.j), lrw = jq - r0, lo = (lrw + 2) * PL + 4 + 4 * gq;
         if (edge) ec_update_v<true>(g, c, lo, gq, lrw, S4, S5, o0, o1);
         else ec_update_v<false>(g, c, lo, gq, lrw, S4, S5, o0, o1);
-        if (edge && do_x && !(p.dbg & 16)) publish(lrw, gq, 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
-        if (SAVE && !(p.dbg & 2)) {
+        if (edge && do_x && !(kDbg(p) & 16)) publish(lrw, gq, 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
+        if (SAVE && !(kDbg(p) & 2)) {
             float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(jq * p.gp + 4 * gq);
             st4(Sn + 3 * (long long)ncell, S4); st4(Sn + 4 * (long long)ncell, S5);
         }
@@ -492,8 +492,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         const float4 amp = source_amp(g, q, n);
         if (edge) ec_update_s<true>(g, c, lo, gq, lrw, amp, S1, S2, S3, o0, o1);
         else ec_update_s<false>(g, c, lo, gq, lrw, amp, S1, S2, S3, o0, o1);
-        if (edge && do_x && !(p.dbg & 16)) publish(lrw, gq, 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
-        if (SAVE && !(p.dbg & 2)) {
+        if (edge && do_x && !(kDbg(p) & 16)) publish(lrw, gq, 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
+        if (SAVE && !(kDbg(p) & 2)) {
             float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(jq * p.gp + 4 * gq);
             st4(Sn, S1); st4(Sn + (long long)ncell, S2); st4(Sn + 2 * (long long)ncell, S3);
         }
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
             if (G[q].inner) do_v(G[q], n, it, false);
             __builtin_amdgcn_sched_barrier(0);             // one group at a time: bounds the register peak
         }
-        if (do_x && it > 0 && !(p.dbg & 32)) receive(1, (unsigned)(2 * it), (it - 1) & 1);
+        if (do_x && it > 0 && !(kDbg(p) & 32)) receive(1, (unsigned)(2 * it), (it - 1) & 1);
         __syncthreads();                                   // A: stress halo rows are in LDS
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
@@ -520,9 +520,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
             if (G[q].inner) do_s(G[q], q, n, it, false);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (do_x && !(p.dbg & 32)) receive(0, (unsigned)(2 * it + 1), it & 1);
+        if (do_x && !(kDbg(p) & 32)) receive(0, (unsigned)(2 * it + 1), it & 1);
         // ---- receivers sample the new velocities (stores after the poll) ----------------------------
-        if (p.rec_vx != nullptr && !(p.dbg & 8)) {
+        if (p.rec_vx != nullptr && !(kDbg(p) & 8)) {
             if (!slow) {
                 const long long ro = ((long long)n * p.nshot + s) * p.nrec + t;
                 if (smp_lo >= 0) {
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     // ---- halo hand-off: kind 0 = E2 (plane 1), E3 (plane 2); kind 1 = D2 (plane 1), D4 (plane 3) ----
     EcHandoff X;
     X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, false);
-    const bool do_x = p.NW > 1 && !(p.dbg & 1);
+    const bool do_x = p.NW > 1 && !(kDbg(p) & 1);
     auto receive = [&](int kind, unsigned epoch, int parity) {
         X.receive(kind, epoch, parity, [&](int is_a, int off, float v) {
             pln[(is_a ? (kind == 0 ? 2 : 3) : 1) * fsz + off] = v;
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     };
     const long long sshot = (long long)s * 5 * ncell;
     auto request_S = [&](EaGroup &g, int n) {
-        if (!g.own || (p.dbg & 2)) return;
+        if (!g.own || (kDbg(p) & 2)) return;
         const float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot +
                           (unsigned)(ec_opaque(g.j) * p.gp + 4 * ec_opaque(g.g));
         g.S1 = ld4(Sn); g.S2 = ld4(Sn + (long long)ncell); g.S3 = ld4(Sn + 2 * (long long)ncell);
