@@ -705,7 +705,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             const float *Gq = p.G + (long long)((adj ? n_ - 1 : n_) - p.g_first) * p.g_step + plane;
 #pragma unroll
             for (int i = 0; i < kClMaxNG; ++i)
-                if (i < nown) Gbuf[i] = *reinterpret_cast<const float4 *>(Gq + goff_of(cl_opaque(jg[i])));
+                if (i < nown) Gbuf[i] = mifwi::ldnt4(Gq + goff_of(cl_opaque(jg[i])));
         }
     };
     prefetch(0);
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         if (MODE == 1 && !(kDbg(p) & 2)) {
 #pragma unroll
             for (int i = 0; i < kClMaxNG; ++i)
-                if (i < nown) *reinterpret_cast<float4 *>(Gn + goff_of(cl_opaque(jg[i]))) = Gbuf[i];
+                if (i < nown) mifwi::stnt4(Gn + goff_of(cl_opaque(jg[i])), Gbuf[i]);
         }
         prefetch(it + 1);
         // a timed-out thread carries garbage forward until the next collective check (fatal anyway)

@@ -56,6 +56,21 @@ constexpr int kClusterLdsLimit = 150 * 1024;      // = the eligibility bound of 
 #define kDbg(p) 0
 #endif
 
+#ifdef __HIPCC__
+// write-once / read-once streams (snapshots): non-temporal accesses keep them out of the way of the
+// cache-resident planes
+typedef float mifwi_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stnt4(float *p, const float4 &v)
+{
+    __builtin_nontemporal_store(mifwi_v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<mifwi_v4f *>(p));
+}
+__device__ __forceinline__ float4 ldnt4(const float *p)
+{
+    const mifwi_v4f v = __builtin_nontemporal_load(reinterpret_cast<const mifwi_v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#endif
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

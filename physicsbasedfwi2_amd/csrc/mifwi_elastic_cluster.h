@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         if (edge && do_x && !(kDbg(p) & 16)) publish(lrw, gq, 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
         if (SAVE && !(kDbg(p) & 2)) {
             float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(jq * p.gp + 4 * gq);
-            st4(Sn + 3 * (long long)ncell, S4); st4(Sn + 4 * (long long)ncell, S5);
+            mifwi::stnt4(Sn + 3 * (long long)ncell, S4); mifwi::stnt4(Sn + 4 * (long long)ncell, S5);
         }
     };
     auto do_s = [&](EcGroup &g, int q, int n, int it, bool edge) {
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         if (edge && do_x && !(kDbg(p) & 16)) publish(lrw, gq, 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
         if (SAVE && !(kDbg(p) & 2)) {
             float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(jq * p.gp + 4 * gq);
-            st4(Sn, S1); st4(Sn + (long long)ncell, S2); st4(Sn + 2 * (long long)ncell, S3);
+            mifwi::stnt4(Sn, S1); mifwi::stnt4(Sn + (long long)ncell, S2); mifwi::stnt4(Sn + 2 * (long long)ncell, S3);
         }
     };
     for (int it = 0; it < nsteps; ++it) {
@@ -785,8 +785,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         if (!g.own || (kDbg(p) & 2)) return;
         const float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot +
                           (unsigned)(ec_opaque(g.j) * p.gp + 4 * ec_opaque(g.g));
-        g.S1 = ld4(Sn); g.S2 = ld4(Sn + (long long)ncell); g.S3 = ld4(Sn + 2 * (long long)ncell);
-        g.S4 = ld4(Sn + 3 * (long long)ncell); g.S5 = ld4(Sn + 4 * (long long)ncell);
+        g.S1 = mifwi::ldnt4(Sn); g.S2 = mifwi::ldnt4(Sn + (long long)ncell); g.S3 = mifwi::ldnt4(Sn + 2 * (long long)ncell);
+        g.S4 = mifwi::ldnt4(Sn + 3 * (long long)ncell); g.S5 = mifwi::ldnt4(Sn + 4 * (long long)ncell);
     };
     auto request_amp = [&](int n) {
         if (inj_lo >= 0 && n >= p.n_last) {
