@@ -186,9 +186,8 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
                     float *prow = prev + (long long)(j + 2) * p.pitch + col;
                     const float4 up = *reinterpret_cast<const float4 *>(prow);
                     float4 Gv = make_float4(0.f, 0.f, 0.f, 0.f), drv = Gv;
-                    if (IMAGE)
-                        Gv = *reinterpret_cast<const float4 *>(
-                            p.G + ((long long)s * p.n0 + j) * p.gp + 4 * g);
+                    if (IMAGE)          // snapshot stream: written once, read once -> non-temporal
+                        Gv = mifwi::ldnt4(p.G + ((long long)s * p.n0 + j) * p.gp + 4 * g);
                     if (IMAGE && p.born_dr)
                         drv = *reinterpret_cast<const float4 *>(p.born_dr + (long long)j * p.gp + 4 * g);
                     const float xs[8] = {L.x, L.y, w2.x, w2.y, w2.z, w2.w, R.x, R.y};
@@ -226,9 +225,8 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
                     }
                     *reinterpret_cast<float4 *>(prow) = make_float4(un[0], un[1], un[2], un[3]);
                     if (SAVE)
-                        *reinterpret_cast<float4 *>(p.G + ((long long)s * p.n0 + j) * p.gp +
-                                                    4 * g) =
-                            make_float4(gk[0], gk[1], gk[2], gk[3]);
+                        mifwi::stnt4(p.G + ((long long)s * p.n0 + j) * p.gp + 4 * g,
+                                     make_float4(gk[0], gk[1], gk[2], gk[3]));
                     if (IMAGE && !p.born_dr) {
                         acc[rz].x = fmaf(un[0], Gv.x, acc[rz].x);
                         acc[rz].y = fmaf(un[1], Gv.y, acc[rz].y);

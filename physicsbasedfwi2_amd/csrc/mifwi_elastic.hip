@@ -294,8 +294,8 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
             st4(vz + o, vzv);
             if (SAVE) {
                 float *Sp = p.S + (long long)s * 5 * ncell + cc;
-                st4(Sp + 3 * (long long)ncell, make_float4(s4v[0], s4v[1], s4v[2], s4v[3]));
-                st4(Sp + 4 * (long long)ncell, make_float4(s5v[0], s5v[1], s5v[2], s5v[3]));
+                mifwi::stnt4(Sp + 3 * (long long)ncell, make_float4(s4v[0], s4v[1], s4v[2], s4v[3]));
+                mifwi::stnt4(Sp + 4 * (long long)ncell, make_float4(s5v[0], s5v[1], s5v[2], s5v[3]));
             }
             a0 = a1; a1 = a2; a2 = a3;
             b0 = b1; b1 = b2; b2 = b3;
@@ -417,9 +417,9 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const E
                     st4(sxz + o, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
                     if (SAVE) {
                         float *Sp = p.S + (long long)s * 5 * ncell + cc;
-                        st4(Sp, make_float4(e1[0], e1[1], e1[2], e1[3]));
-                        st4(Sp + (long long)ncell, make_float4(e2[0], e2[1], e2[2], e2[3]));
-                        st4(Sp + 2 * (long long)ncell, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
+                        mifwi::stnt4(Sp, make_float4(e1[0], e1[1], e1[2], e1[3]));
+                        mifwi::stnt4(Sp + (long long)ncell, make_float4(e2[0], e2[1], e2[2], e2[3]));
+                        mifwi::stnt4(Sp + 2 * (long long)ncell, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
                     }
                     a0 = a1; a1 = a2; a2 = a3;
                     b0 = b1; b1 = b2; b2 = b3;
@@ -548,8 +548,8 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
             if (p.fsurf && oj == 0) bzz = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 bxz = ld4(fl + F_SXZ * fs + o);
             const float *Sp = p.S + (long long)s * 5 * ncell + occ;
-            const float4 S1 = ld4(Sp), S2 = ld4(Sp + (long long)ncell), S3 = ld4(Sp + 2 * (long long)ncell);
-            const float4 S4 = ld4(Sp + 3 * (long long)ncell), S5 = ld4(Sp + 4 * (long long)ncell);
+            const float4 S1 = mifwi::ldnt4(Sp), S2 = mifwi::ldnt4(Sp + (long long)ncell), S3 = mifwi::ldnt4(Sp + 2 * (long long)ncell);
+            const float4 S4 = mifwi::ldnt4(Sp + 3 * (long long)ncell), S5 = mifwi::ldnt4(Sp + 4 * (long long)ncell);
             float nvx[4], nvz[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
