@@ -878,7 +878,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                     failed = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(48);          // ~1.3 us: about one hand-off flight; short naps only add polling traffic
             }
 #pragma unroll
             for (int kk = 0; kk < kGr; ++kk)

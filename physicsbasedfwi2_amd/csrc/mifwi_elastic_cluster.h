@@ -144,7 +144,7 @@ struct EcHandoff {
                 failed = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(48);          // ~1.3 us: about one hand-off flight; short naps only add polling traffic
         }
 #pragma unroll
         for (int k = 0; k < kEcGr; ++k)
