@@ -333,6 +333,7 @@ struct ClParams {
     int rt;                      // rows of the first / last slab (0: even split), see slab_rows
     int shot0, shot1;            // shots [shot0, shot1) are handled by this launch
     int dbg;                     // timing experiments only: 1 = skip the halo hand-off, 2 = skip snapshots
+    int nap;                     // s_sleep units between poll passes (mifwi::poll_nap)
     int nt, n_first, n_last;     // forward: steps n_first..n_last-1 ; adjoint: k = n_first down to n_last
     float c0, c1;
     const float *r, *q0, *q1;
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                     failed = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(48);          // ~1.3 us: about one hand-off flight; short naps only add polling traffic
+                mifwi::poll_nap(p.nap);
             }
 #pragma unroll
             for (int kk = 0; kk < kGr; ++kk)
@@ -1052,6 +1053,8 @@ ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const flo
     c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
     c.err = reinterpret_cast<int *>(xbuf + 2LL * pl->d.nshot * pl->NW * 8 * pl->gp);
     c.dbg = env_int("MIFWI_AC_CL_DBG", 0);
+    // fat slabs nap long between poll passes, thin ones short (mifwi::poll_nap)
+    c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(pl->d.n0, pl->NW) >= 16 ? 48 : 1);
     return c;
 }
 

@@ -57,6 +57,18 @@ constexpr int kClusterLdsLimit = 150 * 1024;      // = the eligibility bound of 
 #endif
 
 #ifdef __HIPCC__
+// nap between two poll passes of a halo hand-off (s_sleep takes an immediate: four lengths, ~64 clocks each
+// unit).  Fat slabs (interior rows cover the flight, a miss means the neighbour is a good microsecond
+// behind) nap long - every extra pass is memory traffic in the way of the publishes; thin slabs, whose
+// step is the hand-off chain itself, nap short.
+__device__ __forceinline__ void poll_nap(int units)
+{
+    if (units >= 48) __builtin_amdgcn_s_sleep(48);
+    else if (units >= 16) __builtin_amdgcn_s_sleep(16);
+    else if (units >= 4) __builtin_amdgcn_s_sleep(4);
+    else __builtin_amdgcn_s_sleep(1);
+}
+
 // write-once / read-once streams (snapshots): non-temporal accesses keep them out of the way of the
 // cache-resident planes
 typedef float mifwi_v4f __attribute__((ext_vector_type(4)));

@@ -1073,6 +1073,7 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
         c.rec_cell = rec_cell; c.rec_w = rec_w;
         c.rec_vx = want_rec ? rec_vx : nullptr; c.rec_vz = want_rec ? rec_vz : nullptr;
         c.dbg = env_int("MIFWI_EL_CL_DBG", 0);
+        c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(d.nz, c.NW) >= 8 ? 48 : 1);   // mifwi::poll_nap
         return snap ? el_cluster_run<true>(pl, c, xbuf, st) : el_cluster_run<false>(pl, c, xbuf, st);
     }
     {
@@ -1161,6 +1162,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         c.rec_cell = rec_cell; c.rec_w = rec_w; c.g_vx = g_vx; c.g_vz = g_vz;
         c.slab_cnt = lists; c.slab_list = lists + (long long)d.nshot * pl->adj_NW;
         c.dbg = env_int("MIFWI_EL_CL_DBG", 0);
+        c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(d.nz, c.NW) >= 8 ? 48 : 1);   // mifwi::poll_nap
         MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
         c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
         c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);

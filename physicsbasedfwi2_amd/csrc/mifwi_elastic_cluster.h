@@ -39,7 +39,7 @@ struct EcParams {
     float *rec_vx, *rec_vz;              // [nt][nshot][nrec] or null
     unsigned long long *xbuf;            // [nshot][NW][2 kinds][2 parities][8*gp] granules
     int *err;
-    int dbg;
+    int dbg, nap;
 };
 
 __device__ __forceinline__ void ec_slab_rows(int nz, int NW, int w, int &r0, int &rows)
@@ -92,10 +92,12 @@ struct EcHandoff {
     unsigned rcv_meta;                   // per k: bit0 field A, bit1 comes from the slab above
     int *err;
     bool failed, no_wait;                // no_wait: timing ablation only (wrong results)
+    int nap;                             // s_sleep units between poll passes (mifwi::poll_nap)
 
     __device__ __forceinline__ void init(unsigned long long *xbuf, int s, int NW_, int w_, int R_, int PL, int gp_,
-                                         int ng_, int t_, int *err_, bool no_wait_)
+                                         int ng_, int t_, int *err_, bool no_wait_, int nap_)
     {
+        nap = nap_;
         gp = gp_; ng = ng_; NW = NW_; w = w_; R = R_; t = t_; err = err_; failed = false; no_wait = no_wait_;
         xslot = (long long)kEcRowFields * gp;
         xw = xbuf + ((long long)s * NW + w) * 4 * xslot;
@@ -144,7 +146,7 @@ struct EcHandoff {
                 failed = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(48);          // ~1.3 us: about one hand-off flight; short naps only add polling traffic
+            mifwi::poll_nap(nap);
         }
 #pragma unroll
         for (int k = 0; k < kEcGr; ++k)
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 
     // ---- halo hand-off: kind 0 = velocities after V, kind 1 = stresses after S ------------------
     EcHandoff X;
-    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, (kDbg(p) & 4) != 0);
+    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, (kDbg(p) & 4) != 0, p.nap);
     const bool do_x = p.NW > 1 && !(kDbg(p) & 1);
     auto receive = [&](int kind, unsigned epoch, int parity) {
         X.receive(kind, epoch, parity, [&](int is_a, int off, float v) {
@@ -621,7 +623,7 @@ struct EaParams {
     const int *slab_cnt, *slab_list;     // receivers per slab: [nshot][NW], [nshot][NW][nrec]
     unsigned long long *xbuf;
     int *err;
-    int dbg;
+    int dbg, nap;
 };
 
 // receivers of each slab (adjoint sources), one block per shot
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
 
     // ---- halo hand-off: kind 0 = E2 (plane 1), E3 (plane 2); kind 1 = D2 (plane 1), D4 (plane 3) ----
     EcHandoff X;
-    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, false);
+    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, false, p.nap);
     const bool do_x = p.NW > 1 && !(kDbg(p) & 1);
     auto receive = [&](int kind, unsigned epoch, int parity) {
         X.receive(kind, epoch, parity, [&](int is_a, int off, float v) {
