@@ -16,8 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 KERNELS = {   # kernel-name prefix -> (workload class, bench kernel label)
-    "ac_cluster<1>": (bench.AcousticMarmousi, "forward+save"),
-    "ac_cluster<2>": (bench.AcousticMarmousi, "adjoint+imaging"),
+    "ac_cluster<1,": (bench.AcousticMarmousi, "forward+save"),
+    "ac_cluster<2,": (bench.AcousticMarmousi, "adjoint+imaging"),
     "el_cluster_fwd<true": (bench.ElasticMarmousi, "forward+save"),
     "el_cluster_adj<": (bench.ElasticMarmousi, "adjoint+imaging"),
 }
