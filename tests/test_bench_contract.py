@@ -48,3 +48,21 @@ def test_committed_bench_line_has_the_contract_fields():
     wl = bench.AcousticMarmousi
     units = wl.nz * wl.nx * wl.nt * wl.shots_per_gpu * d["steps"]
     assert abs(d["value"] - units / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6) <= 1e-6 * d["value"]
+
+
+def test_pmc_tool_knows_the_kernels_the_bench_runs():
+    """tools/pmc_traffic.py maps kernel-name prefixes to bench labels: every prefix must match a kernel
+    of the committed kernel-trace summary, and the traffic file must cover both workloads."""
+    import csv
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    names = [r["Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+             for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_bench_default_kernel_stats.csv")))]
+    for pre in pmc_traffic.KERNELS:
+        assert any(n.startswith(pre) for n in names), pre
+    with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+        t = json.load(fh)
+    for wl in (bench.AcousticMarmousi, bench.ElasticMarmousi):
+        assert set(t[wl.name]) == {"forward+save", "adjoint+imaging"}
+        for rec in t[wl.name].values():
+            assert 0 < rec["bytes_per_cell_step"] < 80.0      # below the algorithmic figures of SURVEY 8d
