@@ -1061,6 +1061,7 @@ ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const flo
 template <int MODE>
 int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStream_t st)
 {
+    if (mifwi::fake_timeout()) return mifwi::kClusterTimedOut;
     MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
     for (int s0 = 0; s0 < pl->d.nshot; s0 += pl->cl_shots) {
         c.shot0 = s0;
@@ -1078,11 +1079,19 @@ int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStrea
     int err = 0;
     MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
     MIFWI_HIP_TRY(hipStreamSynchronize(st));
-    if (err != 0)
-        return mifwi::fail(MIFWI_EHIP, "cluster kernel: a halo hand-off timed out (not all %d workgroups "
-                           "were resident?); set MIFWI_AC_CLUSTER=0 to use one launch per step",
-                           8 * pl->NW * mifwi::ceil_div(std::min(pl->d.nshot, pl->cl_shots), 8));
-    return MIFWI_OK;
+    return err != 0 ? mifwi::kClusterTimedOut : MIFWI_OK;
+}
+
+// outcome of a single-launch attempt: done (return rc), or fall back to one launch per step
+bool cluster_done(int rc, int32_t flags, int *out)
+{
+    if (rc != mifwi::kClusterTimedOut) { *out = rc; return true; }
+    if (!(flags & MIFWI_ZERO_STATE)) {
+        *out = mifwi::fail(MIFWI_EHIP, "single-launch time loop: a halo hand-off timed out (not every workgroup was "
+                           "resident in time) on a resumed call; set MIFWI_AC_CLUSTER=0 to use one launch per step");
+        return true;
+    }
+    return false;                          // caller re-zeroes the state and runs the per-step family
 }
 
 }  // namespace
@@ -1212,7 +1221,9 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *pl, const float *r, const float 
         c.src_cell = src_cell; c.src_w = src_w; c.f = f;
         c.rec_cell = rec_cell; c.rec_w = rec_w; c.rec_out = (rec_out && d.nrec > 0) ? rec_out : nullptr;
         c.G = snap; c.g_first = n_begin; c.g_step = snap_step;
-        return snap ? cluster_run<1>(pl, c, xbuf, st) : cluster_run<0>(pl, c, xbuf, st);
+        int out = 0;
+        if (cluster_done(snap ? cluster_run<1>(pl, c, xbuf, st) : cluster_run<0>(pl, c, xbuf, st), flags, &out)) return out;
+        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * 2 * pl->field_elems, st));
     }
     for (int n = n_begin; n < n_end; ++n) {
         p.cur = (n & 1) ? ub : ua;
@@ -1258,7 +1269,9 @@ int mifwi_acoustic_born(mifwi_acoustic_plan *pl, const float *r, const float *q0
         c.rec_cell = rec_cell; c.rec_w = rec_w; c.rec_out = d.nrec > 0 ? drec_out : nullptr;
         c.G = const_cast<float *>(snap); c.g_first = snap_first; c.g_step = snap_step;
         c.born_dr = dr;
-        return cluster_run<3>(pl, c, xbuf, st);
+        int out = 0;
+        if (cluster_done(cluster_run<3>(pl, c, xbuf, st), flags, &out)) return out;
+        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * 2 * pl->field_elems, st));
     }
     AcParams p = base_params(pl, r, q0, q1);
     p.ninj = 0;
@@ -1315,6 +1328,7 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
     const long long snap_step = (long long)d.nshot * pl->coef_elems;
     // step k computes z^k from cur = z^{k+1}, prev = z^{k+2}; samples grad_f[k] from z^{k+1}.
     // Buffer parity is absolute in k so that a range can be resumed by a later call.
+    bool per_step = true;
     if (pl->cluster && k_hi >= k_lo) {
         float *xbuf = reinterpret_cast<float *>(bbox) + mifwi::round_up64(4LL * d.nshot, 64);
         int *lists = reinterpret_cast<int *>(xbuf + pl->xbuf_elems);
@@ -1328,10 +1342,16 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
         c.G = const_cast<float *>(snap); c.g_first = snap_first; c.g_step = snap_step;
         c.acc = acc;
         c.slab_cnt = lists; c.slab_list = lists + (long long)d.nshot * pl->NW;
-        rc = cluster_run<2>(pl, c, xbuf, st);
-        if (rc) return rc;
-    } else
-    for (int k = k_hi; k >= k_lo; --k) {
+        int out = 0;
+        if (cluster_done(cluster_run<2>(pl, c, xbuf, st), flags, &out)) {
+            if (out) return out;
+            per_step = false;
+        } else {
+            MIFWI_HIP_TRY(hipMemsetAsync(
+                work, 0, sizeof(float) * (2 * pl->field_elems + pl->ngroups * pl->coef_elems), st));
+        }
+    }
+    for (int k = k_hi; per_step && k >= k_lo; --k) {
         const int par = (d.nt - 1 - k) & 1;
         p.cur = par ? zb : za;
         p.prev = par ? za : zb;

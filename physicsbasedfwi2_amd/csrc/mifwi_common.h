@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/mifwi.h"
@@ -32,6 +33,18 @@ inline int fail(int code, const char *fmt, ...)
             return ::mifwi::fail(MIFWI_EHIP, "%s failed: %s (%s:%d)", #expr,             \
                                  hipGetErrorString(e__), __FILE__, __LINE__);            \
     } while (0)
+
+// Internal status of a single-launch time loop whose hand-off timed out (some workgroups were not
+// resident in time, e.g. another stream held CUs for a long kernel).  A call that started from a zero
+// state is then simply re-run with one launch per step; a resumed call cannot be (its input state has
+// been overwritten) and reports MIFWI_EHIP.
+constexpr int kClusterTimedOut = 1;
+
+inline bool fake_timeout()          // test hook: MIFWI_TEST_FAKE_TIMEOUT=1 exercises the fall-back on the host
+{
+    const char *v = getenv("MIFWI_TEST_FAKE_TIMEOUT");
+    return v && *v == '1';
+}
 
 inline int check_device(int device)
 {

@@ -907,6 +907,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
 template <bool SAVE>
 int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStream_t st)
 {
+    if (mifwi::fake_timeout()) return mifwi::kClusterTimedOut;
     MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
     c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
     c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
@@ -923,10 +924,19 @@ int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStr
     int err = 0;
     MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
     MIFWI_HIP_TRY(hipStreamSynchronize(st));
-    if (err != 0)
-        return mifwi::fail(MIFWI_EHIP, "elastic cluster kernel: a halo hand-off timed out; set "
-                           "MIFWI_EL_CLUSTER=0 to use one launch per half step");
-    return MIFWI_OK;
+    return err != 0 ? mifwi::kClusterTimedOut : MIFWI_OK;
+}
+
+// outcome of a single-launch attempt: done (return *out), or fall back to one launch per half step
+bool el_cluster_done(int rc, int32_t flags, int *out)
+{
+    if (rc != mifwi::kClusterTimedOut) { *out = rc; return true; }
+    if (!(flags & MIFWI_ZERO_STATE)) {
+        *out = mifwi::fail(MIFWI_EHIP, "single-launch time loop: a halo hand-off timed out (not every workgroup was "
+                           "resident in time) on a resumed call; set MIFWI_EL_CLUSTER=0 / MIFWI_EL_CLUSTER_ADJ=0");
+        return true;
+    }
+    return false;
 }
 
 }  // namespace
@@ -1074,7 +1084,11 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
         c.rec_vx = want_rec ? rec_vx : nullptr; c.rec_vz = want_rec ? rec_vz : nullptr;
         c.dbg = env_int("MIFWI_EL_CL_DBG", 0);
         c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(d.nz, c.NW) >= 8 ? 48 : 1);   // mifwi::poll_nap
-        return snap ? el_cluster_run<true>(pl, c, xbuf, st) : el_cluster_run<false>(pl, c, xbuf, st);
+        int out = 0;
+        if (el_cluster_done(snap ? el_cluster_run<true>(pl, c, xbuf, st) : el_cluster_run<false>(pl, c, xbuf, st),
+                            flags, &out))
+            return out;
+        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (pl->fields_elems + psi), st));
     }
     {
         p.fields = fbuf[0]; p.psix = pbuf[0]; p.psiz = pbuf[0] + pl->psix_elems;
@@ -1139,6 +1153,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
     const bool want_f = grad_f != nullptr && d.nsrc > 0;
     ps.nsmp = want_f ? d.nsrc : 0; ps.ntap_smp = d.ntap; ps.smp_cell = src_cell; ps.smp_w = src_w;
     const long long snap_step = 5LL * d.nshot * pl->coef_elems;
+    bool per_step = true;
     if (pl->cl_adj && n_hi >= n_lo) {
         float *xbuf = reinterpret_cast<float *>(bbox) + mifwi::round_up64(4LL * d.nshot, 64);
         int *lists = reinterpret_cast<int *>(xbuf + pl->xbuf_elems);
@@ -1166,7 +1181,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
         c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
         c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
-        for (int s0 = 0; s0 < d.nshot; s0 += pl->adj_shots) {
+        for (int s0 = 0; s0 < d.nshot && !mifwi::fake_timeout(); s0 += pl->adj_shots) {
             c.shot0 = s0;
             c.shot1 = std::min(d.nshot, s0 + pl->adj_shots);
             const int nsl8 = mifwi::ceil_div(c.shot1 - s0, 8);
@@ -1179,11 +1194,15 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         int err = 0;
         MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
         MIFWI_HIP_TRY(hipStreamSynchronize(st));
-        if (err != 0)
-            return mifwi::fail(MIFWI_EHIP, "elastic adjoint cluster kernel: a halo hand-off timed out; set "
-                               "MIFWI_EL_CLUSTER_ADJ=0 to use one launch per half step");
-    } else
-    for (int n = n_hi; n >= n_lo; --n) {
+        int out = 0;
+        if (el_cluster_done((err != 0 || mifwi::fake_timeout()) ? mifwi::kClusterTimedOut : MIFWI_OK, flags, &out)) {
+            if (out) return out;
+            per_step = false;
+        } else {
+            MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (pl->fields_elems + 2 * psi + nacc), st));
+        }
+    }
+    for (int n = n_hi; per_step && n >= n_lo; --n) {
         // ping-pong of the adjoint memory variables is absolute in n (resumable ranges)
         const int par = (d.nt - 1 - n) & 1;
         float *rd = par ? psiB : psiA, *wr = par ? psiA : psiB;
