@@ -65,6 +65,7 @@ struct ElParams {
     const float *smp_w;
     float *smp_out0, *smp_out1;
     int tiles_z;
+    int xcd;                     // 1: XCD-contiguous tile order (xcd_tile)
 };
 
 __device__ __forceinline__ float comp(const float4 &v, int c)
@@ -115,14 +116,29 @@ __device__ __forceinline__ int zstrip(const ElParams &p, int j)
     return -1;
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin in launch order, each XCD with an L2 of its own: with
+// the plain blockIdx -> tile map, neighbouring tiles never share an L2 and every halo row/column is
+// fetched from memory again.  Remap so that each XCD walks one contiguous, row-major run of the
+// (x, y) tiles of its z slice (a bijection on [0, gridDim.x * gridDim.y)).
+__device__ __forceinline__ void xcd_tile(const ElParams &p, int &bx, int &by)
+{
+    bx = (int)blockIdx.x; by = (int)blockIdx.y;
+    if (!p.xcd) return;
+    const unsigned gx = gridDim.x, n2 = gx * gridDim.y;
+    const unsigned L = blockIdx.x + gx * blockIdx.y;
+    const unsigned c = L & 7u, idx = L >> 3, q = n2 >> 3, r = n2 & 7u;
+    const unsigned T = c * q + (c < r ? c : r) + idx;
+    by = (int)(T / gx); bx = (int)(T - (unsigned)by * gx);
+}
+
 // ------------------------------------------------------------------------------------------------
 // sampling workgroups.  mode 0: out0 = sum w vx, out1 = sum w vz ; mode 1: out0 = sum w (sxx+szz)
 template <int MODE>
-__device__ void sample_points(const ElParams &p)
+__device__ void sample_points(const ElParams &p, int bx, int by)
 {
     if (p.smp_out0 == nullptr) return;
     const int nrb = (int)(gridDim.y - p.tiles_z) * (int)gridDim.x;
-    const int rb = ((int)blockIdx.y - p.tiles_z) * (int)gridDim.x + (int)blockIdx.x;
+    const int rb = (by - p.tiles_z) * (int)gridDim.x + bx;
     const int total = p.gs * p.nsmp;
     for (int e = rb * (int)blockDim.x + (int)threadIdx.x; e < total; e += nrb * (int)blockDim.x) {
         const int si = e / p.nsmp, ip = e - si * p.nsmp;
@@ -187,8 +203,10 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
 {
     constexpr int LZ = kThreads / LX;
     const int lx = (int)threadIdx.x % LX, lz = (int)threadIdx.x / LX;
-    const int g = (int)blockIdx.x * LX + lx;
-    const int j0 = ((int)blockIdx.y * LZ + lz) * RZ;
+    int bx, by;
+    xcd_tile(p, bx, by);
+    const int g = bx * LX + lx;
+    const int j0 = (by * LZ + lz) * RZ;
     if (g >= p.ng || j0 >= p.nz) return;
     const int s = (int)blockIdx.z;
     const unsigned fs = p.field_stride;
@@ -311,14 +329,16 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const E
 {
     constexpr int LZ = kThreads / LX;
     constexpr int TZ = LZ * RZ, TX = LX * 4;
-    if ((int)blockIdx.y >= p.tiles_z) {
-        sample_points<0>(p);
+    int bx, by;
+    xcd_tile(p, bx, by);
+    if (by >= p.tiles_z) {
+        sample_points<0>(p, bx, by);
         return;
     }
     __shared__ float inj[TZ * TX];
     const int lx = (int)threadIdx.x % LX, lz = (int)threadIdx.x / LX;
-    const int g = (int)blockIdx.x * LX + lx;
-    const int tile_j = (int)blockIdx.y * TZ, tile_i = (int)blockIdx.x * TX;
+    const int g = bx * LX + lx;
+    const int tile_j = by * TZ, tile_i = bx * TX;
     const int j0 = tile_j + lz * RZ;
     const bool active = (g < p.ng) && (j0 < p.nz);
     const unsigned fs = p.field_stride;
@@ -434,130 +454,191 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const E
 // adjoint launches.  Tile = TZ x (4*GXO) owned cells, staged on (TZ+4) x 4*(GXO+2) in LDS.
 // ================================================================================================
 constexpr int ATZ = 16;          // owned rows
-constexpr int AGX = 16;          // staged groups per row (14 owned + 1 halo group each side)
-constexpr int AGO = AGX - 2;     // owned groups per row
+constexpr int AGO = 16;          // owned groups per row: a quarter wave reads one contiguous LDS row
+constexpr int AGX = AGO + 2;     // staged groups per row (1 halo group each side)
 constexpr int ASZ = ATZ + 4;     // staged rows
-constexpr int ASX = 4 * AGX;     // staged columns
+constexpr int ASX = 4 * AGX;     // staged columns (72 floats: consecutive rows start 8 banks apart)
+static_assert(ATZ * AGO == kThreads, "one owned 4-cell group per thread");
+
+// x stencils on the 8 values {L.z, L.w, C.x .. C.w, R.x, R.y} around an owned group
+struct Row8 { float v[8]; };
+__device__ __forceinline__ Row8 row8(const float *row, int cb)
+{
+    const float4 l = ld4(row + cb - 4), c = ld4(row + cb), r = ld4(row + cb + 4);
+    return Row8{{l.z, l.w, c.x, c.y, c.z, c.w, r.x, r.y}};
+}
+
+// staged coordinates of the halo group a thread stages besides its own group (threads 0..kHalo-1):
+// the two rows above and below the tile, then the left/right halo group of every owned row
+constexpr int kHalo = 4 * AGX + 2 * ATZ;
+__device__ __forceinline__ void halo_item(int h, int &sr, int &sg)
+{
+    if (h < 4 * AGX) {
+        const int q = h / AGX;
+        sr = q < 2 ? q : ATZ + q;
+        sg = h - q * AGX;
+    } else {
+        const int k = h - 4 * AGX;
+        sr = 2 + (k >> 1);
+        sg = (k & 1) * (AGX - 1);
+    }
+}
+
+struct AdjIn { float4 a, b, c, m0, m1, m2; };
+
+// E1..E4 of one group: C^T sigma_bar through the transposed C-PML (memory variables written by the owner)
+__device__ __forceinline__ void stage_E(const ElParams &p, int s, int j, int g, const AdjIn &in, bool mine,
+                                        float4 &E1, float4 &E2, float4 &E3, float4 &E4)
+{
+    float e1[4], e2[4], e3[4], e4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        e1[c] = fmaf(comp(in.m1, c), comp(in.a, c), comp(in.m0, c) * comp(in.b, c));
+        e2[c] = fmaf(comp(in.m0, c), comp(in.a, c), comp(in.m1, c) * comp(in.b, c));
+        e3[c] = comp(in.m2, c) * comp(in.c, c);
+        e4[c] = e3[c];
+    }
+    const int xs_off = xstrip(p, g);
+    if (xs_off >= 0) {
+        const float4 pxa = ld4(p.px + PA * p.gp + 4 * g), pxb = ld4(p.px + PB * p.gp + 4 * g);
+        const float4 pxk = ld4(p.px + PK * p.gp + 4 * g), pxah = ld4(p.px + PAH * p.gp + 4 * g);
+        const float4 pxbh = ld4(p.px + PBH * p.gp + 4 * g), pxkh = ld4(p.px + PKH * p.gp + 4 * g);
+        const long long q5 = (long long)s * p.psix_shot + ((long long)2 * p.nz + j) * p.wx + xs_off;
+        const long long q8 = (long long)s * p.psix_shot + ((long long)3 * p.nz + j) * p.wx + xs_off;
+        const float4 s5 = ld4(p.psix + q5), s8 = ld4(p.psix + q8);
+        float n5[4], n8[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            e1[c] = pmlT(comp(s5, c), comp(pxa, c), comp(pxb, c), comp(pxk, c), e1[c], n5[c]);
+            e4[c] = pmlT(comp(s8, c), comp(pxah, c), comp(pxbh, c), comp(pxkh, c), e4[c], n8[c]);
+        }
+        if (mine) {
+            st4(p.psix_out + q5, make_float4(n5[0], n5[1], n5[2], n5[3]));
+            st4(p.psix_out + q8, make_float4(n8[0], n8[1], n8[2], n8[3]));
+        }
+    }
+    const int zs = zstrip(p, j);
+    if (zs >= 0) {
+        const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
+        const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
+        const long long q6 = (long long)s * p.psiz_shot + ((long long)2 * 2 * p.W + zs) * p.gp + 4 * g;
+        const long long q7 = (long long)s * p.psiz_shot + ((long long)3 * 2 * p.W + zs) * p.gp + 4 * g;
+        const float4 s6 = ld4(p.psiz + q6), s7 = ld4(p.psiz + q7);
+        float n6[4], n7[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            e2[c] = pmlT(comp(s6, c), za, zb, zk, e2[c], n6[c]);
+            e3[c] = pmlT(comp(s7, c), zah, zbh, zkh, e3[c], n7[c]);
+        }
+        if (mine) {
+            st4(p.psiz_out + q6, make_float4(n6[0], n6[1], n6[2], n6[3]));
+            st4(p.psiz_out + q7, make_float4(n7[0], n7[1], n7[2], n7[3]));
+        }
+    }
+    E1 = make_float4(e1[0], e1[1], e1[2], e1[3]); E2 = make_float4(e2[0], e2[1], e2[2], e2[3]);
+    E3 = make_float4(e3[0], e3[1], e3[2], e3[3]); E4 = make_float4(e4[0], e4[1], e4[2], e4[3]);
+}
 
 // S^T:  E = C^T sigma_bar through the transposed C-PML;  v_bar -= stencils(E);  v_bar += R^T g;
 //       all five material-gradient accumulators.
-__global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
+// Every global load of a shot (own group, halo group, adjoint velocities, the five snapshot planes) is
+// requested before the first use: one memory round trip per shot instead of three.
+#ifndef MIFWI_ADJ_S_MINWAVES
+#define MIFWI_ADJ_S_MINWAVES 1
+#endif
+__global__ __launch_bounds__(kThreads, MIFWI_ADJ_S_MINWAVES) void el_adj_s(const ElParams p)
 {
-    if ((int)blockIdx.y >= p.tiles_z) {
-        sample_points<1>(p);
+    int bx, by;
+    xcd_tile(p, bx, by);
+    if (by >= p.tiles_z) {
+        sample_points<1>(p, bx, by);
         return;
     }
     __shared__ float E[4][ASZ][ASX];
     __shared__ float inj[2 * ATZ * 4 * AGO];
-    const int tile_j = (int)blockIdx.y * ATZ;
-    const int tile_g = (int)blockIdx.x * AGO;           // first owned group
+    const int tile_j = by * ATZ;
+    const int tile_g = bx * AGO;           // first owned group
     const unsigned fs = p.field_stride;
     const unsigned ncell = (unsigned)p.nz * p.gp;
-    // stencil-phase ownership: thread t -> (row t / AGO, group t % AGO) for t < ATZ*AGO
     const int t = (int)threadIdx.x;
-    const bool owner = t < ATZ * AGO;
     const int orow = t / AGO, ogrp = t % AGO;
     const int oj = tile_j + orow, og = tile_g + ogrp;
-    const bool own_ok = owner && oj < p.nz && og < p.ng;
+    const bool own_ok = oj < p.nz && og < p.ng;
     const unsigned occ = (unsigned)oj * p.gp + 4 * og;
+    const unsigned oo = (unsigned)(oj + 2) * p.pitch + 4 + 4 * og;
+    int hr = 0, hg = 0;
+    if (t < kHalo) halo_item(t, hr, hg);
+    const int hj = tile_j - 2 + hr, hgg = tile_g - 1 + hg;
+    const bool halo_ok = t < kHalo && hj >= 0 && hj < p.nz && hgg >= 0 && hgg < p.ng;
+    const unsigned hcc = (unsigned)hj * p.gp + 4 * hgg;
+    const unsigned ho = (unsigned)(hj + 2) * p.pitch + 4 + 4 * hgg;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc[5];
+    AdjIn own, halo;
+    own.m0 = own.m1 = own.m2 = halo.m0 = halo.m1 = halo.m2 = zero4;
     if (own_ok) {
 #pragma unroll
         for (int k = 0; k < 5; ++k)
             acc[k] = ld4(p.acc + ((long long)blockIdx.z * 5 + k) * ncell + occ);
+        own.m0 = ld4(p.mat + M_L * ncell + occ); own.m1 = ld4(p.mat + M_M * ncell + occ);
+        own.m2 = ld4(p.mat + M_MU * ncell + occ);
+    }
+    if (halo_ok) {
+        halo.m0 = ld4(p.mat + M_L * ncell + hcc); halo.m1 = ld4(p.mat + M_M * ncell + hcc);
+        halo.m2 = ld4(p.mat + M_MU * ncell + hcc);
     }
     for (int si = 0; si < p.gs; ++si) {
         const int s = (int)blockIdx.z * p.gs + si;
         if (s >= p.nshot) break;
         float *fl = p.fields + (long long)s * p.shot_stride;
+        float4 vxb = zero4, vzb = zero4, S1 = zero4, S2 = zero4, S3 = zero4, S4 = zero4, S5 = zero4;
+        own.a = own.b = own.c = halo.a = halo.b = halo.c = zero4;
+        if (own_ok) {
+            own.a = ld4(fl + F_SXX * fs + oo); own.b = ld4(fl + F_SZZ * fs + oo); own.c = ld4(fl + F_SXZ * fs + oo);
+        }
+        if (halo_ok) {
+            halo.a = ld4(fl + F_SXX * fs + ho); halo.b = ld4(fl + F_SZZ * fs + ho); halo.c = ld4(fl + F_SXZ * fs + ho);
+        }
+        if (own_ok) {
+            vxb = ld4(fl + F_VX * fs + oo); vzb = ld4(fl + F_VZ * fs + oo);
+            const float *Sp = p.S + (long long)s * 5 * ncell + occ;
+            S1 = mifwi::ldnt4(Sp); S2 = mifwi::ldnt4(Sp + (long long)ncell); S3 = mifwi::ldnt4(Sp + 2 * (long long)ncell);
+            S4 = mifwi::ldnt4(Sp + 3 * (long long)ncell); S5 = mifwi::ldnt4(Sp + 4 * (long long)ncell);
+        }
         const bool has_inj = stage_injection<ATZ, 4 * AGO, 2>(p, s, tile_j, 4 * tile_g, inj);
         // ---- stage E1..E4 on the tile + halo -------------------------------------------------
-        for (int e = t; e < ASZ * AGX; e += kThreads) {
-            const int sr = e / AGX, sg = e - sr * AGX;
-            const int j = tile_j - 2 + sr, g = tile_g - 1 + sg;
-            float4 E1 = make_float4(0.f, 0.f, 0.f, 0.f), E2 = E1, E3 = E1, E4 = E1;
-            if (j >= 0 && j < p.nz && g >= 0 && g < p.ng) {
-                const unsigned o = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
-                const unsigned cc = (unsigned)j * p.gp + 4 * g;
-                const float4 bxx = ld4(fl + F_SXX * fs + o);
-                float4 bzz = ld4(fl + F_SZZ * fs + o);
-                if (p.fsurf && j == 0) bzz = make_float4(0.f, 0.f, 0.f, 0.f);   // adjoint of szz(0,.) is discarded
-                const float4 bxz = ld4(fl + F_SXZ * fs + o);
-                const float4 Ls = ld4(p.mat + M_L * ncell + cc), Ms = ld4(p.mat + M_M * ncell + cc);
-                const float4 mus = ld4(p.mat + M_MU * ncell + cc);
-                float e1[4], e2[4], e3[4], e4[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    e1[c] = fmaf(comp(Ms, c), comp(bxx, c), comp(Ls, c) * comp(bzz, c));
-                    e2[c] = fmaf(comp(Ls, c), comp(bxx, c), comp(Ms, c) * comp(bzz, c));
-                    e3[c] = comp(mus, c) * comp(bxz, c);
-                    e4[c] = e3[c];
-                }
-                const bool mine = (sr >= 2 && sr < 2 + ATZ && sg >= 1 && sg <= AGO);
-                const int xs_off = xstrip(p, g);
-                if (xs_off >= 0) {
-                    const float4 pxa = ld4(p.px + PA * p.gp + 4 * g), pxb = ld4(p.px + PB * p.gp + 4 * g);
-                    const float4 pxk = ld4(p.px + PK * p.gp + 4 * g), pxah = ld4(p.px + PAH * p.gp + 4 * g);
-                    const float4 pxbh = ld4(p.px + PBH * p.gp + 4 * g), pxkh = ld4(p.px + PKH * p.gp + 4 * g);
-                    const long long q5 = (long long)s * p.psix_shot + ((long long)2 * p.nz + j) * p.wx + xs_off;
-                    const long long q8 = (long long)s * p.psix_shot + ((long long)3 * p.nz + j) * p.wx + xs_off;
-                    const float4 s5 = ld4(p.psix + q5), s8 = ld4(p.psix + q8);
-                    float n5[4], n8[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        e1[c] = pmlT(comp(s5, c), comp(pxa, c), comp(pxb, c), comp(pxk, c), e1[c], n5[c]);
-                        e4[c] = pmlT(comp(s8, c), comp(pxah, c), comp(pxbh, c), comp(pxkh, c), e4[c], n8[c]);
-                    }
-                    if (mine) {
-                        st4(p.psix_out + q5, make_float4(n5[0], n5[1], n5[2], n5[3]));
-                        st4(p.psix_out + q8, make_float4(n8[0], n8[1], n8[2], n8[3]));
-                    }
-                }
-                const int zs = zstrip(p, j);
-                if (zs >= 0) {
-                    const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
-                    const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
-                    const long long q6 = (long long)s * p.psiz_shot + ((long long)2 * 2 * p.W + zs) * p.gp + 4 * g;
-                    const long long q7 = (long long)s * p.psiz_shot + ((long long)3 * 2 * p.W + zs) * p.gp + 4 * g;
-                    const float4 s6 = ld4(p.psiz + q6), s7 = ld4(p.psiz + q7);
-                    float n6[4], n7[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        e2[c] = pmlT(comp(s6, c), za, zb, zk, e2[c], n6[c]);
-                        e3[c] = pmlT(comp(s7, c), zah, zbh, zkh, e3[c], n7[c]);
-                    }
-                    if (mine) {
-                        st4(p.psiz_out + q6, make_float4(n6[0], n6[1], n6[2], n6[3]));
-                        st4(p.psiz_out + q7, make_float4(n7[0], n7[1], n7[2], n7[3]));
-                    }
-                }
-                E1 = make_float4(e1[0], e1[1], e1[2], e1[3]); E2 = make_float4(e2[0], e2[1], e2[2], e2[3]);
-                E3 = make_float4(e3[0], e3[1], e3[2], e3[3]); E4 = make_float4(e4[0], e4[1], e4[2], e4[3]);
-            }
-            st4(&E[0][sr][4 * sg], E1); st4(&E[1][sr][4 * sg], E2);
-            st4(&E[2][sr][4 * sg], E3); st4(&E[3][sr][4 * sg], E4);
+        if (p.fsurf && oj == 0) own.b = zero4;            // adjoint of szz(0,.) is discarded
+        if (p.fsurf && hj == 0) halo.b = zero4;
+        {
+            float4 E1 = zero4, E2 = zero4, E3 = zero4, E4 = zero4;
+            if (own_ok) stage_E(p, s, oj, og, own, true, E1, E2, E3, E4);
+            const int x = 4 * (ogrp + 1);
+            st4(&E[0][orow + 2][x], E1); st4(&E[1][orow + 2][x], E2);
+            st4(&E[2][orow + 2][x], E3); st4(&E[3][orow + 2][x], E4);
+        }
+        if (t < kHalo) {
+            float4 E1 = zero4, E2 = zero4, E3 = zero4, E4 = zero4;
+            if (halo_ok) stage_E(p, s, hj, hgg, halo, false, E1, E2, E3, E4);
+            st4(&E[0][hr][4 * hg], E1); st4(&E[1][hr][4 * hg], E2);
+            st4(&E[2][hr][4 * hg], E3); st4(&E[3][hr][4 * hg], E4);
         }
         __syncthreads();
         // ---- stencils from LDS + injection + gradient accumulation ---------------------------
         if (own_ok) {
-            const unsigned o = (unsigned)(oj + 2) * p.pitch + 4 + 4 * og;
             const int r = orow + 2, cb = 4 * (ogrp + 1);
-            float4 vxb = ld4(fl + F_VX * fs + o), vzb = ld4(fl + F_VZ * fs + o);
-            const float4 bxx = ld4(fl + F_SXX * fs + o);
-            float4 bzz = ld4(fl + F_SZZ * fs + o);
-            if (p.fsurf && oj == 0) bzz = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 bxz = ld4(fl + F_SXZ * fs + o);
-            const float *Sp = p.S + (long long)s * 5 * ncell + occ;
-            const float4 S1 = mifwi::ldnt4(Sp), S2 = mifwi::ldnt4(Sp + (long long)ncell), S3 = mifwi::ldnt4(Sp + 2 * (long long)ncell);
-            const float4 S4 = mifwi::ldnt4(Sp + 3 * (long long)ncell), S5 = mifwi::ldnt4(Sp + 4 * (long long)ncell);
+            const float4 bxx = own.a, bzz = own.b, bxz = own.c;
             float nvx[4], nvz[4];
+            const Row8 x1 = row8(&E[0][r][0], cb), x4 = row8(&E[3][r][0], cb);
+            const float4 z3a = ld4(&E[2][r - 2][cb]), z3b = ld4(&E[2][r - 1][cb]);
+            const float4 z3c = ld4(&E[2][r][cb]), z3d = ld4(&E[2][r + 1][cb]);
+            const float4 z2a = ld4(&E[1][r - 1][cb]), z2b = ld4(&E[1][r][cb]);
+            const float4 z2c = ld4(&E[1][r + 1][cb]), z2d = ld4(&E[1][r + 2][cb]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int x = cb + c;
-                const float dx1 = dfw(E[0][r][x - 1], E[0][r][x], E[0][r][x + 1], E[0][r][x + 2]);
-                const float dz3 = dbw(E[2][r - 2][x], E[2][r - 1][x], E[2][r][x], E[2][r + 1][x]);
-                const float dz2 = dfw(E[1][r - 1][x], E[1][r][x], E[1][r + 1][x], E[1][r + 2][x]);
-                const float dx4 = dbw(E[3][r][x - 2], E[3][r][x - 1], E[3][r][x], E[3][r][x + 1]);
+                const float dx1 = dfw(x1.v[c + 1], x1.v[c + 2], x1.v[c + 3], x1.v[c + 4]);
+                const float dz3 = dbw(comp(z3a, c), comp(z3b, c), comp(z3c, c), comp(z3d, c));
+                const float dz2 = dfw(comp(z2a, c), comp(z2b, c), comp(z2c, c), comp(z2d, c));
+                const float dx4 = dbw(x4.v[c], x4.v[c + 1], x4.v[c + 2], x4.v[c + 3]);
                 float ax = comp(vxb, c) - (dx1 + dz3);
                 float az = comp(vzb, c) - (dz2 + dx4);
                 if (has_inj) {
@@ -567,8 +648,8 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
                 if (4 * og + c >= p.nx) { ax = 0.f; az = 0.f; }
                 nvx[c] = ax; nvz[c] = az;
             }
-            st4(fl + F_VX * fs + o, make_float4(nvx[0], nvx[1], nvx[2], nvx[3]));
-            st4(fl + F_VZ * fs + o, make_float4(nvz[0], nvz[1], nvz[2], nvz[3]));
+            st4(fl + F_VX * fs + oo, make_float4(nvx[0], nvx[1], nvx[2], nvx[3]));
+            st4(fl + F_VZ * fs + oo, make_float4(nvz[0], nvz[1], nvz[2], nvz[3]));
             // gradients (oracle order): Ms, Ls, mus from sigma_bar; bxs, bzs from the new v_bar
 #define ACC3(dst, a, b, c_, d) dst = fmaf(a, b, fmaf(c_, d, dst))
             ACC3(acc[M_M].x, S1.x, bxx.x, S2.x, bzz.x); ACC3(acc[M_M].y, S1.y, bxx.y, S2.y, bzz.y);
@@ -592,107 +673,139 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
     }
 }
 
+// D1..D4 of one group: B^T v_bar through the transposed C-PML
+__device__ __forceinline__ void stage_D(const ElParams &p, int s, int j, int g, const float4 &vxb, const float4 &vzb,
+                                        const float4 &bxs, const float4 &bzs, bool mine,
+                                        float4 &D1, float4 &D2, float4 &D3, float4 &D4)
+{
+    float d1[4], d2[4], d3[4], d4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        d1[c] = comp(bxs, c) * comp(vxb, c); d2[c] = d1[c];
+        d3[c] = comp(bzs, c) * comp(vzb, c); d4[c] = d3[c];
+    }
+    const int xs_off = xstrip(p, g);
+    if (xs_off >= 0) {
+        const float4 pxa = ld4(p.px + PA * p.gp + 4 * g), pxb = ld4(p.px + PB * p.gp + 4 * g);
+        const float4 pxk = ld4(p.px + PK * p.gp + 4 * g), pxah = ld4(p.px + PAH * p.gp + 4 * g);
+        const float4 pxbh = ld4(p.px + PBH * p.gp + 4 * g), pxkh = ld4(p.px + PKH * p.gp + 4 * g);
+        const long long q1 = (long long)s * p.psix_shot + ((long long)0 * p.nz + j) * p.wx + xs_off;
+        const long long q3 = (long long)s * p.psix_shot + ((long long)1 * p.nz + j) * p.wx + xs_off;
+        const float4 s1 = ld4(p.psix + q1), s3 = ld4(p.psix + q3);
+        float n1[4], n3[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            d1[c] = pmlT(comp(s1, c), comp(pxah, c), comp(pxbh, c), comp(pxkh, c), d1[c], n1[c]);
+            d3[c] = pmlT(comp(s3, c), comp(pxa, c), comp(pxb, c), comp(pxk, c), d3[c], n3[c]);
+        }
+        if (mine) {
+            st4(p.psix_out + q1, make_float4(n1[0], n1[1], n1[2], n1[3]));
+            st4(p.psix_out + q3, make_float4(n3[0], n3[1], n3[2], n3[3]));
+        }
+    }
+    const int zs = zstrip(p, j);
+    if (zs >= 0) {
+        const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
+        const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
+        const long long q2 = (long long)s * p.psiz_shot + ((long long)0 * 2 * p.W + zs) * p.gp + 4 * g;
+        const long long q4 = (long long)s * p.psiz_shot + ((long long)1 * 2 * p.W + zs) * p.gp + 4 * g;
+        const float4 s2 = ld4(p.psiz + q2), s4 = ld4(p.psiz + q4);
+        float n2[4], n4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            d2[c] = pmlT(comp(s2, c), za, zb, zk, d2[c], n2[c]);
+            d4[c] = pmlT(comp(s4, c), zah, zbh, zkh, d4[c], n4[c]);
+        }
+        if (mine) {
+            st4(p.psiz_out + q2, make_float4(n2[0], n2[1], n2[2], n2[3]));
+            st4(p.psiz_out + q4, make_float4(n4[0], n4[1], n4[2], n4[3]));
+        }
+    }
+    D1 = make_float4(d1[0], d1[1], d1[2], d1[3]); D2 = make_float4(d2[0], d2[1], d2[2], d2[3]);
+    D3 = make_float4(d3[0], d3[1], d3[2], d3[3]); D4 = make_float4(d4[0], d4[1], d4[2], d4[3]);
+}
+
 // V^T:  D = B^T v_bar through the transposed C-PML;  sigma_bar -= stencils(D)
 __global__ __launch_bounds__(kThreads) void el_adj_v(const ElParams p)
 {
     __shared__ float D[4][ASZ][ASX];
-    const int tile_j = (int)blockIdx.y * ATZ;
-    const int tile_g = (int)blockIdx.x * AGO;
+    int bx, by;
+    xcd_tile(p, bx, by);
+    const int tile_j = by * ATZ;
+    const int tile_g = bx * AGO;
     const int s = (int)blockIdx.z;
     const unsigned fs = p.field_stride;
     const unsigned ncell = (unsigned)p.nz * p.gp;
     const int t = (int)threadIdx.x;
     float *fl = p.fields + (long long)s * p.shot_stride;
-    for (int e = t; e < ASZ * AGX; e += kThreads) {
-        const int sr = e / AGX, sg = e - sr * AGX;
-        const int j = tile_j - 2 + sr, g = tile_g - 1 + sg;
-        float4 D1 = make_float4(0.f, 0.f, 0.f, 0.f), D2 = D1, D3 = D1, D4 = D1;
-        if (j >= 0 && j < p.nz && g >= 0 && g < p.ng) {
-            const unsigned o = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
-            const unsigned cc = (unsigned)j * p.gp + 4 * g;
-            const float4 vxb = ld4(fl + F_VX * fs + o), vzb = ld4(fl + F_VZ * fs + o);
-            const float4 bxs = ld4(p.mat + M_BX * ncell + cc), bzs = ld4(p.mat + M_BZ * ncell + cc);
-            float d1[4], d2[4], d3[4], d4[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                d1[c] = comp(bxs, c) * comp(vxb, c); d2[c] = d1[c];
-                d3[c] = comp(bzs, c) * comp(vzb, c); d4[c] = d3[c];
-            }
-            const bool mine = (sr >= 2 && sr < 2 + ATZ && sg >= 1 && sg <= AGO);
-            const int xs_off = xstrip(p, g);
-            if (xs_off >= 0) {
-                const float4 pxa = ld4(p.px + PA * p.gp + 4 * g), pxb = ld4(p.px + PB * p.gp + 4 * g);
-                const float4 pxk = ld4(p.px + PK * p.gp + 4 * g), pxah = ld4(p.px + PAH * p.gp + 4 * g);
-                const float4 pxbh = ld4(p.px + PBH * p.gp + 4 * g), pxkh = ld4(p.px + PKH * p.gp + 4 * g);
-                const long long q1 = (long long)s * p.psix_shot + ((long long)0 * p.nz + j) * p.wx + xs_off;
-                const long long q3 = (long long)s * p.psix_shot + ((long long)1 * p.nz + j) * p.wx + xs_off;
-                const float4 s1 = ld4(p.psix + q1), s3 = ld4(p.psix + q3);
-                float n1[4], n3[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    d1[c] = pmlT(comp(s1, c), comp(pxah, c), comp(pxbh, c), comp(pxkh, c), d1[c], n1[c]);
-                    d3[c] = pmlT(comp(s3, c), comp(pxa, c), comp(pxb, c), comp(pxk, c), d3[c], n3[c]);
-                }
-                if (mine) {
-                    st4(p.psix_out + q1, make_float4(n1[0], n1[1], n1[2], n1[3]));
-                    st4(p.psix_out + q3, make_float4(n3[0], n3[1], n3[2], n3[3]));
-                }
-            }
-            const int zs = zstrip(p, j);
-            if (zs >= 0) {
-                const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
-                const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
-                const long long q2 = (long long)s * p.psiz_shot + ((long long)0 * 2 * p.W + zs) * p.gp + 4 * g;
-                const long long q4 = (long long)s * p.psiz_shot + ((long long)1 * 2 * p.W + zs) * p.gp + 4 * g;
-                const float4 s2 = ld4(p.psiz + q2), s4 = ld4(p.psiz + q4);
-                float n2[4], n4[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    d2[c] = pmlT(comp(s2, c), za, zb, zk, d2[c], n2[c]);
-                    d4[c] = pmlT(comp(s4, c), zah, zbh, zkh, d4[c], n4[c]);
-                }
-                if (mine) {
-                    st4(p.psiz_out + q2, make_float4(n2[0], n2[1], n2[2], n2[3]));
-                    st4(p.psiz_out + q4, make_float4(n4[0], n4[1], n4[2], n4[3]));
-                }
-            }
-            D1 = make_float4(d1[0], d1[1], d1[2], d1[3]); D2 = make_float4(d2[0], d2[1], d2[2], d2[3]);
-            D3 = make_float4(d3[0], d3[1], d3[2], d3[3]); D4 = make_float4(d4[0], d4[1], d4[2], d4[3]);
-        }
-        st4(&D[0][sr][4 * sg], D1); st4(&D[1][sr][4 * sg], D2);
-        st4(&D[2][sr][4 * sg], D3); st4(&D[3][sr][4 * sg], D4);
+    const int orow = t / AGO, ogrp = t % AGO;
+    const int oj = tile_j + orow, og = tile_g + ogrp;
+    const bool own_ok = oj < p.nz && og < p.ng;
+    const unsigned occ = (unsigned)oj * p.gp + 4 * og;
+    const unsigned oo = (unsigned)(oj + 2) * p.pitch + 4 + 4 * og;
+    int hr = 0, hg = 0;
+    if (t < kHalo) halo_item(t, hr, hg);
+    const int hj = tile_j - 2 + hr, hgg = tile_g - 1 + hg;
+    const bool halo_ok = t < kHalo && hj >= 0 && hj < p.nz && hgg >= 0 && hgg < p.ng;
+    const unsigned hcc = (unsigned)hj * p.gp + 4 * hgg;
+    const unsigned ho = (unsigned)(hj + 2) * p.pitch + 4 + 4 * hgg;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ovx = zero4, ovz = zero4, obx = zero4, obz = zero4, hvx = zero4, hvz = zero4, hbx = zero4, hbz = zero4;
+    float4 bxx = zero4, bzz = zero4, bxz = zero4;
+    if (own_ok) {
+        ovx = ld4(fl + F_VX * fs + oo); ovz = ld4(fl + F_VZ * fs + oo);
+        obx = ld4(p.mat + M_BX * ncell + occ); obz = ld4(p.mat + M_BZ * ncell + occ);
+    }
+    if (halo_ok) {
+        hvx = ld4(fl + F_VX * fs + ho); hvz = ld4(fl + F_VZ * fs + ho);
+        hbx = ld4(p.mat + M_BX * ncell + hcc); hbz = ld4(p.mat + M_BZ * ncell + hcc);
+    }
+    if (own_ok) {
+        bxx = ld4(fl + F_SXX * fs + oo); bzz = ld4(fl + F_SZZ * fs + oo); bxz = ld4(fl + F_SXZ * fs + oo);
+    }
+    {
+        float4 D1 = zero4, D2 = zero4, D3 = zero4, D4 = zero4;
+        if (own_ok) stage_D(p, s, oj, og, ovx, ovz, obx, obz, true, D1, D2, D3, D4);
+        const int x = 4 * (ogrp + 1);
+        st4(&D[0][orow + 2][x], D1); st4(&D[1][orow + 2][x], D2);
+        st4(&D[2][orow + 2][x], D3); st4(&D[3][orow + 2][x], D4);
+    }
+    if (t < kHalo) {
+        float4 D1 = zero4, D2 = zero4, D3 = zero4, D4 = zero4;
+        if (halo_ok) stage_D(p, s, hj, hgg, hvx, hvz, hbx, hbz, false, D1, D2, D3, D4);
+        st4(&D[0][hr][4 * hg], D1); st4(&D[1][hr][4 * hg], D2);
+        st4(&D[2][hr][4 * hg], D3); st4(&D[3][hr][4 * hg], D4);
     }
     __syncthreads();
-    if (t < ATZ * AGO) {
-        const int orow = t / AGO, ogrp = t % AGO;
-        const int oj = tile_j + orow, og = tile_g + ogrp;
-        if (oj < p.nz && og < p.ng) {
-            const unsigned o = (unsigned)(oj + 2) * p.pitch + 4 + 4 * og;
-            const int r = orow + 2, cb = 4 * (ogrp + 1);
-            const float4 bxx = ld4(fl + F_SXX * fs + o), bzz = ld4(fl + F_SZZ * fs + o);
-            const float4 bxz = ld4(fl + F_SXZ * fs + o);
-            float nxx[4], nzz[4], nxz[4];
+    if (own_ok) {
+        const int r = orow + 2, cb = 4 * (ogrp + 1);
+        float nxx[4], nzz[4], nxz[4];
+        const Row8 x1 = row8(&D[0][r][0], cb), x3 = row8(&D[2][r][0], cb);
+        const float4 z2a = ld4(&D[1][r - 1][cb]), z2b = ld4(&D[1][r][cb]);
+        const float4 z2c = ld4(&D[1][r + 1][cb]), z2d = ld4(&D[1][r + 2][cb]);
+        const float4 z4a = ld4(&D[3][r - 2][cb]), z4b = ld4(&D[3][r - 1][cb]);
+        const float4 z4c = ld4(&D[3][r][cb]), z4d = ld4(&D[3][r + 1][cb]);
+        float4 m12 = zero4, m13 = zero4, m32 = zero4;
+        if (p.fsurf && oj < 2) { m12 = ld4(&D[1][2][cb]); m13 = ld4(&D[1][3][cb]); m32 = ld4(&D[3][2][cb]); }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int x = cb + c;
-                const float dx1 = dbw(D[0][r][x - 2], D[0][r][x - 1], D[0][r][x], D[0][r][x + 1]);
-                const float dz2 = dfw(D[1][r - 1][x], D[1][r][x], D[1][r + 1][x], D[1][r + 2][x]);
-                const float dx3 = dfw(D[2][r][x - 1], D[2][r][x], D[2][r][x + 1], D[2][r][x + 2]);
-                const float dz4 = dbw(D[3][r - 2][x], D[3][r - 1][x], D[3][r][x], D[3][r + 1][x]);
-                nxx[c] = comp(bxx, c) - dx1;
-                nxz[c] = comp(bxz, c) - (dz2 + dx3);
-                nzz[c] = comp(bzz, c) - dz4;
-                if (p.fsurf && oj < 2) {
-                    // transposed odd mirroring (tile_j == 0 here: staged row 2 is grid row 0)
-                    if (oj == 0) nxz[c] = nxz[c] + fmaf(C1, D[1][2][x], C2 * D[1][3][x]);
-                    else { nxz[c] = nxz[c] + C2 * D[1][2][x]; nzz[c] = nzz[c] + C2 * D[3][2][x]; }
-                }
-                if (4 * og + c >= p.nx) { nxx[c] = 0.f; nxz[c] = 0.f; nzz[c] = 0.f; }
+        for (int c = 0; c < 4; ++c) {
+            const float dx1 = dbw(x1.v[c], x1.v[c + 1], x1.v[c + 2], x1.v[c + 3]);
+            const float dz2 = dfw(comp(z2a, c), comp(z2b, c), comp(z2c, c), comp(z2d, c));
+            const float dx3 = dfw(x3.v[c + 1], x3.v[c + 2], x3.v[c + 3], x3.v[c + 4]);
+            const float dz4 = dbw(comp(z4a, c), comp(z4b, c), comp(z4c, c), comp(z4d, c));
+            nxx[c] = comp(bxx, c) - dx1;
+            nxz[c] = comp(bxz, c) - (dz2 + dx3);
+            nzz[c] = comp(bzz, c) - dz4;
+            if (p.fsurf && oj < 2) {
+                // transposed odd mirroring (tile_j == 0 here: staged row 2 is grid row 0)
+                if (oj == 0) nxz[c] = nxz[c] + fmaf(C1, comp(m12, c), C2 * comp(m13, c));
+                else { nxz[c] = nxz[c] + C2 * comp(m12, c); nzz[c] = nzz[c] + C2 * comp(m32, c); }
             }
-            st4(fl + F_SXX * fs + o, make_float4(nxx[0], nxx[1], nxx[2], nxx[3]));
-            st4(fl + F_SZZ * fs + o, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
-            st4(fl + F_SXZ * fs + o, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
+            if (4 * og + c >= p.nx) { nxx[c] = 0.f; nxz[c] = 0.f; nzz[c] = 0.f; }
         }
+        st4(fl + F_SXX * fs + oo, make_float4(nxx[0], nxx[1], nxx[2], nxx[3]));
+        st4(fl + F_SZZ * fs + oo, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
+        st4(fl + F_SXZ * fs + oo, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
     }
 }
 
@@ -750,7 +863,7 @@ struct mifwi_elastic_plan {
     mifwi_elastic_desc d;
     int device;
     int ng, gp, pitch, lx, rz, gs, ngroups;
-    int W, wl, xr0, wx;
+    int W, wl, xr0, wx, xcd;
     long long field_stride, shot_stride, fields_elems, psix_elems, psiz_elems, coef_elems;
     long long psi_elems;  // psix+psiz rounded up to 64
     // cluster path (LDS-resident time loop); 0 when a shot does not fit
@@ -773,6 +886,7 @@ ElParams el_base(const mifwi_elastic_plan *pl, const float *mat, const float *pz
     p.fsurf = pl->d.free_surface;
     p.psix_shot = 4LL * pl->d.nz * pl->wx; p.psiz_shot = 4LL * 2 * pl->W * pl->gp;
     p.mat = mat; p.pz = pz; p.px = px;
+    p.xcd = pl->xcd;
     return p;
 }
 
@@ -992,6 +1106,7 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     }
     { const int v = env_int("MIFWI_EL_LX", 0); if (v == 16 || v == 32 || v == 64) pl->lx = v; }
     pl->rz = 1;
+    pl->xcd = env_int("MIFWI_EL_XCD", 1) != 0;
     int gs = d->shots_per_group;
     if (gs <= 0) gs = env_int("MIFWI_EL_GS", 4);
     if (gs <= 0) gs = 1;

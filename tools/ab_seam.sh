@@ -1,0 +1,7 @@
+#!/bin/bash
+# usage: tools/ab_seam.sh "ENV=.. ENV=.." ...   - times the SEAM-sized elastic workload once per environment string
+i=0
+for E in "$@"; do i=$((i+1)); env $E timeout -k 10 200 python bench.py --workload ${WL:-elastic_seam} ${GRID:+--grid $GRID} --nt ${NT:-90} ${SHOTS:+--shots $SHOTS} --steps 5 --warmup 1 --no-cpu-baseline --no-also > gpurun_out/ab_$i.json 2>gpurun_out/ab_err.log; python -c "
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(sys.argv[2], round(d['value']), {k:round(v['avg_step_s']*1e6,1) for k,v in d['kernels'].items()}, d['check'])" gpurun_out/ab_$i.json "$E"; done
