@@ -58,13 +58,16 @@ class AcousticMarmousi:
     pml = 20
     fwd_bytes, adj_bytes = 16.0, 20.0          # SURVEY.md 8d algorithmic B / cell-step
 
-    def __init__(self, dev, rank, world, nt=None, shots=None):
+    def __init__(self, dev, rank, world, nt=None, shots=None, grid=None):
         import torch
         import physicsbasedfwi2_amd.compat.deepwave as deepwave
         from physicsbasedfwi2_amd import misfit
         self.torch, self.deepwave, self.dev, self.misfit = torch, deepwave, dev, misfit
         if nt:
             self.nt = nt
+        if grid:
+            self.nz, self.nx = grid
+            self.name = "acoustic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, shots or self.shots_per_gpu, self.nt)
         ns = shots or self.shots_per_gpu
         self.ns = ns
         total = ns * world
@@ -324,7 +327,7 @@ def run_workload(name, args, dev, rank, world, want_cpu):
     import torch
     import torch.distributed as dist
     kw = {}
-    if args.grid and name != "acoustic_marmousi":
+    if args.grid:
         kw["grid"] = tuple(int(v) for v in args.grid.lower().split("x"))
     wl = WORKLOADS[name](dev, rank, world, nt=args.nt or None, shots=args.shots or None, **kw)
 
@@ -406,7 +409,7 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--nt", type=int, default=0, help="override time steps (debug only)")
     ap.add_argument("--shots", type=int, default=0, help="override shots per GPU (debug only)")
-    ap.add_argument("--grid", default="", help="NZxNX override for the elastic workloads")
+    ap.add_argument("--grid", default="", help="NZxNX override (debug / large-grid measurements only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for --gpus > 1 (gloo: rehearsal of the multi-rank path)")

@@ -54,6 +54,7 @@ struct AcParams {
     const float *smp_w;
     float *smp_out;              // [nshot][nsmp] for this step (NULL: skip)
     int tiles_z;                 // grid.y rows that are stencil tiles; the rest sample
+    int xcd;                     // 1: XCD-contiguous tile order (xcd_tile)
 };
 
 __device__ __forceinline__ float comp(const float4 &v, int c)
@@ -61,12 +62,26 @@ __device__ __forceinline__ float comp(const float4 &v, int c)
     return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
 }
 
+// Workgroups go to the 8 XCDs round-robin in launch order and every XCD has its own L2: remap so that
+// each XCD walks one contiguous row-major run of the (x, y) tiles of its z slice and halo rows of
+// neighbouring tiles are L2 hits (bijection on [0, gridDim.x * gridDim.y); same map as the elastic kernels)
+__device__ __forceinline__ void xcd_tile(const AcParams &p, int &bx, int &by)
+{
+    bx = (int)blockIdx.x; by = (int)blockIdx.y;
+    if (!p.xcd) return;
+    const unsigned gx = gridDim.x, n2 = gx * gridDim.y;
+    const unsigned L = blockIdx.x + gx * blockIdx.y;
+    const unsigned c = L & 7u, idx = L >> 3, q = n2 >> 3, r = n2 & 7u;
+    const unsigned T = c * q + (c < r ? c : r) + idx;
+    by = (int)(T / gx); bx = (int)(T - (unsigned)by * gx);
+}
+
 // ---- sampling workgroups (receivers in forward, source-gradient in backward) ----------------
-__device__ void sample_points(const AcParams &p)
+__device__ void sample_points(const AcParams &p, int bx, int by)
 {
     if (p.smp_out == nullptr) return;
     const int nrb = (int)(gridDim.y - p.tiles_z) * (int)gridDim.x;
-    const int rb = ((int)blockIdx.y - p.tiles_z) * (int)gridDim.x + (int)blockIdx.x;
+    const int rb = (by - p.tiles_z) * (int)gridDim.x + bx;
     const int total = p.gs * p.nsmp;
     for (int e = rb * kThreads + (int)threadIdx.x; e < total; e += nrb * kThreads) {
         const int si = e / p.nsmp, ip = e - si * p.nsmp;
@@ -97,15 +112,17 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
     constexpr int LZ = kThreads / LX;
     constexpr int TZ = LZ * RZ;
     constexpr int TX = LX * 4;
-    if ((int)blockIdx.y >= p.tiles_z) {
-        sample_points(p);
+    int bx, by;
+    xcd_tile(p, bx, by);
+    if (by >= p.tiles_z) {
+        sample_points(p, bx, by);
         return;
     }
     __shared__ float inj[TZ][TX];
 
     const int lx = (int)threadIdx.x % LX, lz = (int)threadIdx.x / LX;
-    const int g = (int)blockIdx.x * LX + lx;
-    const int tile_i0 = (int)blockIdx.y * TZ, tile_i1 = (int)blockIdx.x * TX;
+    const int g = bx * LX + lx;
+    const int tile_i0 = by * TZ, tile_i1 = bx * TX;
     const int j0 = tile_i0 + lz * RZ;
     const bool active = (g < p.ng) && (j0 < p.n0);
     const int col = 4 + 4 * g;                      // first wavefield column of this group
@@ -927,7 +944,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
 struct mifwi_acoustic_plan {
     mifwi_acoustic_desc d;
     int device;
-    int ng, gp, pitch, lx, rz, gs, ngroups;
+    int ng, gp, pitch, lx, rz, gs, ngroups, xcd;
     long long shot_stride, field_elems, coef_elems;
     // cluster path (LDS-resident time loop), 0 when the shot does not fit
     int cluster, NW, PL, cl_shots, cl_lds, rt;
@@ -981,6 +998,7 @@ AcParams base_params(const mifwi_acoustic_plan *pl, const float *r, const float 
     p.n0 = pl->d.n0; p.n1 = pl->d.n1; p.ng = pl->ng; p.pitch = pl->pitch; p.gp = pl->gp;
     p.shot_stride = pl->shot_stride; p.nshot = pl->d.nshot; p.gs = pl->gs;
     p.c0 = pl->d.c0; p.c1 = pl->d.c1; p.r = r; p.q0 = q0; p.q1 = q1;
+    p.xcd = pl->xcd;
     return p;
 }
 
@@ -1137,6 +1155,7 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
         if (padded * 10 <= pl->ng * 12) { pl->lx = cand; break; }
     }
     pl->rz = 2;
+    pl->xcd = env_int("MIFWI_AC_XCD", 1) != 0;
     // tuning overrides (benchmarks only)
     { const int v = env_int("MIFWI_AC_LX", 0); if (v == 16 || v == 32 || v == 64) pl->lx = v; }
     { const int v = env_int("MIFWI_AC_RZ", 0); if (v == 1 || v == 2 || v == 4 || v == 8) pl->rz = v; }

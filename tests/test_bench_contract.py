@@ -66,3 +66,23 @@ def test_pmc_tool_knows_the_kernels_the_bench_runs():
         assert set(t[wl.name]) == {"forward+save", "adjoint+imaging"}
         for rec in t[wl.name].values():
             assert 0 < rec["bytes_per_cell_step"] < 80.0      # below the algorithmic figures of SURVEY 8d
+
+
+def test_xcd_tile_order_is_a_bijection_with_contiguous_runs():
+    """The per-step kernels remap blockIdx so that each XCD (launch order modulo 8) walks one contiguous
+    run of tiles (csrc: xcd_tile).  Same arithmetic here: a permutation for every grid shape, and the
+    tiles of one XCD are consecutive."""
+    for gx in (1, 3, 12, 47):
+        for gy in (1, 2, 7, 63, 250):
+            n2 = gx * gy
+            q, r = n2 >> 3, n2 & 7
+            seen, runs = set(), {}
+            for L in range(n2):
+                c, idx = L & 7, L >> 3
+                T = c * q + min(c, r) + idx
+                assert 0 <= T < n2
+                seen.add(T)
+                runs.setdefault(c, []).append(T)
+            assert len(seen) == n2
+            for c, ts in runs.items():
+                assert ts == list(range(ts[0], ts[0] + len(ts)))
