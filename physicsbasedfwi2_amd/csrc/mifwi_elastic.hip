@@ -599,12 +599,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_ADJ_S_MINWAVES) void el_adj_s(const
         if (halo_ok) {
             halo.a = ld4(fl + F_SXX * fs + ho); halo.b = ld4(fl + F_SZZ * fs + ho); halo.c = ld4(fl + F_SXZ * fs + ho);
         }
-        if (own_ok) {
-            vxb = ld4(fl + F_VX * fs + oo); vzb = ld4(fl + F_VZ * fs + oo);
-            const float *Sp = p.S + (long long)s * 5 * ncell + occ;
-            S1 = mifwi::ldnt4(Sp); S2 = mifwi::ldnt4(Sp + (long long)ncell); S3 = mifwi::ldnt4(Sp + 2 * (long long)ncell);
-            S4 = mifwi::ldnt4(Sp + 3 * (long long)ncell); S5 = mifwi::ldnt4(Sp + 4 * (long long)ncell);
-        }
+        if (own_ok) { vxb = ld4(fl + F_VX * fs + oo); vzb = ld4(fl + F_VZ * fs + oo); }
         const bool has_inj = stage_injection<ATZ, 4 * AGO, 2>(p, s, tile_j, 4 * tile_g, inj);
         // ---- stage E1..E4 on the tile + halo -------------------------------------------------
         if (p.fsurf && oj == 0) own.b = zero4;            // adjoint of szz(0,.) is discarded
@@ -621,6 +616,12 @@ __global__ __launch_bounds__(kThreads, MIFWI_ADJ_S_MINWAVES) void el_adj_s(const
             if (halo_ok) stage_E(p, s, hj, hgg, halo, false, E1, E2, E3, E4);
             st4(&E[0][hr][4 * hg], E1); st4(&E[1][hr][4 * hg], E2);
             st4(&E[2][hr][4 * hg], E3); st4(&E[3][hr][4 * hg], E4);
+        }
+        // the snapshot planes are only needed after the barrier: requested last, they do not delay the staging
+        if (own_ok) {
+            const float *Sp = p.S + (long long)s * 5 * ncell + occ;
+            S1 = mifwi::ldnt4(Sp); S2 = mifwi::ldnt4(Sp + (long long)ncell); S3 = mifwi::ldnt4(Sp + 2 * (long long)ncell);
+            S4 = mifwi::ldnt4(Sp + 3 * (long long)ncell); S5 = mifwi::ldnt4(Sp + 4 * (long long)ncell);
         }
         __syncthreads();
         // ---- stencils from LDS + injection + gradient accumulation ---------------------------

@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage: tools/ab_seam.sh "ENV=.. ENV=.." ...   - times the SEAM-sized elastic workload once per environment string
+# the first run on a fresh box is 2-3 % slow (clocks, cold caches): one throw-away run first
+timeout -k 10 200 python bench.py --workload ${WL:-elastic_seam} ${GRID:+--grid $GRID} --nt 20 ${SHOTS:+--shots $SHOTS} --steps 2 --warmup 1 --no-cpu-baseline --no-also > /dev/null 2>&1
 i=0
 for E in "$@"; do i=$((i+1)); env $E timeout -k 10 200 python bench.py --workload ${WL:-elastic_seam} ${GRID:+--grid $GRID} --nt ${NT:-90} ${SHOTS:+--shots $SHOTS} --steps 5 --warmup 1 --no-cpu-baseline --no-also > gpurun_out/ab_$i.json 2>gpurun_out/ab_err.log; python -c "
 import json,sys
