@@ -49,6 +49,7 @@ struct ElParams {
     long long psix_shot, psiz_shot;   // floats per shot: 4*nz*wx, 4*2W*gp
     const float *mat, *pz, *px;
     float *fields;
+    float *fields_out;           // fused forward step: the copy of the state this launch writes
     float *psix, *psiz;          // forward: updated in place; adjoint: read side
     float *psix_out, *psiz_out;  // adjoint: write side (ping-pong)
     float *S;                    // snapshot slice of this step [nshot][5][nz][gp]
@@ -810,6 +811,259 @@ __global__ __launch_bounds__(kThreads) void el_adj_v(const ElParams p)
     }
 }
 
+// ================================================================================================
+// fused forward step: V and S of one time step in ONE launch (large grids, HBM-bound regime).
+// A workgroup owns 16 rows x 64 cells.  It computes the new velocities on its tile plus a two-row /
+// one-group halo (recomputing what the neighbours also compute) into LDS, then the new stresses of its
+// tile from LDS.  Nothing is updated in place: a neighbour may still need the old value of a cell this
+// workgroup owns, so the launch reads one copy of the state (fields + C-PML memory variables) and
+// writes the other.  HBM traffic per cell-step: 40 B read + 20 B written (+20 B snapshot) instead of the
+// 61 + 21 B of the two-launch form; the arithmetic is the same fmaf chain, term by term.
+// Opt-in (MIFWI_EL_FUSED=1): on 1000x3000x16 shots it moves 86 instead of 102 B/cell but takes 0.80-0.84 ms
+// against 0.78 ms for the two launches - two workgroups per CU with a barrier in the middle keep fewer
+// loads in flight than twelve independent streaming waves.
+// Receivers sample the INPUT state, i.e. the velocities of the previous step (the driver shifts the output
+// row by one and samples the last step with a launch of its own).
+// ================================================================================================
+struct VIn {
+    float4 cxx, a0, a1, a2, a3, b0, b1, b2, b3, vx, vz, bx, bz;
+    float2 Lxx, Rxx, Lxz, Rxz;
+};
+
+__device__ __forceinline__ void v_load(const ElParams &p, const float *fl, int j, int g, VIn &in)
+{
+    const unsigned fs = p.field_stride;
+    const float *sxx = fl + F_SXX * fs, *szz = fl + F_SZZ * fs, *sxz = fl + F_SXZ * fs;
+    const unsigned o = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
+    const unsigned cc = (unsigned)j * p.gp + 4 * g;
+    const unsigned ncell = (unsigned)p.nz * p.gp;
+    in.a0 = ld4(sxz + o - 2 * p.pitch); in.a1 = ld4(sxz + o - p.pitch);
+    in.a2 = ld4(sxz + o); in.a3 = ld4(sxz + o + p.pitch);
+    in.b0 = ld4(szz + o - p.pitch); in.b1 = ld4(szz + o);
+    in.b2 = ld4(szz + o + p.pitch); in.b3 = ld4(szz + o + 2 * p.pitch);
+    in.cxx = ld4(sxx + o); in.Lxx = ld2(sxx + o - 2); in.Rxx = ld2(sxx + o + 4);
+    in.Lxz = ld2(sxz + o - 2); in.Rxz = ld2(sxz + o + 4);
+    in.vx = ld4(fl + F_VX * fs + o); in.vz = ld4(fl + F_VZ * fs + o);
+    in.bx = ld4(p.mat + M_BX * ncell + cc); in.bz = ld4(p.mat + M_BZ * ncell + cc);
+}
+
+// the V update of el_step_v on one group; memory variables read from psi*, written (owner only) to psi*_out
+__device__ __forceinline__ void v_update(const ElParams &p, int s, int j, int g, VIn &in, bool mine,
+                                         float4 &vxn, float4 &vzn, float4 &s4o, float4 &s5o)
+{
+    {
+        // free surface, odd mirroring about row 0: sxz(-m) = -sxz(m-1), szz(-m) = -szz(m).  Component-wise
+        // selects: a select between whole float4 values sends the struct to scratch memory
+        const bool m0 = p.fsurf && j == 0, m1 = p.fsurf && j == 1;
+#define MIFWI_SEL(dst, c, v) dst.x = (c) ? -(v).x : dst.x; dst.y = (c) ? -(v).y : dst.y; \
+                             dst.z = (c) ? -(v).z : dst.z; dst.w = (c) ? -(v).w : dst.w
+        MIFWI_SEL(in.a0, m1, in.a1);
+        MIFWI_SEL(in.a0, m0, in.a3);
+        MIFWI_SEL(in.a1, m0, in.a2);
+        MIFWI_SEL(in.b0, m0, in.b2);
+#undef MIFWI_SEL
+    }
+    const float xx[8] = {in.Lxx.x, in.Lxx.y, in.cxx.x, in.cxx.y, in.cxx.z, in.cxx.w, in.Rxx.x, in.Rxx.y};
+    const float xz[8] = {in.Lxz.x, in.Lxz.y, in.a2.x, in.a2.y, in.a2.z, in.a2.w, in.Rxz.x, in.Rxz.y};
+    float d1[4], d2[4], d3[4], d4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        d1[c] = dfw(xx[c + 1], xx[c + 2], xx[c + 3], xx[c + 4]);
+        d2[c] = dbw(comp(in.a0, c), comp(in.a1, c), comp(in.a2, c), comp(in.a3, c));
+        d3[c] = dbw(xz[c], xz[c + 1], xz[c + 2], xz[c + 3]);
+        d4[c] = dfw(comp(in.b0, c), comp(in.b1, c), comp(in.b2, c), comp(in.b3, c));
+    }
+    const int xs_off = xstrip(p, g);
+    if (xs_off >= 0) {
+        const float4 pxa = ld4(p.px + PA * p.gp + 4 * g), pxb = ld4(p.px + PB * p.gp + 4 * g);
+        const float4 pxk = ld4(p.px + PK * p.gp + 4 * g), pxah = ld4(p.px + PAH * p.gp + 4 * g);
+        const float4 pxbh = ld4(p.px + PBH * p.gp + 4 * g), pxkh = ld4(p.px + PKH * p.gp + 4 * g);
+        const long long q1 = (long long)s * p.psix_shot + ((long long)0 * p.nz + j) * p.wx + xs_off;
+        const long long q3 = (long long)s * p.psix_shot + ((long long)1 * p.nz + j) * p.wx + xs_off;
+        const float4 s1 = ld4(p.psix + q1), s3 = ld4(p.psix + q3);
+        float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t3[4] = {s3.x, s3.y, s3.z, s3.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            d1[c] = pml(t1[c], comp(pxah, c), comp(pxbh, c), comp(pxkh, c), d1[c]);
+            d3[c] = pml(t3[c], comp(pxa, c), comp(pxb, c), comp(pxk, c), d3[c]);
+        }
+        if (mine) {
+            st4(p.psix_out + q1, make_float4(t1[0], t1[1], t1[2], t1[3]));
+            st4(p.psix_out + q3, make_float4(t3[0], t3[1], t3[2], t3[3]));
+        }
+    }
+    const int zs = zstrip(p, j);
+    if (zs >= 0) {
+        const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
+        const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
+        const long long q2 = (long long)s * p.psiz_shot + ((long long)0 * 2 * p.W + zs) * p.gp + 4 * g;
+        const long long q4 = (long long)s * p.psiz_shot + ((long long)1 * 2 * p.W + zs) * p.gp + 4 * g;
+        const float4 s2 = ld4(p.psiz + q2), s4 = ld4(p.psiz + q4);
+        float t2[4] = {s2.x, s2.y, s2.z, s2.w}, t4[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            d2[c] = pml(t2[c], za, zb, zk, d2[c]);
+            d4[c] = pml(t4[c], zah, zbh, zkh, d4[c]);
+        }
+        if (mine) {
+            st4(p.psiz_out + q2, make_float4(t2[0], t2[1], t2[2], t2[3]));
+            st4(p.psiz_out + q4, make_float4(t4[0], t4[1], t4[2], t4[3]));
+        }
+    }
+    float s4v[4], s5v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { s4v[c] = d1[c] + d2[c]; s5v[c] = d3[c] + d4[c]; }
+    vxn = make_float4(fmaf(in.bx.x, s4v[0], in.vx.x), fmaf(in.bx.y, s4v[1], in.vx.y),
+                      fmaf(in.bx.z, s4v[2], in.vx.z), fmaf(in.bx.w, s4v[3], in.vx.w));
+    vzn = make_float4(fmaf(in.bz.x, s5v[0], in.vz.x), fmaf(in.bz.y, s5v[1], in.vz.y),
+                      fmaf(in.bz.z, s5v[2], in.vz.z), fmaf(in.bz.w, s5v[3], in.vz.w));
+    s4o = make_float4(s4v[0], s4v[1], s4v[2], s4v[3]);
+    s5o = make_float4(s5v[0], s5v[1], s5v[2], s5v[3]);
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(kThreads) void el_step_fused(const ElParams p)
+{
+    int bx, by;
+    xcd_tile(p, bx, by);
+    if (by >= p.tiles_z) {
+        sample_points<0>(p, bx, by);
+        return;
+    }
+    __shared__ float V[2][ASZ][ASX];
+    __shared__ float inj[ATZ * 4 * AGO];
+    const int tile_j = by * ATZ;
+    const int tile_g = bx * AGO;
+    const int s = (int)blockIdx.z;
+    const unsigned fs = p.field_stride;
+    const unsigned ncell = (unsigned)p.nz * p.gp;
+    const int t = (int)threadIdx.x;
+    const float *fin = p.fields + (long long)s * p.shot_stride;
+    float *fout = p.fields_out + (long long)s * p.shot_stride;
+    const int orow = t / AGO, ogrp = t % AGO;
+    const int oj = tile_j + orow, og = tile_g + ogrp;
+    const bool own_ok = oj < p.nz && og < p.ng;
+    const unsigned occ = (unsigned)oj * p.gp + 4 * og;
+    const unsigned oo = (unsigned)(oj + 2) * p.pitch + 4 + 4 * og;
+    int hr = 0, hg = 0;
+    if (t < kHalo) halo_item(t, hr, hg);
+    const int hj = tile_j - 2 + hr, hgg = tile_g - 1 + hg;
+    const bool halo_ok = t < kHalo && hj >= 0 && hj < p.nz && hgg >= 0 && hgg < p.ng;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    VIn own, halo;
+    float4 Ls = zero4, Ms = zero4, mus = zero4;
+    if (own_ok) v_load(p, fin, oj, og, own);
+    if (halo_ok) v_load(p, fin, hj, hgg, halo);
+    if (own_ok) {
+        Ls = ld4(p.mat + M_L * ncell + occ); Ms = ld4(p.mat + M_M * ncell + occ);
+        mus = ld4(p.mat + M_MU * ncell + occ);
+    }
+    const bool has_inj = stage_injection<ATZ, 4 * AGO, 1>(p, s, tile_j, 4 * tile_g, inj);
+    // ---- V: new velocities of the tile + halo into LDS ---------------------------------------------
+    float4 oxx = zero4, ozz = zero4, oxz = zero4;
+    {
+        float4 vxn = zero4, vzn = zero4, s4 = zero4, s5 = zero4;
+        if (own_ok) {
+            oxx = own.cxx; ozz = own.b1; oxz = own.a2;           // old stresses of the own group (S needs them)
+            v_update(p, s, oj, og, own, true, vxn, vzn, s4, s5);
+            st4(fout + F_VX * fs + oo, vxn);
+            st4(fout + F_VZ * fs + oo, vzn);
+            if (SAVE) {
+                float *Sp = p.S + (long long)s * 5 * ncell + occ;
+                mifwi::stnt4(Sp + 3 * (long long)ncell, s4);
+                mifwi::stnt4(Sp + 4 * (long long)ncell, s5);
+            }
+        }
+        const int x = 4 * (ogrp + 1);
+        st4(&V[0][orow + 2][x], vxn); st4(&V[1][orow + 2][x], vzn);
+    }
+    if (t < kHalo) {
+        float4 vxn = zero4, vzn = zero4, s4, s5;
+        if (halo_ok) v_update(p, s, hj, hgg, halo, false, vxn, vzn, s4, s5);
+        st4(&V[0][hr][4 * hg], vxn); st4(&V[1][hr][4 * hg], vzn);
+    }
+    __syncthreads();
+    // ---- S: new stresses of the tile from LDS ------------------------------------------------------
+    if (own_ok) {
+        const int r = orow + 2, cb = 4 * (ogrp + 1);
+        const Row8 xv = row8(&V[0][r][0], cb), zv = row8(&V[1][r][0], cb);
+        const float4 a0 = ld4(&V[1][r - 2][cb]), a1 = ld4(&V[1][r - 1][cb]);
+        const float4 a2 = ld4(&V[1][r][cb]), a3 = ld4(&V[1][r + 1][cb]);
+        const float4 b0 = ld4(&V[0][r - 1][cb]), b1 = ld4(&V[0][r][cb]);
+        const float4 b2 = ld4(&V[0][r + 1][cb]), b3 = ld4(&V[0][r + 2][cb]);
+        float e1[4], e2[4], e3[4], e4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            e1[c] = dbw(xv.v[c], xv.v[c + 1], xv.v[c + 2], xv.v[c + 3]);
+            e2[c] = dbw(comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
+            e3[c] = dfw(comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
+            e4[c] = dfw(zv.v[c + 1], zv.v[c + 2], zv.v[c + 3], zv.v[c + 4]);
+        }
+        const int xs_off = xstrip(p, og);
+        if (xs_off >= 0) {
+            const float4 pxa = ld4(p.px + PA * p.gp + 4 * og), pxb = ld4(p.px + PB * p.gp + 4 * og);
+            const float4 pxk = ld4(p.px + PK * p.gp + 4 * og), pxah = ld4(p.px + PAH * p.gp + 4 * og);
+            const float4 pxbh = ld4(p.px + PBH * p.gp + 4 * og), pxkh = ld4(p.px + PKH * p.gp + 4 * og);
+            const long long q5 = (long long)s * p.psix_shot + ((long long)2 * p.nz + oj) * p.wx + xs_off;
+            const long long q8 = (long long)s * p.psix_shot + ((long long)3 * p.nz + oj) * p.wx + xs_off;
+            const float4 s5 = ld4(p.psix + q5), s8 = ld4(p.psix + q8);
+            float t5[4] = {s5.x, s5.y, s5.z, s5.w}, t8[4] = {s8.x, s8.y, s8.z, s8.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                e1[c] = pml(t5[c], comp(pxa, c), comp(pxb, c), comp(pxk, c), e1[c]);
+                e4[c] = pml(t8[c], comp(pxah, c), comp(pxbh, c), comp(pxkh, c), e4[c]);
+            }
+            st4(p.psix_out + q5, make_float4(t5[0], t5[1], t5[2], t5[3]));
+            st4(p.psix_out + q8, make_float4(t8[0], t8[1], t8[2], t8[3]));
+        }
+        const int zs = zstrip(p, oj);
+        if (zs >= 0) {
+            const float za = p.pz[PA * p.nz + oj], zb = p.pz[PB * p.nz + oj], zk = p.pz[PK * p.nz + oj];
+            const float zah = p.pz[PAH * p.nz + oj], zbh = p.pz[PBH * p.nz + oj], zkh = p.pz[PKH * p.nz + oj];
+            const long long q6 = (long long)s * p.psiz_shot + ((long long)2 * 2 * p.W + zs) * p.gp + 4 * og;
+            const long long q7 = (long long)s * p.psiz_shot + ((long long)3 * 2 * p.W + zs) * p.gp + 4 * og;
+            const float4 s6 = ld4(p.psiz + q6), s7 = ld4(p.psiz + q7);
+            float t6[4] = {s6.x, s6.y, s6.z, s6.w}, t7[4] = {s7.x, s7.y, s7.z, s7.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                e2[c] = pml(t6[c], za, zb, zk, e2[c]);
+                e3[c] = pml(t7[c], zah, zbh, zkh, e3[c]);
+            }
+            st4(p.psiz_out + q6, make_float4(t6[0], t6[1], t6[2], t6[3]));
+            st4(p.psiz_out + q7, make_float4(t7[0], t7[1], t7[2], t7[3]));
+        }
+        float nxx[4], nzz[4], nxz[4], s3v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s3v[c] = e3[c] + e4[c];
+            nxx[c] = fmaf(comp(Ms, c), e1[c], fmaf(comp(Ls, c), e2[c], comp(oxx, c)));
+            nzz[c] = fmaf(comp(Ls, c), e1[c], fmaf(comp(Ms, c), e2[c], comp(ozz, c)));
+            nxz[c] = fmaf(comp(mus, c), s3v[c], comp(oxz, c));
+            if (has_inj) {
+                const float a = inj[orow * 4 * AGO + 4 * ogrp + c];
+                nxx[c] += a;
+                nzz[c] += a;
+            }
+            if (p.fsurf && oj == 0) nzz[c] = 0.f;
+        }
+        st4(fout + F_SXX * fs + oo, make_float4(nxx[0], nxx[1], nxx[2], nxx[3]));
+        st4(fout + F_SZZ * fs + oo, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
+        st4(fout + F_SXZ * fs + oo, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
+        if (SAVE) {
+            float *Sp = p.S + (long long)s * 5 * ncell + occ;
+            mifwi::stnt4(Sp, make_float4(e1[0], e1[1], e1[2], e1[3]));
+            mifwi::stnt4(Sp + (long long)ncell, make_float4(e2[0], e2[1], e2[2], e2[3]));
+            mifwi::stnt4(Sp + 2 * (long long)ncell, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
+        }
+    }
+}
+
+// receivers of the state in p.fields (the last step of a fused range)
+__global__ __launch_bounds__(kThreads) void el_sample_v(const ElParams p)
+{
+    sample_points<0>(p, (int)blockIdx.x, (int)blockIdx.y);
+}
+
 __global__ void el_points_bbox(const int *cell, int npts_per_shot, int n1, int *bbox)
 {
     __shared__ int red[4][kThreads];
@@ -865,6 +1119,7 @@ struct mifwi_elastic_plan {
     int device;
     int ng, gp, pitch, lx, rz, gs, ngroups;
     int W, wl, xr0, wx, xcd;
+    int fused;             // forward V+S in one launch (second copy of the state in the work buffer)
     long long field_stride, shot_stride, fields_elems, psix_elems, psiz_elems, coef_elems;
     long long psi_elems;  // psix+psiz rounded up to 64
     // cluster path (LDS-resident time loop); 0 when a shot does not fit
@@ -1116,6 +1371,7 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     pl->ngroups = mifwi::ceil_div(d->nshot, gs);
     pl->psi_elems = mifwi::round_up64(pl->psix_elems + pl->psiz_elems, 64);
     el_cluster_setup(pl);
+    pl->fused = !pl->cluster && env_int("MIFWI_EL_FUSED", 0) != 0;   // measured: no faster than two launches yet
     if (pl->cl_adj) {                    // the adjoint cluster kernel keeps one accumulator set per shot
         pl->gs = 1;
         pl->ngroups = d->nshot;
@@ -1145,7 +1401,8 @@ int mifwi_elastic_plan_layout(const mifwi_elastic_plan *pl, mifwi_elastic_layout
     const long long psi = pl->psi_elems;
     const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
     out->state_elems = pl->fields_elems + psi;
-    out->work_forward_elems = out->state_elems + bbox + (pl->cluster ? pl->xbuf_elems : 0);
+    out->work_forward_elems = out->state_elems + bbox + (pl->cluster ? pl->xbuf_elems : 0) +
+                              (pl->fused ? out->state_elems : 0);
     out->work_backward_elems = pl->fields_elems + 2 * psi + 5LL * pl->ngroups * pl->coef_elems + bbox +
                                (pl->cl_adj ? pl->xbuf_elems + pl->list_elems : 0);
     return MIFWI_OK;
@@ -1206,7 +1463,44 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
             return out;
         MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (pl->fields_elems + psi), st));
     }
-    {
+    if (pl->fused && n_end > n_begin) {
+        // V+S in one launch: the state ping-pongs between the copy at the head of the work buffer and a
+        // second one behind the bounding boxes; an odd number of steps ends with a copy back
+        const long long state = pl->fields_elems + psi;
+        float *B = work + state + mifwi::round_up64(4LL * d.nshot, 64);
+        MIFWI_HIP_TRY(hipMemsetAsync(B, 0, sizeof(float) * state, st));     // its pad rows / columns stay zero
+        ElParams q = p;
+        q.ninj = d.nsrc; q.ntap_inj = d.ntap; q.inj_cell = src_cell; q.inj_w = src_w; q.inj_bbox = bbox;
+        q.nsmp = want_rec ? d.nrec : 0; q.ntap_smp = d.ntap; q.smp_cell = rec_cell; q.smp_w = rec_w;
+        const int tx = mifwi::ceil_div(pl->ng, AGO), tz = mifwi::ceil_div(d.nz, ATZ);
+        const int ex = want_rec ? mifwi::ceil_div(mifwi::ceil_div(d.nrec, kThreads), tx) : 0;
+        q.tiles_z = tz;
+        for (int n = n_begin; n < n_end; ++n) {
+            const bool even = ((n - n_begin) & 1) == 0;
+            float *in = even ? work : B, *out = even ? B : work;
+            q.fields = in; q.psix = in + pl->fields_elems; q.psiz = q.psix + pl->psix_elems;
+            q.fields_out = out; q.psix_out = out + pl->fields_elems; q.psiz_out = q.psix_out + pl->psix_elems;
+            q.S = snap ? snap + (long long)(n - n_begin) * snap_step : nullptr;
+            q.inj_amp0 = f ? f + (long long)n * d.nshot * d.nsrc : nullptr;
+            // the receivers see the input state: the velocities of step n-1
+            const bool smp = want_rec && n > n_begin;
+            q.smp_out0 = smp ? rec_vx + (long long)(n - 1) * d.nshot * d.nrec : nullptr;
+            q.smp_out1 = smp ? rec_vz + (long long)(n - 1) * d.nshot * d.nrec : nullptr;
+            const dim3 grid(tx, tz + (smp ? ex : 0), d.nshot);
+            if (snap) hipLaunchKernelGGL(el_step_fused<true>, grid, dim3(kThreads), 0, st, q);
+            else hipLaunchKernelGGL(el_step_fused<false>, grid, dim3(kThreads), 0, st, q);
+        }
+        float *last = ((n_end - n_begin) & 1) ? B : work;
+        if (want_rec) {
+            q.fields = last; q.tiles_z = 0;
+            q.smp_out0 = rec_vx + (long long)(n_end - 1) * d.nshot * d.nrec;
+            q.smp_out1 = rec_vz + (long long)(n_end - 1) * d.nshot * d.nrec;
+            hipLaunchKernelGGL(el_sample_v, dim3(mifwi::ceil_div(d.nrec, kThreads), 1, d.nshot), dim3(kThreads), 0,
+                               st, q);
+        }
+        if (last != work)
+            MIFWI_HIP_TRY(hipMemcpyAsync(work, B, sizeof(float) * state, hipMemcpyDeviceToDevice, st));
+    } else {
         p.fields = fbuf[0]; p.psix = pbuf[0]; p.psiz = pbuf[0] + pl->psix_elems;
         ElParams ps = p;
         ps.ninj = d.nsrc; ps.ntap_inj = d.ntap; ps.inj_cell = src_cell; ps.inj_w = src_w;

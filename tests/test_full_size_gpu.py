@@ -214,3 +214,32 @@ def test_full_length_runs_agree_between_families(monkeypatch):
     assert torch.isfinite(outs[0][0]).all()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert rel_l2(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()) <= 5e-5
+
+
+def test_fused_forward_step_matches_the_two_launch_form(monkeypatch):
+    """MIFWI_EL_FUSED=1: V and S in one launch with a recomputed halo and a ping-pong state (opt-in, large
+    grids).  Same arithmetic term by term: traces and gradients equal the two-launch kernels bit for bit,
+    with the free surface, an odd number of steps, checkpointed segments and a grid wider than one tile."""
+    monkeypatch.setenv("MIFWI_EL_CLUSTER", "0")
+    monkeypatch.setenv("MIFWI_EL_CLUSTER_ADJ", "0")
+    from physicsbasedfwi2_amd import elastic
+    from physicsbasedfwi2_amd.elastic import ElasticPlan
+    case = elastic_case(seed=61, nz=70, nx=150, fw=8, ns=3, nrec=40, nt=75)
+    outs = []
+    for fused, fsurf, budget in (("0", 0, 1 << 40), ("1", 0, 1 << 40), ("0", 1, 1 << 40), ("1", 1, 1 << 40),
+                                 ("1", 1, 3 << 20)):
+        monkeypatch.setenv("MIFWI_EL_FUSED", fused)
+        lay0 = ElasticPlan(70, 150, 75, 3, 1, 40, 1, 8, 0).layout
+        mat = torch.tensor(case["mat"], dtype=torch.float32, device=DEV, requires_grad=True)
+        f = torch.tensor(case["f"], dtype=torch.float32, device=DEV, requires_grad=True)
+        rvx, rvz = elastic.propagate(mat, f, torch.tensor(case["pz"]), torch.tensor(case["px"]),
+                                     torch.tensor(case["sc"]), torch.tensor(case["sw"]),
+                                     torch.tensor(case["rc"]), torch.tensor(case["rw"]), case["fw"],
+                                     free_surface=fsurf, snapshot_budget=budget)
+        torch.autograd.backward([rvx, rvz], [torch.sign(rvx.detach()), torch.sign(rvz.detach())])
+        outs.append((lay0.work_forward_elems, rvx.detach(), rvz.detach(), mat.grad.clone(), f.grad.clone()))
+    assert outs[1][0] > outs[0][0]                      # the fused plan carries a second copy of the state
+    assert float(outs[0][1].abs().max()) > 0
+    for a, b in ((0, 1), (2, 3), (2, 4)):
+        for x, y in zip(outs[a][1:], outs[b][1:]):
+            assert torch.equal(x, y)
