@@ -22,6 +22,7 @@
 #include "mifwi_common.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace {
@@ -44,6 +45,7 @@ struct ElParams {
     unsigned field_stride;       // (nz+4)*pitch
     long long shot_stride;       // 5*field_stride
     int nshot, gs;
+    int s0;                      // first shot of this pass over the time range (blockIdx.z counts from it)
     int W, wl, xr0, wx;          // C-PML strip geometry; W = 0 disables the layer
     int fsurf;                   // 1: stress-imaging free surface on row 0
     long long psix_shot, psiz_shot;   // floats per shot: 4*nz*wx, 4*2W*gp
@@ -143,7 +145,7 @@ __device__ void sample_points(const ElParams &p, int bx, int by)
     const int total = p.gs * p.nsmp;
     for (int e = rb * (int)blockDim.x + (int)threadIdx.x; e < total; e += nrb * (int)blockDim.x) {
         const int si = e / p.nsmp, ip = e - si * p.nsmp;
-        const int s = (int)blockIdx.z * p.gs + si;
+        const int s = p.s0 + (int)blockIdx.z * p.gs + si;
         if (s >= p.nshot) continue;
         const float *fl = p.fields + (long long)s * p.shot_stride;
         float a0 = 0.f, a1 = 0.f;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
     const int g = bx * LX + lx;
     const int j0 = (by * LZ + lz) * RZ;
     if (g >= p.ng || j0 >= p.nz) return;
-    const int s = (int)blockIdx.z;
+    const int s = p.s0 + (int)blockIdx.z;
     const unsigned fs = p.field_stride;
     float *fl = p.fields + (long long)s * p.shot_stride;
     const float *sxx = fl + F_SXX * fs, *szz = fl + F_SZZ * fs, *sxz = fl + F_SXZ * fs;
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const E
         pxbh = ld4(p.px + PBH * p.gp + 4 * g); pxkh = ld4(p.px + PKH * p.gp + 4 * g);
     }
     for (int si = 0; si < p.gs; ++si) {
-        const int s = (int)blockIdx.z * p.gs + si;
+        const int s = p.s0 + (int)blockIdx.z * p.gs + si;
         if (s >= p.nshot) break;
         const bool has_inj = stage_injection<TZ, TX, 1>(p, s, tile_j, tile_i, inj);
         if (active) {
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_ADJ_S_MINWAVES) void el_adj_s(const
     if (own_ok) {
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            acc[k] = ld4(p.acc + ((long long)blockIdx.z * 5 + k) * ncell + occ);
+            acc[k] = ld4(p.acc + ((long long)(p.s0 / p.gs + (int)blockIdx.z) * 5 + k) * ncell + occ);
         own.m0 = ld4(p.mat + M_L * ncell + occ); own.m1 = ld4(p.mat + M_M * ncell + occ);
         own.m2 = ld4(p.mat + M_MU * ncell + occ);
     }
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_ADJ_S_MINWAVES) void el_adj_s(const
         halo.m2 = ld4(p.mat + M_MU * ncell + hcc);
     }
     for (int si = 0; si < p.gs; ++si) {
-        const int s = (int)blockIdx.z * p.gs + si;
+        const int s = p.s0 + (int)blockIdx.z * p.gs + si;
         if (s >= p.nshot) break;
         float *fl = p.fields + (long long)s * p.shot_stride;
         float4 vxb = zero4, vzb = zero4, S1 = zero4, S2 = zero4, S3 = zero4, S4 = zero4, S5 = zero4;
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_ADJ_S_MINWAVES) void el_adj_s(const
     if (own_ok) {
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            st4(p.acc + ((long long)blockIdx.z * 5 + k) * ncell + occ, acc[k]);
+            st4(p.acc + ((long long)(p.s0 / p.gs + (int)blockIdx.z) * 5 + k) * ncell + occ, acc[k]);
     }
 }
 
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_v(const ElParams p)
     xcd_tile(p, bx, by);
     const int tile_j = by * ATZ;
     const int tile_g = bx * AGO;
-    const int s = (int)blockIdx.z;
+    const int s = p.s0 + (int)blockIdx.z;
     const unsigned fs = p.field_stride;
     const unsigned ncell = (unsigned)p.nz * p.gp;
     const int t = (int)threadIdx.x;
@@ -1119,6 +1121,8 @@ struct mifwi_elastic_plan {
     int device;
     int ng, gp, pitch, lx, rz, gs, ngroups;
     int W, wl, xr0, wx, xcd;
+    int pass_shots;        // forward per-step family: shots per pass over the time range
+    int pass_groups;       // adjoint per-step family: shot groups per pass
     int fused;             // forward V+S in one launch (second copy of the state in the work buffer)
     long long field_stride, shot_stride, fields_elems, psix_elems, psiz_elems, coef_elems;
     long long psi_elems;  // psix+psiz rounded up to 64
@@ -1147,10 +1151,10 @@ ElParams el_base(const mifwi_elastic_plan *pl, const float *mat, const float *pz
 }
 
 template <bool SAVE>
-void launch_v(const mifwi_elastic_plan *pl, const ElParams &p, hipStream_t st)
+void launch_v(const mifwi_elastic_plan *pl, const ElParams &p, int nshot, hipStream_t st)
 {
     const int lz = kThreads / pl->lx;
-    dim3 grid(mifwi::ceil_div(pl->ng, pl->lx), mifwi::ceil_div(pl->d.nz, lz * pl->rz), pl->d.nshot);
+    dim3 grid(mifwi::ceil_div(pl->ng, pl->lx), mifwi::ceil_div(pl->d.nz, lz * pl->rz), nshot);
     dim3 block(kThreads);
     if (pl->rz == 1) {
         switch (pl->lx) {
@@ -1168,7 +1172,7 @@ void launch_v(const mifwi_elastic_plan *pl, const ElParams &p, hipStream_t st)
 }
 
 template <bool SAVE>
-void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, hipStream_t st)
+void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, int nshot, hipStream_t st)
 {
     const int lz = kThreads / pl->lx;
     const int tiles_x = mifwi::ceil_div(pl->ng, pl->lx);
@@ -1177,7 +1181,7 @@ void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, hipStream_t st)
     int extra = 0;
     if (p.smp_out0 != nullptr && p.nsmp > 0)
         extra = mifwi::ceil_div(mifwi::ceil_div(p.gs * p.nsmp, kThreads), tiles_x);
-    dim3 grid(tiles_x, p.tiles_z + extra, mifwi::ceil_div(pl->d.nshot, p.gs)), block(kThreads);
+    dim3 grid(tiles_x, p.tiles_z + extra, mifwi::ceil_div(nshot, p.gs)), block(kThreads);
     if (pl->rz == 1) {
         switch (pl->lx) {
             case 64: hipLaunchKernelGGL((el_step_s<64, 1, SAVE>), grid, block, 0, st, p); break;
@@ -1371,6 +1375,41 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     pl->ngroups = mifwi::ceil_div(d->nshot, gs);
     pl->psi_elems = mifwi::round_up64(pl->psix_elems + pl->psiz_elems, 64);
     el_cluster_setup(pl);
+    {
+        // Infinity Cache residency (per-step family, large grids): a pass over the time range takes only as
+        // many shots as keep state + materials (+ gradient accumulators) under kResident bytes; measured on
+        // 1000x3000: forward 3 shots (240 MB) 0.61 ms, 4 shots (300 MB) 0.82 ms = the all-shots time
+        constexpr double kResident = 250e6;
+        const double cells = (double)pl->coef_elems;
+        const double mats = 4.0 * 5.0 * cells;
+        const double psi1 = 4.0 * (double)(pl->psix_elems + pl->psiz_elems) / d->nshot;
+        const double fstate = 4.0 * (double)pl->shot_stride + psi1;
+        int ps = d->nshot;
+        if (d->nshot * fstate + mats > kResident) ps = (int)std::max(1.0, std::floor((kResident - mats) / fstate));
+        ps = env_int("MIFWI_EL_PASS_SHOTS", ps);
+        pl->pass_shots = std::min(d->nshot, std::max(1, ps));
+        // adjoint: groups of gs shots share one accumulator set; when the groups do not all fit, smaller groups
+        // (more accumulator traffic, 40/gs B per cell-step) can still pay: 1000x3000, gs 2, one group per pass
+        // 0.87 ms against 0.98 ms for gs 4 over all shots
+        const double astate = 4.0 * (double)pl->shot_stride + 2.0 * psi1, accg = 4.0 * 5.0 * cells;
+        if (!pl->cl_adj && d->shots_per_group <= 0 && env_int("MIFWI_EL_GS", 0) <= 0 &&
+            pl->ngroups * (pl->gs * astate + accg) + mats > kResident) {
+            int g = pl->gs;
+            while (g > 2 && g * astate + accg + mats > kResident) g /= 2;
+            if (g * astate + accg + mats <= kResident && g != pl->gs) {
+                pl->gs = g;
+                pl->ngroups = mifwi::ceil_div(d->nshot, g);
+            }
+        }
+        const double group = pl->gs * astate + accg;
+        int k = pl->ngroups;
+        if (pl->ngroups * group + mats > kResident) {
+            k = (int)std::floor((kResident - mats) / group);
+            if (k < 1) k = pl->ngroups;                 // nothing fits: one pass over all groups
+        }
+        k = env_int("MIFWI_EL_PASS_GROUPS", k);
+        pl->pass_groups = std::min(pl->ngroups, std::max(1, k));
+    }
     pl->fused = !pl->cluster && env_int("MIFWI_EL_FUSED", 0) != 0;   // measured: no faster than two launches yet
     if (pl->cl_adj) {                    // the adjoint cluster kernel keeps one accumulator set per shot
         pl->gs = 1;
@@ -1506,14 +1545,20 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
         ps.ninj = d.nsrc; ps.ntap_inj = d.ntap; ps.inj_cell = src_cell; ps.inj_w = src_w;
         ps.inj_bbox = bbox;
         ps.nsmp = want_rec ? d.nrec : 0; ps.ntap_smp = d.ntap; ps.smp_cell = rec_cell; ps.smp_w = rec_w;
-        for (int n = n_begin; n < n_end; ++n) {
-            float *Sn = snap ? snap + (long long)(n - n_begin) * snap_step : nullptr;
-            p.S = Sn; ps.S = Sn;
-            ps.inj_amp0 = f ? f + (long long)n * d.nshot * d.nsrc : nullptr;
-            ps.smp_out0 = want_rec ? rec_vx + (long long)n * d.nshot * d.nrec : nullptr;
-            ps.smp_out1 = want_rec ? rec_vz + (long long)n * d.nshot * d.nrec : nullptr;
-            if (snap) { launch_v<true>(pl, p, st); launch_s<true>(pl, ps, st); }
-            else { launch_v<false>(pl, p, st); launch_s<false>(pl, ps, st); }
+        // shots are independent: taken a few at a time, their state and the materials stay inside the
+        // 256 MiB Infinity Cache from one launch to the next (pl->pass_shots; all shots when they fit anyway)
+        for (int s0 = 0; s0 < d.nshot; s0 += pl->pass_shots) {
+            const int cs = std::min(pl->pass_shots, d.nshot - s0);
+            p.s0 = ps.s0 = s0;
+            for (int n = n_begin; n < n_end; ++n) {
+                float *Sn = snap ? snap + (long long)(n - n_begin) * snap_step : nullptr;
+                p.S = Sn; ps.S = Sn;
+                ps.inj_amp0 = f ? f + (long long)n * d.nshot * d.nsrc : nullptr;
+                ps.smp_out0 = want_rec ? rec_vx + (long long)n * d.nshot * d.nrec : nullptr;
+                ps.smp_out1 = want_rec ? rec_vz + (long long)n * d.nshot * d.nrec : nullptr;
+                if (snap) { launch_v<true>(pl, p, cs, st); launch_s<true>(pl, ps, cs, st); }
+                else { launch_v<false>(pl, p, cs, st); launch_s<false>(pl, ps, cs, st); }
+            }
         }
     }
     MIFWI_HIP_TRY(hipGetLastError());
@@ -1612,7 +1657,12 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
             MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (pl->fields_elems + 2 * psi + nacc), st));
         }
     }
-    for (int n = n_hi; per_step && n >= n_lo; --n) {
+    // shot groups are independent: a few at a time keep fields, accumulators and materials in the Infinity Cache
+    for (int g0 = 0; per_step && g0 < pl->ngroups; g0 += pl->pass_groups)
+    for (int n = n_hi; n >= n_lo; --n) {
+        const int cg = std::min(pl->pass_groups, pl->ngroups - g0);
+        const int cs = std::min(cg * ps.gs, d.nshot - g0 * ps.gs);
+        p.s0 = ps.s0 = g0 * ps.gs;
         // ping-pong of the adjoint memory variables is absolute in n (resumable ranges)
         const int par = (d.nt - 1 - n) & 1;
         float *rd = par ? psiB : psiA, *wr = par ? psiA : psiB;
@@ -1628,8 +1678,8 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
             ps.tiles_z = tz;
             int ex = 0;
             if (want_f) ex = mifwi::ceil_div(mifwi::ceil_div(ps.gs * ps.nsmp, kThreads), tx);
-            hipLaunchKernelGGL(el_adj_s, dim3(tx, tz + ex, pl->ngroups), dim3(kThreads), 0, st, ps);
-            hipLaunchKernelGGL(el_adj_v, dim3(tx, tz, d.nshot), dim3(kThreads), 0, st, p);
+            hipLaunchKernelGGL(el_adj_s, dim3(tx, tz + ex, cg), dim3(kThreads), 0, st, ps);
+            hipLaunchKernelGGL(el_adj_v, dim3(tx, tz, cs), dim3(kThreads), 0, st, p);
         }
     }
     if (flags & MIFWI_FINALIZE) {
