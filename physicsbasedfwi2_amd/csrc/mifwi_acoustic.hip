@@ -22,6 +22,7 @@
 #include "mifwi_common.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace {
@@ -55,6 +56,7 @@ struct AcParams {
     float *smp_out;              // [nshot][nsmp] for this step (NULL: skip)
     int tiles_z;                 // grid.y rows that are stencil tiles; the rest sample
     int xcd;                     // 1: XCD-contiguous tile order (xcd_tile)
+    int g0;                      // first shot group of this pass over the time range (blockIdx.z counts from it)
 };
 
 __device__ __forceinline__ float comp(const float4 &v, int c)
@@ -85,7 +87,7 @@ __device__ void sample_points(const AcParams &p, int bx, int by)
     const int total = p.gs * p.nsmp;
     for (int e = rb * kThreads + (int)threadIdx.x; e < total; e += nrb * kThreads) {
         const int si = e / p.nsmp, ip = e - si * p.nsmp;
-        const int s = (int)blockIdx.z * p.gs + si;
+        const int s = (p.g0 + (int)blockIdx.z) * p.gs + si;
         if (s >= p.nshot) continue;
         const float *cur = p.cur + (long long)s * p.shot_stride;
         float a = 0.f;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
                 if (IMAGE)
                     acc[rz] = p.born_dr ? make_float4(0.f, 0.f, 0.f, 0.f)
                                         : *reinterpret_cast<const float4 *>(
-                                              p.acc + ((long long)blockIdx.z * p.n0 + j) * p.gp + 4 * g);
+                                              p.acc + ((long long)(p.g0 + (int)blockIdx.z) * p.n0 + j) * p.gp + 4 * g);
             } else {
                 rr[rz] = make_float4(0.f, 0.f, 0.f, 0.f);
                 q0v[rz] = 0.f;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
     }
 
     for (int si = 0; si < p.gs; ++si) {
-        const int s = (int)blockIdx.z * p.gs + si;
+        const int s = (p.g0 + (int)blockIdx.z) * p.gs + si;
         if (s >= p.nshot) break;                    // block-uniform
 
         // ---- stage this shot's injection for this tile in LDS (block-uniform branch) -------
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
         for (int rz = 0; rz < RZ; ++rz) {
             const int j = j0 + rz;
             if (j < p.n0)
-                *reinterpret_cast<float4 *>(p.acc + ((long long)blockIdx.z * p.n0 + j) * p.gp +
+                *reinterpret_cast<float4 *>(p.acc + ((long long)(p.g0 + (int)blockIdx.z) * p.n0 + j) * p.gp +
                                             4 * g) = acc[rz];
         }
     }
@@ -945,6 +947,7 @@ struct mifwi_acoustic_plan {
     mifwi_acoustic_desc d;
     int device;
     int ng, gp, pitch, lx, rz, gs, ngroups, xcd;
+    int pass_fwd, pass_adj;                // shot groups per pass over the time range (per-step family)
     long long shot_stride, field_elems, coef_elems;
     // cluster path (LDS-resident time loop), 0 when the shot does not fit
     int cluster, NW, PL, cl_shots, cl_lds, rt;
@@ -966,7 +969,7 @@ void launch_rz(const mifwi_acoustic_plan *pl, dim3 grid, const AcParams &q, hipS
 }
 
 template <bool SAVE, bool IMAGE>
-void launch_step(const mifwi_acoustic_plan *pl, const AcParams &p, hipStream_t st)
+void launch_step(const mifwi_acoustic_plan *pl, const AcParams &p, hipStream_t st, int ngroups = -1)
 {
     const int lz = kThreads / pl->lx;
     const int tiles_x = mifwi::ceil_div(pl->ng, pl->lx);
@@ -976,7 +979,7 @@ void launch_step(const mifwi_acoustic_plan *pl, const AcParams &p, hipStream_t s
     int extra = 0;
     if (p.smp_out != nullptr && p.nsmp > 0)
         extra = mifwi::ceil_div(mifwi::ceil_div(pl->gs * p.nsmp, kThreads), tiles_x);
-    dim3 grid(tiles_x, tiles_z + extra, pl->ngroups);
+    dim3 grid(tiles_x, tiles_z + extra, ngroups > 0 ? ngroups : pl->ngroups);
     switch (pl->lx) {
         case 64: launch_rz<64, SAVE, IMAGE>(pl, grid, q, st); break;
         case 32: launch_rz<32, SAVE, IMAGE>(pl, grid, q, st); break;
@@ -1170,6 +1173,23 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
         pl->gs = 1;
         pl->ngroups = d->nshot;
     }
+    {
+        // Infinity Cache residency of the per-step family (same rule as the elastic plan): a pass over the time
+        // range takes the shot groups whose wavefields (+ accumulators) fit 250 MB together with the model
+        constexpr double kResident = 250e6;
+        const double model = 4.0 * (double)pl->coef_elems;
+        const double gstate = 4.0 * 2.0 * (double)pl->shot_stride * pl->gs;
+        auto fit = [&](double per_group) {
+            int k = pl->ngroups;
+            if (pl->ngroups * per_group + model > kResident) {
+                k = (int)std::floor((kResident - model) / per_group);
+                if (k < 1) k = pl->ngroups;
+            }
+            return k;
+        };
+        pl->pass_fwd = std::min(pl->ngroups, std::max(1, env_int("MIFWI_AC_PASS_GROUPS", fit(gstate))));
+        pl->pass_adj = std::min(pl->ngroups, std::max(1, env_int("MIFWI_AC_PASS_GROUPS", fit(gstate + model))));
+    }
     *plan = pl;
     return MIFWI_OK;
 }
@@ -1244,16 +1264,20 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *pl, const float *r, const float 
         if (cluster_done(snap ? cluster_run<1>(pl, c, xbuf, st) : cluster_run<0>(pl, c, xbuf, st), flags, &out)) return out;
         MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * 2 * pl->field_elems, st));
     }
+    // shot groups are independent: a few at a time keep wavefields and model inside the Infinity Cache
+    for (int g0 = 0; g0 < pl->ngroups; g0 += pl->pass_fwd)
     for (int n = n_begin; n < n_end; ++n) {
+        const int cg = std::min(pl->pass_fwd, pl->ngroups - g0);
+        p.g0 = g0;
         p.cur = (n & 1) ? ub : ua;
         p.prev = (n & 1) ? ua : ub;
         p.inj_amp = f ? f + (long long)n * d.nshot * d.nsrc : nullptr;
         p.smp_out = (rec_out && d.nrec > 0) ? rec_out + (long long)n * d.nshot * d.nrec : nullptr;
         if (snap) {
             p.G = snap + (long long)(n - n_begin) * snap_step;
-            launch_step<true, false>(pl, p, st);
+            launch_step<true, false>(pl, p, st, cg);
         } else {
-            launch_step<false, false>(pl, p, st);
+            launch_step<false, false>(pl, p, st, cg);
         }
     }
     MIFWI_HIP_TRY(hipGetLastError());
@@ -1370,15 +1394,18 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
                 work, 0, sizeof(float) * (2 * pl->field_elems + pl->ngroups * pl->coef_elems), st));
         }
     }
-    for (int k = k_hi; per_step && k >= k_lo; --k) {
+    for (int g0 = 0; per_step && g0 < pl->ngroups; g0 += pl->pass_adj)
+    for (int k = k_hi; k >= k_lo; --k) {
         const int par = (d.nt - 1 - k) & 1;
+        p.g0 = g0;
         p.cur = par ? zb : za;
         p.prev = par ? za : zb;
         p.inj_amp = grad_rec + (long long)k * d.nshot * d.nrec;
         p.G = const_cast<float *>(snap) + (long long)(k - 1 - snap_first) * snap_step;
         p.smp_out = want_f ? grad_f + (long long)k * d.nshot * d.nsrc : nullptr;
-        launch_step<false, true>(pl, p, st);
+        launch_step<false, true>(pl, p, st, std::min(pl->pass_adj, pl->ngroups - g0));
     }
+    p.g0 = 0;
     if (flags & MIFWI_FINALIZE) {
         if (want_f) {
             // grad_f[k_lo-1] from z^{k_lo} (sampling workgroups only)
