@@ -243,3 +243,28 @@ def test_fused_forward_step_matches_the_two_launch_form(monkeypatch):
     for a, b in ((0, 1), (2, 3), (2, 4)):
         for x, y in zip(outs[a][1:], outs[b][1:]):
             assert torch.equal(x, y)
+
+
+def test_passes_over_shot_subsets_change_nothing(monkeypatch):
+    """Large grids run the time loop over a few shots at a time (Infinity Cache residency).  Forced here on a
+    small grid: traces bit for bit, gradients bit for bit for the same accumulator grouping."""
+    monkeypatch.setenv("MIFWI_EL_CLUSTER", "0")
+    monkeypatch.setenv("MIFWI_EL_CLUSTER_ADJ", "0")
+    monkeypatch.setenv("MIFWI_AC_CLUSTER", "0")
+    ce = elastic_case(seed=67, nz=60, nx=130, fw=8, ns=7, nrec=30, nt=60)
+    ca = acoustic_case(seed=69, n0=60, n1=130, nb=8, nt=70, ns=7, nrec=30)
+    outs = []
+    for shots, groups in (("7", "4"), ("2", "1"), ("3", "2")):
+        monkeypatch.setenv("MIFWI_EL_PASS_SHOTS", shots)
+        monkeypatch.setenv("MIFWI_EL_PASS_GROUPS", groups)
+        monkeypatch.setenv("MIFWI_AC_PASS_GROUPS", groups)
+        mat, f, rvx, rvz = _elastic(ce)
+        torch.autograd.backward([rvx, rvz], [torch.sign(rvx.detach()), torch.sign(rvz.detach())])
+        r, fa, rec = _acoustic(ca)
+        rec.backward(torch.sign(rec.detach()))
+        outs.append((rvx.detach(), rvz.detach(), mat.grad.clone(), f.grad.clone(),
+                     rec.detach(), r.grad.clone(), fa.grad.clone()))
+    assert float(outs[0][0].abs().max()) > 0 and float(outs[0][4].abs().max()) > 0
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert torch.equal(x, y)
