@@ -159,6 +159,11 @@ typedef struct {
                                 there, stresses mirrored oddly above it; the caller passes row 0 of
                                 mat[0..1] in the effective form (0, M - L^2/M)                    */
     int32_t shots_per_group; /* adjoint: shots sharing one gradient accumulator; 0 = auto     */
+    int32_t source_type;     /* 0: explosive, f added to sxx and szz after S (DENISE QUELLTYPB 1);
+                                1 / 2: point force, f added to vx / vz between V and S (QUELLTYPB 2 / 3,
+                                pyapi_denise attribute at networks.py:10419-10453).  f arrives scaled by the
+                                host in every case; grad_f is the matching adjoint sample.  Force sources
+                                run on the one-launch-per-half-step kernels.                          */
 } mifwi_elastic_desc;
 
 typedef struct {
@@ -178,7 +183,7 @@ int mifwi_elastic_plan_destroy(mifwi_elastic_plan *plan);
 int mifwi_elastic_plan_layout(const mifwi_elastic_plan *plan, mifwi_elastic_layout *out);
 
 /* Steps n = n_begin .. n_end-1.
- *   f [nt][nshot][nsrc] (added to sxx and szz, pre-scaled by the host)
+ *   f [nt][nshot][nsrc] (added to sxx and szz - or to vx / vz, desc.source_type - pre-scaled by the host)
  *   rec_vx, rec_vz [nt][nshot][nrec] or both NULL
  *   snap NULL or [n_end-n_begin][nshot][5][nz][gp]: the five PML-filtered derivative sums the
  *        material gradient needs (exx', ezz', exz', and the two force terms)                 */

@@ -34,6 +34,9 @@
  *   S:  sxx += Ms Dm_x vx ' + Ls Dm_z vz ' ; szz += Ls Dm_x vx ' + Ms Dm_z vz ' ;
  *       sxz += mus (Dp_z vx ' + Dp_x vz ')
  *   source: sxx, szz [cell] += w f[n] ;  receivers: rec_v*[n] = sum w v*[cell]  (after V)
+ *   source_type 1 / 2 (DENISE QUELLTYPB 2 / 3, point force along x / z): vx (vz) [cell] += w f[n] between
+ *   V and S instead; f arrives scaled by the host (dt/(h^2 rho) at the source node), so the adjoint of the
+ *   injection is plain sampling of the adjoint velocity after S^T.
  * Saved per step for the gradient (S, 5 arrays): e1', e2', e3'+e4', d1'+d2', d3'+d4'.
  *
  * free_surface = 1 (DENISE FREE_SURF, networks.py:9811): row 0 is the free surface (szz = 0 there).
@@ -62,6 +65,7 @@ typedef float real;
 typedef struct {
     int nz, nx, nt, nshot, nsrc, nrec, ntap;
     int free_surface;       /* 1: stress-imaging free surface on row 0 (see header) */
+    int source_type;        /* 0: explosive (sxx, szz), 1: force on vx, 2: force on vz */
 } oracle_elastic_cfg;
 
 typedef struct {
@@ -178,8 +182,20 @@ int oracle_elastic_forward(const oracle_elastic_cfg *c, const real *mat, const r
                     st.sxz[at(&g, -2, i)] = -st.sxz[at(&g, 1, i)];
                 }
             step_v(&g, mat, pz, px, &st, Sn);
+            if (c->source_type != 0)
+                for (int is = 0; is < c->nsrc; ++is) {
+                    const real amp = f[((size_t)n * ns + s) * c->nsrc + is];
+                    for (int t = 0; t < c->ntap; ++t) {
+                        const size_t e = ((size_t)s * c->nsrc + is) * c->ntap + t;
+                        const int cell = src_cell[e];
+                        if (cell < 0) continue;
+                        const size_t k = at(&g, cell / nx, cell % nx);
+                        if (c->source_type == 1) st.vx[k] += src_w[e] * amp;
+                        else st.vz[k] += src_w[e] * amp;
+                    }
+                }
             step_s(&g, mat, pz, px, &st, Sn);
-            for (int is = 0; is < c->nsrc; ++is) {
+            for (int is = 0; is < c->nsrc && c->source_type == 0; ++is) {
                 const real amp = f[((size_t)n * ns + s) * c->nsrc + is];
                 for (int t = 0; t < c->ntap; ++t) {
                     const size_t e = ((size_t)s * c->nsrc + is) * c->ntap + t;
@@ -259,7 +275,7 @@ int oracle_elastic_backward(const oracle_elastic_cfg *c, const real *mat, const 
             if (c->free_surface)
                 for (int i = 0; i < nx; ++i) st.szz[at(&g, 0, i)] = 0;
             /* b. source^T */
-            if (grad_f)
+            if (grad_f && c->source_type == 0)
                 for (int is = 0; is < c->nsrc; ++is) {
                     real a = 0;
                     for (int t = 0; t < c->ntap; ++t) {
@@ -294,6 +310,19 @@ int oracle_elastic_backward(const oracle_elastic_cfg *c, const real *mat, const 
                     const size_t k = at(&g, j, i);
                     st.vx[k] = st.vx[k] - (DPX(T[0], k) + DMZ(T[2], k, p));
                     st.vz[k] = st.vz[k] - (DPZ(T[1], k, p) + DMX(T[3], k));
+                }
+            /* force source^T: the adjoint velocity after S^T */
+            if (grad_f && c->source_type != 0)
+                for (int is = 0; is < c->nsrc; ++is) {
+                    real a = 0;
+                    for (int t = 0; t < c->ntap; ++t) {
+                        const size_t e = ((size_t)s * c->nsrc + is) * c->ntap + t;
+                        const int cell = src_cell[e];
+                        if (cell < 0) continue;
+                        const size_t k = at(&g, cell / nx, cell % nx);
+                        a = FMA(src_w[e], c->source_type == 1 ? st.vx[k] : st.vz[k], a);
+                    }
+                    grad_f[((size_t)n * ns + s) * c->nsrc + is] = a;
                 }
             /* d. V^T */
             for (int j = 0; j < nz; ++j)

@@ -38,7 +38,8 @@ class ElasticDesc(ctypes.Structure):
     _fields_ = [("nz", ctypes.c_int32), ("nx", ctypes.c_int32), ("nt", ctypes.c_int32),
                 ("nshot", ctypes.c_int32), ("nsrc", ctypes.c_int32), ("nrec", ctypes.c_int32),
                 ("ntap", ctypes.c_int32), ("pml_width", ctypes.c_int32),
-                ("free_surface", ctypes.c_int32), ("shots_per_group", ctypes.c_int32)]
+                ("free_surface", ctypes.c_int32), ("shots_per_group", ctypes.c_int32),
+                ("source_type", ctypes.c_int32)]
 
 
 class ElasticLayout(ctypes.Structure):

@@ -199,6 +199,7 @@ class Denise:
         self.QUELLART = 1
         self.QUELLTYP = 1
         self.QUELLTYPB = 1
+        self.QUELLTYP = 1
         self.FC_SPIKE_1 = -5.0
         self.FC_SPIKE_2 = 15.0
         self.ORDER_SPIKE = 5
@@ -291,12 +292,20 @@ class Denise:
         else:
             raise MifwiError("QUELLART=%s not implemented (1 Ricker, 3 samples, 6 band-limited spike)"
                              % self.QUELLART)
-        if self.QUELLTYPB not in (1, 2) or (self.QUELLTYPB == 2 and self.PHYSICS != 2):
-            raise MifwiError("QUELLTYPB=%s: only the explosive source is implemented" % self.QUELLTYPB)
+        # QUELLTYP: the point source (1 explosive, 2 / 3 force along x / y = depth).  QUELLTYPB is DENISE's
+        # ADJOINT source type - which seismogram components enter the misfit (1 both, 2 y only, 3 x only,
+        # 4 pressure); networks.py:10452 sets 2 for the hydrophone-free real-data case.
+        if self.QUELLTYP not in (1, 2, 3):
+            raise MifwiError("QUELLTYP=%s not implemented (1 explosive, 2 force x, 3 force y)" % self.QUELLTYP)
+        if self.QUELLTYPB not in (1, 2, 3):
+            raise MifwiError("QUELLTYPB=%s not implemented (1: x and y components, 2: y only, 3: x only)"
+                             % self.QUELLTYPB)
         if self.SEISMO != 1:
             raise MifwiError("SEISMO=%s: only particle-velocity seismograms are implemented" % self.SEISMO)
-        # explosive source: moment-rate density added to sxx and szz
-        f = torch.tensor(wav * (dt / (h * h)), dtype=torch.float32).view(nt, ns, 1)
+        # explosive source: moment-rate density added to sxx and szz; a point force keeps the bare wavelet
+        # here and gets dt/(h^2 rho) at the source node from elastic.force_amplitude (differentiable)
+        scale = dt / (h * h) if self.QUELLTYP == 1 else 1.0
+        f = torch.tensor(wav * scale, dtype=torch.float32).view(nt, ns, 1)
         fw = int(self.FW)
         fsurf = bool(int(self.FREE_SURF))
         pz = torch.tensor(profiles.cpml_tables(nz, fw, h, dt, self.DAMPING, self.FPML, self.npower,
@@ -313,13 +322,19 @@ class Denise:
                for a in (model.vp, vs, model.rho)]
         return prm, elastic.staggered_materials(prm[0], prm[1], prm[2], dt, h, free_surface=fsurf)
 
+    def _propagate(self, mat, f, pz, px, g, fw, fsurf, h):
+        kind = {1: "explosive", 2: "fx", 3: "fz"}[self.QUELLTYP]
+        if kind != "explosive":
+            f = elastic.force_amplitude(f, mat, g["sc"], g["sw"], h, kind)
+        return elastic.propagate(mat, f, pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw,
+                                 free_surface=fsurf, source_type=kind)
+
     def forward(self, model, src, rec):
         """Forward modelling; seismograms are kept in memory (``get_shots``)."""
         dev, h, dt, nt, g, f, pz, px, fw, fsurf = self._setup(model, src, rec)
         with torch.no_grad():
             _, mat = self._materials(model, dev, dt, h, False, fsurf)
-            vx, vy = elastic.propagate(mat, f.to(dev), pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw,
-                                       free_surface=fsurf)
+            vx, vy = self._propagate(mat, f.to(dev), pz, px, g, fw, fsurf, h)
         self._shots = (vx.permute(1, 2, 0).cpu().numpy(), vy.permute(1, 2, 0).cpu().numpy())
         self.DT_used = dt
         return self._shots
@@ -343,8 +358,7 @@ class Denise:
                 raise MifwiError("no observed data: call set_observed(vx, vy) or set DATA_DIR")
         dev, h, dt, nt, g, f, pz, px, fw, fsurf = self._setup(model, src, rec)
         prm, mat = self._materials(model, dev, dt, h, True, fsurf)
-        vx, vy = elastic.propagate(mat, f.to(dev), pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw,
-                                   free_surface=fsurf)
+        vx, vy = self._propagate(mat, f.to(dev), pz, px, g, fw, fsurf, h)
         ox, oy = (o.to(dev).permute(1, 0, 2) for o in self._observed)     # -> [nt, ns, nrec]
         if ox.shape != vx.shape:
             raise MifwiError("observed data %s do not match modelled %s (nt, nshot, nrec)"
@@ -353,8 +367,10 @@ class Denise:
         fl = lambda a: butterworth(a, dt, st.get("fc_low", 0.0), st.get("fc_high", 0.0),
                                    st.get("order", 6))
         # L2 objective (lnorm = 2) and its adjoint sources in one fused pass each (csrc/mifwi_misfit.hip)
-        loss = misfit.l2_half(fl(vy), fl(oy))
-        if self.QUELLTYPB != 2:
+        loss = 0.0
+        if self.QUELLTYPB in (1, 2):
+            loss = loss + misfit.l2_half(fl(vy), fl(oy))
+        if self.QUELLTYPB in (1, 3):
             loss = loss + misfit.l2_half(fl(vx), fl(ox))
         loss.backward()
         self.loss = float(loss.detach())

@@ -546,10 +546,7 @@ __device__ __forceinline__ void stage_E(const ElParams &p, int s, int j, int g, 
 //       all five material-gradient accumulators.
 // Every global load of a shot (own group, halo group, adjoint velocities, the five snapshot planes) is
 // requested before the first use: one memory round trip per shot instead of three.
-#ifndef MIFWI_ADJ_S_MINWAVES
-#define MIFWI_ADJ_S_MINWAVES 1
-#endif
-__global__ __launch_bounds__(kThreads, MIFWI_ADJ_S_MINWAVES) void el_adj_s(const ElParams p)
+__global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
 {
     int bx, by;
     xcd_tile(p, bx, by);
@@ -1066,6 +1063,43 @@ __global__ __launch_bounds__(kThreads) void el_sample_v(const ElParams p)
     sample_points<0>(p, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+// ---- point forces (source_type 1 / 2): a handful of cells per shot, launches of their own ---------------------
+// forward: v[cell] += w * f[n] between V and S.  One thread per shot walks its sources in order (several
+// sources may share a cell: no atomics, the sum order is fixed).
+__global__ void el_inject_force(const ElParams p, int comp)
+{
+    const int s = p.s0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s >= p.nshot || s >= p.s0 + p.gs) return;
+    float *v = p.fields + (long long)s * p.shot_stride + (comp == 1 ? F_VX : F_VZ) * (long long)p.field_stride;
+    for (int e = 0; e < p.ninj * p.ntap_inj; ++e) {
+        const long long ee = (long long)s * p.ninj * p.ntap_inj + e;
+        const int cell = p.inj_cell[ee];
+        if (cell < 0) continue;
+        const int j = cell / p.nx, i = cell - j * p.nx;
+        v[(unsigned)(j + 2) * p.pitch + 4 + i] += p.inj_w[ee] * p.inj_amp0[(long long)s * p.ninj + e / p.ntap_inj];
+    }
+}
+
+// adjoint: grad_f[n] = sum w * v_bar[cell], sampled between S^T and V^T
+__global__ void el_sample_force(const ElParams p, int comp)
+{
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);     // over the p.gs shots of this pass
+    if (idx >= p.gs * p.nsmp) return;
+    const int s = p.s0 + idx / p.nsmp;
+    if (s >= p.nshot) return;
+    const int e = s * p.nsmp + idx % p.nsmp;
+    const float *v = p.fields + (long long)s * p.shot_stride + (comp == 1 ? F_VX : F_VZ) * (long long)p.field_stride;
+    float a = 0.f;
+    for (int t = 0; t < p.ntap_smp; ++t) {
+        const long long ee = (long long)e * p.ntap_smp + t;
+        const int cell = p.smp_cell[ee];
+        if (cell < 0) continue;
+        const int j = cell / p.nx, i = cell - j * p.nx;
+        a = fmaf(p.smp_w[ee], v[(unsigned)(j + 2) * p.pitch + 4 + i], a);
+    }
+    p.smp_out0[e] = a;
+}
+
 __global__ void el_points_bbox(const int *cell, int npts_per_shot, int n1, int *bbox)
 {
     __shared__ int red[4][kThreads];
@@ -1201,7 +1235,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
 {
     pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0; pl->xbuf_elems = 0;
     pl->cl_adj = 0; pl->adj_NW = 0; pl->adj_shots = 0; pl->adj_lds = 0; pl->adj_ng = 0; pl->adj_zrows = 0; pl->list_elems = 0;
-    if (pl->d.ntap != 1) return;
+    if (pl->d.ntap != 1 || pl->d.source_type != 0) return;     // point forces: per-step kernels only
     const bool want_fwd = env_int("MIFWI_EL_CLUSTER", 1) != 0;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device) != hipSuccess) return;
@@ -1328,6 +1362,8 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
         return mifwi::fail(MIFWI_EINVAL, "free_surface must be 0 or 1");
     if (d->free_surface && d->nz < 4) return mifwi::fail(MIFWI_EINVAL, "free surface needs nz >= 4");
     if (d->pml_width < 0) return mifwi::fail(MIFWI_EINVAL, "pml_width < 0");
+    if (d->source_type < 0 || d->source_type > 2)
+        return mifwi::fail(MIFWI_EINVAL, "source_type must be 0 (explosive), 1 (force x) or 2 (force z)");
     int rc = mifwi::check_device(device);
     if (rc) return rc;
     // function attributes and CU counts queried during set-up belong to THIS device (one process per
@@ -1410,7 +1446,7 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
         k = env_int("MIFWI_EL_PASS_GROUPS", k);
         pl->pass_groups = std::min(pl->ngroups, std::max(1, k));
     }
-    pl->fused = !pl->cluster && env_int("MIFWI_EL_FUSED", 0) != 0;   // measured: no faster than two launches yet
+    pl->fused = !pl->cluster && d->source_type == 0 && env_int("MIFWI_EL_FUSED", 0) != 0;   // measured: no faster than two launches yet
     if (pl->cl_adj) {                    // the adjoint cluster kernel keeps one accumulator set per shot
         pl->gs = 1;
         pl->ngroups = d->nshot;
@@ -1542,8 +1578,11 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
     } else {
         p.fields = fbuf[0]; p.psix = pbuf[0]; p.psiz = pbuf[0] + pl->psix_elems;
         ElParams ps = p;
-        ps.ninj = d.nsrc; ps.ntap_inj = d.ntap; ps.inj_cell = src_cell; ps.inj_w = src_w;
+        const bool force = d.source_type != 0;       // point force: injected into vx / vz by a launch of its own
+        ps.ninj = force ? 0 : d.nsrc; ps.ntap_inj = d.ntap; ps.inj_cell = src_cell; ps.inj_w = src_w;
         ps.inj_bbox = bbox;
+        ElParams pf = p;
+        pf.ninj = d.nsrc; pf.ntap_inj = d.ntap; pf.inj_cell = src_cell; pf.inj_w = src_w;
         ps.nsmp = want_rec ? d.nrec : 0; ps.ntap_smp = d.ntap; ps.smp_cell = rec_cell; ps.smp_w = rec_w;
         // shots are independent: taken a few at a time, their state and the materials stay inside the
         // 256 MiB Infinity Cache from one launch to the next (pl->pass_shots; all shots when they fit anyway)
@@ -1556,8 +1595,13 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
                 ps.inj_amp0 = f ? f + (long long)n * d.nshot * d.nsrc : nullptr;
                 ps.smp_out0 = want_rec ? rec_vx + (long long)n * d.nshot * d.nrec : nullptr;
                 ps.smp_out1 = want_rec ? rec_vz + (long long)n * d.nshot * d.nrec : nullptr;
-                if (snap) { launch_v<true>(pl, p, cs, st); launch_s<true>(pl, ps, cs, st); }
-                else { launch_v<false>(pl, p, cs, st); launch_s<false>(pl, ps, cs, st); }
+                if (snap) launch_v<true>(pl, p, cs, st); else launch_v<false>(pl, p, cs, st);
+                if (force && d.nsrc > 0 && f) {
+                    pf.s0 = s0; pf.gs = cs; pf.inj_amp0 = ps.inj_amp0;
+                    hipLaunchKernelGGL(el_inject_force, dim3(mifwi::ceil_div(cs, 64)), dim3(64), 0, st, pf,
+                                       d.source_type);
+                }
+                if (snap) launch_s<true>(pl, ps, cs, st); else launch_s<false>(pl, ps, cs, st);
             }
         }
     }
@@ -1671,14 +1715,21 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         ps.S = const_cast<float *>(snap) + (long long)(n - snap_first) * snap_step;
         ps.inj_amp0 = g_vx + (long long)n * d.nshot * d.nrec;
         ps.inj_amp1 = g_vz + (long long)n * d.nshot * d.nrec;
-        ps.smp_out0 = want_f ? grad_f + (long long)n * d.nshot * d.nsrc : nullptr;
+        const bool force = d.source_type != 0;        // grad_f of a point force: v_bar sampled between S^T and V^T
+        ps.smp_out0 = (want_f && !force) ? grad_f + (long long)n * d.nshot * d.nsrc : nullptr;
         p.psix = ps.psix; p.psiz = ps.psiz; p.psix_out = ps.psix_out; p.psiz_out = ps.psiz_out;
         {
             const int tx = mifwi::ceil_div(pl->ng, AGO), tz = mifwi::ceil_div(d.nz, ATZ);
             ps.tiles_z = tz;
             int ex = 0;
-            if (want_f) ex = mifwi::ceil_div(mifwi::ceil_div(ps.gs * ps.nsmp, kThreads), tx);
+            if (want_f && !force) ex = mifwi::ceil_div(mifwi::ceil_div(ps.gs * ps.nsmp, kThreads), tx);
             hipLaunchKernelGGL(el_adj_s, dim3(tx, tz + ex, cg), dim3(kThreads), 0, st, ps);
+            if (want_f && force) {
+                ElParams pq = ps;
+                pq.gs = cs; pq.smp_out0 = grad_f + (long long)n * d.nshot * d.nsrc;
+                hipLaunchKernelGGL(el_sample_force, dim3(mifwi::ceil_div(cs * d.nsrc, 64)), dim3(64), 0, st, pq,
+                                   d.source_type);
+            }
             hipLaunchKernelGGL(el_adj_v, dim3(tx, tz, cs), dim3(kThreads), 0, st, p);
         }
     }

@@ -51,10 +51,10 @@ def staggered_materials(vp, vs, rho, dt, h, free_surface=False):
 
 class ElasticPlan:
     def __init__(self, nz, nx, nt, nshot, nsrc, nrec, ntap, pml_width, device_index,
-                 shots_per_group=0, free_surface=0):
+                 shots_per_group=0, free_surface=0, source_type=0):
         self._lib = _lib.load()
         self.desc = _lib.ElasticDesc(nz, nx, nt, nshot, nsrc, nrec, ntap, pml_width,
-                                     free_surface, shots_per_group)
+                                     free_surface, shots_per_group, source_type)
         self._h = ctypes.c_void_p()
         _lib.check(self._lib.mifwi_elastic_plan_create(ctypes.byref(self._h), device_index,
                                                        ctypes.byref(self.desc)))
@@ -83,7 +83,8 @@ class ElasticPlan:
 
 class _ElasticFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mat, f, pz, px, geom, pml_width, shots_per_group, snapshot_budget, free_surface):
+    def forward(ctx, mat, f, pz, px, geom, pml_width, shots_per_group, snapshot_budget, free_surface,
+                source_type=0):
         _require_cuda(mat, "mat")
         dev = mat.device
         lib = _lib.load()
@@ -99,7 +100,7 @@ class _ElasticFn(torch.autograd.Function):
             raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (nz, nx))
         with torch.cuda.device(dev):
             plan = ElasticPlan(nz, nx, nt, ns, nsrc, nrec, ntap, pml_width, dev.index,
-                               shots_per_group, free_surface)
+                               shots_per_group, free_surface, source_type)
             lay = plan.layout
             gp = lay.gp
             mat_p = torch.zeros((5, nz, gp), device=dev, dtype=torch.float32)
@@ -196,14 +197,18 @@ class _ElasticFn(torch.autograd.Function):
             plan.close()
             ctx.snap = None
             ctx.ckpt = None
-        return (grad_mat[:, :, :nx].contiguous(), grad_f, None, None, None, None, None, None, None)
+        return (grad_mat[:, :, :nx].contiguous(), grad_f, None, None, None, None, None, None, None, None)
 
 
 def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
-              shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET, free_surface=False):
+              shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET, free_surface=False,
+              source_type="explosive"):
     """Elastic forward modelling, differentiable w.r.t. ``mat`` and ``f``.
 
     mat [5,nz,nx] from :func:`staggered_materials`;  f [nt,nshot,nsrc] (added to sxx and szz);
+    source_type "explosive" (DENISE QUELLTYPB 1), or a point force "fx" / "fz" (QUELLTYPB 2 / 3): f is then
+    added to vx / vz between the velocity and the stress update - scale it with
+    :func:`force_amplitude` so that the density at the source node enters the gradient;
     pz [6,nz], px [6,nx] from :func:`profiles.cpml_tables`;  cells are iz*nx+ix.
     free_surface: row 0 is a stress-free surface (build ``mat`` with ``free_surface=True`` and
     ``pz`` with ``low=False``).
@@ -211,5 +216,24 @@ def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
     _require_cuda(mat, "mat")
     geom = _Geometry(src_cell, src_w, rec_cell, rec_w, mat.device)
     f = f.to(device=mat.device)
+    try:
+        st = SOURCE_TYPES[source_type]
+    except KeyError:
+        raise MifwiError("source_type must be one of %s" % sorted(k for k in SOURCE_TYPES if isinstance(k, str)))
     return _ElasticFn.apply(mat, f, pz, px, geom, int(pml_width), int(shots_per_group),
-                            int(snapshot_budget), 1 if free_surface else 0)
+                            int(snapshot_budget), 1 if free_surface else 0, st)
+
+
+SOURCE_TYPES = {"explosive": 0, "fx": 1, "fz": 2, 0: 0, 1: 1, 2: 2}
+
+
+def force_amplitude(wavelet, mat, src_cell, src_w, h, source_type):
+    """Point-force amplitudes for :func:`propagate`: wavelet [nt,nshot,nsrc] (force per unit length, N/m)
+    times dt/(h^2 rho) at the source node - DENISE's ``vx += DT * amp / (DH^2 rho)`` with
+    mat[3] = dt/(h rho_x), mat[4] = dt/(h rho_z).  Differentiable w.r.t. ``mat``: the source term's share of
+    the density gradient comes from autograd."""
+    plane = mat[3 if SOURCE_TYPES[source_type] == 1 else 4].reshape(-1)
+    cell = src_cell.to(device=mat.device, dtype=torch.long).clamp_min(0)
+    w = src_w.to(device=mat.device, dtype=mat.dtype) * (src_cell.to(mat.device) >= 0)
+    b = (plane[cell] * w).sum(dim=-1)                       # [nshot, nsrc]
+    return wavelet.to(device=mat.device, dtype=mat.dtype) * (b / h)[None]

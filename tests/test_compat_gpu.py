@@ -204,3 +204,43 @@ def test_denise_source_kinds_physics2_and_gradient_taper(tmp_path, monkeypatch):
     for a, b in zip(g0, g1):
         assert np.allclose(np.flipud(b), np.flipud(a) * w, rtol=1e-6, atol=0)
     assert not np.any(np.flipud(g1[1])[:21]) and not np.any(np.flipud(g1[1])[57:])
+
+
+def test_denise_point_force_and_adjoint_source_components(oracle32, tmp_path, monkeypatch):
+    """QUELLTYP 3 (vertical point force): seismograms equal the oracle fed with wavelet * dt/(h^2 rho) at the
+    source node.  QUELLTYPB (DENISE's adjoint-source type; networks.py:10452 sets 2) selects the components
+    of the misfit: 2 = y only, 3 = x only, and the two losses add up to QUELLTYPB = 1."""
+    api, d, (vp, vs, rho), dx, src, rec = _denise_setup(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    from oracle import helpers as H
+    model = api.Model(np.flipud(vp), np.flipud(vs), np.flipud(rho), dx)
+    ex, ey = d.forward(model, src, rec)
+    d.QUELLTYP = 3
+    sx, sy = d.forward(model, src, rec)
+    assert np.abs(sy).max() > 0 and rel_l2(sy / np.abs(sy).max(), ey / np.abs(ey).max()) > 0.1
+    nt = sx.shape[2]
+    dt, nz, nx = 0.002, vp.shape[0], vp.shape[1]
+    mat = H.elastic_materials(vp, vs, rho, dt, dx)
+    pz, px = H.cpml_profiles(nz, 10, dx, dt, 1500.0, 5.0), H.cpml_profiles(nx, 10, dx, dt, 1500.0, 5.0)
+    ix, iz = np.rint(src.x / dx).astype(int) - 1, np.rint(src.y / dx).astype(int) - 1
+    jx, jz = np.rint(rec.x / dx).astype(int) - 1, np.rint(rec.y / dx).astype(int) - 1
+    sc, sw = H.cell_taps(iz[:, None], ix[:, None], nx)
+    rc, rw = H.cell_taps(np.tile(jz, (3, 1)), np.tile(jx, (3, 1)), nx)
+    w = api.ricker_denise(8.0, nt, dt).astype(np.float64)
+    f = np.stack([w * mat[4][iz[k], ix[k]] / dx for k in range(3)], axis=1)[:, :, None].astype(np.float32)
+    ovx, ovz = oracle32.elastic_forward(mat, pz, px, f, sc, sw, rc, rw, source_type=2)
+    assert rel_l2(np.transpose(sy, (2, 0, 1)), ovz) <= 2e-5 and rel_l2(np.transpose(sx, (2, 0, 1)), ovx) <= 2e-5
+    # adjoint-source components
+    d.set_observed(0.8 * np.transpose(sx, (0, 2, 1)), 0.8 * np.transpose(sy, (0, 2, 1)))
+    losses, grads = {}, {}
+    for b in (1, 2, 3):
+        d.QUELLTYPB = b
+        losses[b] = d.grad(model, src, rec)
+        grads[b] = d.get_fwi_gradients(["seis"])
+    assert losses[2] > 0 and losses[3] > 0
+    assert abs(losses[2] + losses[3] - losses[1]) <= 1e-5 * losses[1]
+    for k in range(3):
+        assert np.allclose(grads[2][k] + grads[3][k], grads[1][k], rtol=2e-4, atol=1e-6 * np.abs(grads[1][k]).max())
+    d.QUELLTYPB = 4
+    with pytest.raises(Exception, match="QUELLTYPB"):
+        d.grad(model, src, rec)

@@ -15,7 +15,7 @@ TOL_TRACE = 1e-6
 TOL_GRAD = 2e-5
 
 
-def _run_hip(case, gs=0, budget=None, need_f=True):
+def _run_hip(case, gs=0, budget=None, need_f=True, source_type="explosive"):
     from physicsbasedfwi2_amd import elastic
     dev = torch.device("cuda:0")
     mat = torch.tensor(case["mat"], dtype=torch.float32, device=dev, requires_grad=True)
@@ -24,7 +24,8 @@ def _run_hip(case, gs=0, budget=None, need_f=True):
     rvx, rvz = elastic.propagate(mat, f, torch.tensor(case["pz"]), torch.tensor(case["px"]),
                                  torch.tensor(case["sc"]), torch.tensor(case["sw"]),
                                  torch.tensor(case["rc"]), torch.tensor(case["rw"]),
-                                 case["fw"], shots_per_group=gs, free_surface=bool(case["fs"]), **kw)
+                                 case["fw"], shots_per_group=gs, free_surface=bool(case["fs"]),
+                                 source_type=source_type, **kw)
     return mat, f, rvx, rvz
 
 
@@ -40,11 +41,11 @@ def test_forward_backward_parity(oracle32, kw):
     _check_parity(oracle32, elastic_case(seed=4, **kw))
 
 
-def _check_parity(o, case, bitwise=False):
+def _check_parity(o, case, bitwise=False, source_type=0):
     ovx, ovz, S = o.elastic_forward(case["mat"], case["pz"], case["px"], case["f"], case["sc"],
                                     case["sw"], case["rc"], case["rw"], save=True,
-                                    free_surface=case["fs"])
-    mat, f, rvx, rvz = _run_hip(case)
+                                    free_surface=case["fs"], source_type=source_type)
+    mat, f, rvx, rvz = _run_hip(case, source_type=source_type)
     hx, hz = rvx.detach().cpu().numpy(), rvz.detach().cpu().numpy()
     assert np.isfinite(hx).all() and np.abs(ovx).max() > 0 and np.abs(ovz).max() > 0
     print("max |hip-oracle| vx %.3e vz %.3e" % (np.abs(hx - ovx).max(), np.abs(hz - ovz).max()))
@@ -57,7 +58,8 @@ def _check_parity(o, case, bitwise=False):
     torch.autograd.backward([rvx, rvz], [torch.tensor(gx, device=rvx.device),
                                          torch.tensor(gz, device=rvx.device)])
     gm_o, gf_o = o.elastic_backward(case["mat"], case["pz"], case["px"], case["sc"], case["sw"],
-                                    case["rc"], case["rw"], gx, gz, S, free_surface=case["fs"])
+                                    case["rc"], case["rw"], gx, gz, S, free_surface=case["fs"],
+                                    source_type=source_type)
     gm_h = mat.grad.cpu().numpy()
     for k, name in enumerate(["lambda", "lambda+2mu", "mu_xz", "1/rho_x", "1/rho_z"]):
         assert rel_l2(gm_h[k], gm_o[k]) <= TOL_GRAD, name
@@ -188,3 +190,44 @@ def test_vp_vs_rho_chain(oracle32):
     mat_c.backward(torch.tensor(gm))
     for a, b, name in zip(prm, prc, ("vp", "vs", "rho")):
         assert rel_l2(a.grad.cpu().numpy(), b.grad.numpy()) <= 5e-5, name
+
+
+@pytest.mark.parametrize("source_type,kw", [
+    (1, dict(nsrc=2)),
+    (2, dict(nsrc=2, free_surface=True)),
+    (2, dict(nz=100, nx=300, fw=10, ns=5, nrec=40, nt=60)),      # a grid the explosive source runs single-launch
+])
+def test_point_force_sources_parity(oracle32, source_type, kw):
+    """desc.source_type 1 / 2: f goes into vx / vz between V and S (launches of their own on the per-step
+    kernels); seismograms, material gradients and the source gradient against oracle/elastic.c."""
+    case = elastic_case(seed=21, **kw)
+    case["f"] = (case["f"] * 1e-3).astype(np.float32)
+    _check_parity(oracle32, case, source_type=source_type)
+
+
+def test_force_amplitude_carries_the_density_gradient():
+    """elastic.force_amplitude scales the wavelet by dt/(h^2 rho) at the source node inside autograd: the
+    gradient w.r.t. the buoyancy plane gets the source term's share (finite-difference check of that share)."""
+    from physicsbasedfwi2_amd import elastic
+    case = elastic_case(seed=23, nsrc=1, ns=2, nrec=12, nt=60)
+    dev = torch.device("cuda:0")
+    sc, sw = torch.tensor(case["sc"]), torch.tensor(case["sw"])
+    geo = (torch.tensor(case["pz"]), torch.tensor(case["px"]), sc, sw, torch.tensor(case["rc"]), torch.tensor(case["rw"]))
+    wav = torch.tensor(case["f"] * 1e-3, dtype=torch.float32, device=dev)
+
+    def run(mat_amp, mat_prop):
+        f = elastic.force_amplitude(wav, mat_amp, sc, sw, 20.0, "fz")
+        vx, vz = elastic.propagate(mat_prop, f, *geo, case["fw"], source_type="fz")
+        return 0.5 * (vx.double() ** 2).sum() + 0.5 * (vz.double() ** 2).sum()
+    mat = torch.tensor(case["mat"], dtype=torch.float32, device=dev)
+    m_amp = mat.clone().requires_grad_(True)
+    J0 = run(m_amp, mat)                       # only the amplitude path sees m_amp
+    J0.backward()
+    cell = int(case["sc"][0, 0, 0])
+    g = float(m_amp.grad[4].reshape(-1)[cell])
+    assert g != 0.0 and float(m_amp.grad[3].abs().max()) == 0.0
+    eps = 1e-2
+    m2 = mat.clone()
+    m2[4].view(-1)[cell] *= (1 + eps)
+    fd = (float(run(m2, mat)) - float(J0)) / (eps * float(mat[4].reshape(-1)[cell]))
+    assert abs(fd - g) <= 2e-2 * abs(g)
