@@ -18,6 +18,11 @@
 // evaluates those four per-cell quantities on its tile + 2-cell halo into LDS, then applies the
 // stencils from LDS.  All five material-gradient accumulators are updated in the S^T launch and
 // stay in registers across the shots of a group (one read-modify-write per group, not per shot).
+// Tiles are taken in an XCD-contiguous order (xcd_tile) so that neighbouring tiles share an L2, and the
+// drivers sweep the time range a few shots at a time when all shots together would not stay inside the
+// 256 MiB Infinity Cache (plan->pass_shots / pass_groups).  Grids whose shot fits the LDS of a few CUs run
+// the whole time loop in one launch instead (mifwi_elastic_cluster.h); point forces (source_type 1 / 2) and
+// the opt-in fused V+S launch (el_step_fused) live on the per-step path only.
 // Arithmetic = the explicit fmaf chain of oracle/elastic.c (build with -ffp-contract=off).
 #include "mifwi_common.h"
 
@@ -1503,8 +1508,7 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
     hipStream_t st = (hipStream_t)stream;
     // state layout: [fields | psi | bbox], updated in place
     const long long psi = pl->psi_elems;
-    float *fbuf[1] = {work};
-    float *pbuf[1] = {work + pl->fields_elems};
+    float *fields = work, *psi_state = work + pl->fields_elems;
     int *bbox = reinterpret_cast<int *>(work + pl->fields_elems + psi);
     if (flags & MIFWI_ZERO_STATE)
         MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (pl->fields_elems + psi), st));
@@ -1525,7 +1529,7 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
         c.W = pl->W; c.wl = pl->wl; c.xr0 = pl->xr0; c.wx = pl->wx; c.fsurf = d.free_surface;
         c.psix_shot = 4LL * d.nz * pl->wx; c.psiz_shot = 4LL * 2 * pl->W * pl->gp;
         c.mat = mat; c.pz = pz; c.px = px;
-        c.fields = fbuf[0]; c.psix = pbuf[0]; c.psiz = pbuf[0] + pl->psix_elems;
+        c.fields = fields; c.psix = psi_state; c.psiz = psi_state + pl->psix_elems;
         c.S = snap; c.s_first = n_begin; c.s_step = snap_step;
         c.nsrc = d.nsrc; c.nrec = d.nrec; c.src_cell = src_cell; c.src_w = src_w; c.f = f;
         c.rec_cell = rec_cell; c.rec_w = rec_w;
@@ -1576,7 +1580,7 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
         if (last != work)
             MIFWI_HIP_TRY(hipMemcpyAsync(work, B, sizeof(float) * state, hipMemcpyDeviceToDevice, st));
     } else {
-        p.fields = fbuf[0]; p.psix = pbuf[0]; p.psiz = pbuf[0] + pl->psix_elems;
+        p.fields = fields; p.psix = psi_state; p.psiz = psi_state + pl->psix_elems;
         ElParams ps = p;
         const bool force = d.source_type != 0;       // point force: injected into vx / vz by a launch of its own
         ps.ninj = force ? 0 : d.nsrc; ps.ntap_inj = d.ntap; ps.inj_cell = src_cell; ps.inj_w = src_w;
