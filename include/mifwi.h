@@ -164,6 +164,9 @@ typedef struct {
                                 pyapi_denise attribute at networks.py:10419-10453).  f arrives scaled by the
                                 host in every case; grad_f is the matching adjoint sample.  Force sources
                                 run on the one-launch-per-half-step kernels.                          */
+    int32_t record_pressure; /* 1: the plan also serves pressure receivers (DENISE SEISMO 2 / 4, adjoint source
+                                type QUELLTYPB 4) through mifwi_elastic_plan_bind_pressure; such plans run on
+                                the one-launch-per-half-step kernels.                                     */
 } mifwi_elastic_desc;
 
 typedef struct {
@@ -181,6 +184,14 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device,
                               const mifwi_elastic_desc *desc);
 int mifwi_elastic_plan_destroy(mifwi_elastic_plan *plan);
 int mifwi_elastic_plan_layout(const mifwi_elastic_plan *plan, mifwi_elastic_layout *out);
+
+/* Pressure receivers of a plan created with record_pressure = 1 (same cells and weights as the velocity
+ * receivers).  The buffers stay bound to the plan until the next call of this function:
+ *   rec_p [nt][nshot][nrec] or NULL: mifwi_elastic_forward writes sum w (sxx + szz)[cell], sampled after the
+ *         stress update and the source term of each step (DENISE's pressure is its negative);
+ *   g_p   [nt][nshot][nrec] or NULL: mifwi_elastic_backward adds w g_p[n] to the adjoint sxx and szz before the
+ *         adjoint stress update of step n (the exact transpose of the sampling).                          */
+int mifwi_elastic_plan_bind_pressure(mifwi_elastic_plan *plan, float *rec_p, const float *g_p);
 
 /* Steps n = n_begin .. n_end-1.
  *   f [nt][nshot][nsrc] (added to sxx and szz - or to vx / vz, desc.source_type - pre-scaled by the host)

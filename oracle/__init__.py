@@ -133,7 +133,7 @@ def _el_cfg():
 
 
 def _elastic_forward(self, mat, pz, px, f, src_cell, src_w, rec_cell, rec_w, save=False,
-                     free_surface=0, source_type=0):
+                     free_surface=0, source_type=0, pressure=False):
     """mat [5,nz,nx]; pz [6,nz]; px [6,nx]; f [nt,ns,nsrc] -> rec_vx, rec_vz [nt,ns,nrec]
     (and S [nt,ns,5,nz,nx] when save).  source_type 0: f added to sxx and szz; 1 / 2: to vx / vz."""
     mat = self._r(mat); pz = self._r(pz); px = self._r(px); f = self._r(f)
@@ -146,19 +146,22 @@ def _elastic_forward(self, mat, pz, px, f, src_cell, src_w, rec_cell, rec_w, sav
     rvx = np.zeros((nt, ns, nrec), dtype=self.dtype)
     rvz = np.zeros((nt, ns, nrec), dtype=self.dtype)
     S = np.zeros((nt, ns, 5, nz, nx), dtype=self.dtype) if save else None
+    rp = np.zeros((nt, ns, nrec), dtype=self.dtype) if pressure else None   # sum w (sxx + szz)
     st = self.lib.oracle_elastic_forward(ctypes.byref(cfg), self._p(mat), self._p(pz), self._p(px),
                                          self._p(f), self._p(src_cell), self._p(src_w),
                                          self._p(rec_cell), self._p(rec_w), self._p(rvx),
-                                         self._p(rvz), self._p(S))
+                                         self._p(rvz), self._p(S), self._p(rp))
     if st != 0:
         raise RuntimeError("oracle_elastic_forward failed (%d)" % st)
-    return (rvx, rvz, S) if save else (rvx, rvz)
+    out = (rvx, rvz, S) if save else (rvx, rvz)
+    return out + (rp,) if pressure else out
 
 
 def _elastic_backward(self, mat, pz, px, src_cell, src_w, rec_cell, rec_w, g_vx, g_vz, S,
-                      want_grad_f=True, free_surface=0, source_type=0):
+                      want_grad_f=True, free_surface=0, source_type=0, g_p=None):
     mat = self._r(mat); pz = self._r(pz); px = self._r(px)
     g_vx = self._r(g_vx); g_vz = self._r(g_vz); S = self._r(S)
+    g_p = None if g_p is None else self._r(g_p)
     src_cell = self._i(src_cell); rec_cell = self._i(rec_cell)
     src_w = self._r(src_w); rec_w = self._r(rec_w)
     _, nz, nx = mat.shape
@@ -170,7 +173,8 @@ def _elastic_backward(self, mat, pz, px, src_cell, src_w, rec_cell, rec_w, g_vx,
     st = self.lib.oracle_elastic_backward(ctypes.byref(cfg), self._p(mat), self._p(pz),
                                           self._p(px), self._p(src_cell), self._p(src_w),
                                           self._p(rec_cell), self._p(rec_w), self._p(g_vx),
-                                          self._p(g_vz), self._p(S), self._p(gm), self._p(gf))
+                                          self._p(g_vz), self._p(S), self._p(gm), self._p(gf),
+                                          self._p(g_p))
     if st != 0:
         raise RuntimeError("oracle_elastic_backward failed (%d)" % st)
     return gm, gf

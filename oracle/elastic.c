@@ -37,6 +37,9 @@
  *   source_type 1 / 2 (DENISE QUELLTYPB 2 / 3, point force along x / z): vx (vz) [cell] += w f[n] between
  *   V and S instead; f arrives scaled by the host (dt/(h^2 rho) at the source node), so the adjoint of the
  *   injection is plain sampling of the adjoint velocity after S^T.
+ *   pressure receivers (rec_p != NULL; DENISE SEISMO 2 / 4): rec_p[n] = sum w (sxx + szz)[cell] after S and the
+ *   source term (the host applies DENISE's sign, p = -(sxx + syy)); their adjoint adds w g_p[n] to the adjoint
+ *   sxx and szz before anything else of step n.
  * Saved per step for the gradient (S, 5 arrays): e1', e2', e3'+e4', d1'+d2', d3'+d4'.
  *
  * free_surface = 1 (DENISE FREE_SURF, networks.py:9811): row 0 is the free surface (szz = 0 there).
@@ -159,7 +162,7 @@ static void step_s(const geom *g, const real *mat, const real *pz, const real *p
 int oracle_elastic_forward(const oracle_elastic_cfg *c, const real *mat, const real *pz,
                            const real *px, const real *f, const int *src_cell, const real *src_w,
                            const int *rec_cell, const real *rec_w, real *rec_vx, real *rec_vz,
-                           real *S)
+                           real *S, real *rec_p)
 {
     if (c->free_surface && c->nz < 3) return 2;
     geom g = {c->nz, c->nx, (size_t)(c->nx + 2 * HALO), 0};
@@ -222,6 +225,17 @@ int oracle_elastic_forward(const oracle_elastic_cfg *c, const real *mat, const r
                 rec_vx[((size_t)n * ns + s) * c->nrec + ir] = ax;
                 rec_vz[((size_t)n * ns + s) * c->nrec + ir] = az;
             }
+            for (int ir = 0; ir < c->nrec && rec_p; ++ir) {
+                real a = 0;
+                for (int t = 0; t < c->ntap; ++t) {
+                    const size_t e = ((size_t)s * c->nrec + ir) * c->ntap + t;
+                    const int cell = rec_cell[e];
+                    if (cell < 0) continue;
+                    const size_t k = at(&g, cell / nx, cell % nx);
+                    a = FMA(rec_w[e], st.sxx[k] + st.szz[k], a);
+                }
+                rec_p[((size_t)n * ns + s) * c->nrec + ir] = a;
+            }
         }
         state_free(&st);
     }
@@ -236,7 +250,8 @@ int oracle_elastic_forward(const oracle_elastic_cfg *c, const real *mat, const r
 int oracle_elastic_backward(const oracle_elastic_cfg *c, const real *mat, const real *pz,
                             const real *px, const int *src_cell, const real *src_w,
                             const int *rec_cell, const real *rec_w, const real *g_vx,
-                            const real *g_vz, const real *S, real *grad_mat, real *grad_f)
+                            const real *g_vz, const real *S, real *grad_mat, real *grad_f,
+                            const real *g_p)
 {
     if (c->free_surface && c->nz < 3) return 2;
     geom g = {c->nz, c->nx, (size_t)(c->nx + 2 * HALO), 0};
@@ -269,6 +284,17 @@ int oracle_elastic_backward(const oracle_elastic_cfg *c, const real *mat, const 
                     const size_t k = at(&g, cell / nx, cell % nx);
                     st.vx[k] += rec_w[e] * gx;
                     st.vz[k] += rec_w[e] * gz;
+                }
+            }
+            for (int ir = 0; ir < c->nrec && g_p; ++ir) {          /* pressure receivers^T */
+                const real gp = g_p[((size_t)n * ns + s) * c->nrec + ir];
+                for (int t = 0; t < c->ntap; ++t) {
+                    const size_t e = ((size_t)s * c->nrec + ir) * c->ntap + t;
+                    const int cell = rec_cell[e];
+                    if (cell < 0) continue;
+                    const size_t k = at(&g, cell / nx, cell % nx);
+                    st.sxx[k] += rec_w[e] * gp;
+                    st.szz[k] += rec_w[e] * gp;
                 }
             }
             /* free surface: szz(0,.) is identically 0 in the forward run, its adjoint is discarded */

@@ -39,7 +39,7 @@ class ElasticDesc(ctypes.Structure):
                 ("nshot", ctypes.c_int32), ("nsrc", ctypes.c_int32), ("nrec", ctypes.c_int32),
                 ("ntap", ctypes.c_int32), ("pml_width", ctypes.c_int32),
                 ("free_surface", ctypes.c_int32), ("shots_per_group", ctypes.c_int32),
-                ("source_type", ctypes.c_int32)]
+                ("source_type", ctypes.c_int32), ("record_pressure", ctypes.c_int32)]
 
 
 class ElasticLayout(ctypes.Structure):
@@ -68,6 +68,7 @@ SIGNATURES = {
                                                  ctypes.POINTER(ElasticDesc)]),
     "mifwi_elastic_plan_destroy": (ctypes.c_int, [_P]),
     "mifwi_elastic_plan_layout": (ctypes.c_int, [_P, ctypes.POINTER(ElasticLayout)]),
+    "mifwi_elastic_plan_bind_pressure": (ctypes.c_int, [_P, _P, _P]),
     "mifwi_elastic_forward": (ctypes.c_int, [_P] * 13 + [ctypes.c_int32] * 3 + [_P]),
     "mifwi_elastic_backward": (ctypes.c_int, [_P] * 11 + [ctypes.c_int32] + [_P] * 3 +
                                [ctypes.c_int32] * 3 + [_P]),

@@ -221,6 +221,8 @@ class Denise:
         self._observed = None
         self._gradients = None
         self._shots = None
+        self._shots_p = None
+        self._observed_p = None
         self.loss = None
 
     # -- protocol no-ops ------------------------------------------------------------------------
@@ -239,11 +241,12 @@ class Denise:
         self.fwi_stages.append(stage)
 
     # -- observed data ----------------------------------------------------------------------------
-    def set_observed(self, vx, vy):
-        """Observed particle velocities, each [nshot, nt, nrec] (array or tensor), in shot order of
-        the ``Sources`` passed to :meth:`grad`."""
+    def set_observed(self, vx, vy, p=None):
+        """Observed particle velocities (and, for QUELLTYPB = 4, pressure), each [nshot, nt, nrec] (array or
+        tensor), in shot order of the ``Sources`` passed to :meth:`grad`."""
         self._observed = (torch.as_tensor(np.asarray(vx) if not torch.is_tensor(vx) else vx).float(),
                           torch.as_tensor(np.asarray(vy) if not torch.is_tensor(vy) else vy).float())
+        self._observed_p = None if p is None else torch.as_tensor(np.asarray(p) if not torch.is_tensor(p) else p).float()
 
     def load_observed_su(self, nshots):
         """DENISE layout: DATA_DIR + '_x.su.shot<k>' / '_y.su.shot<k>' (networks.py:7690-7692)."""
@@ -297,11 +300,15 @@ class Denise:
         # 4 pressure); networks.py:10452 sets 2 for the hydrophone-free real-data case.
         if self.QUELLTYP not in (1, 2, 3):
             raise MifwiError("QUELLTYP=%s not implemented (1 explosive, 2 force x, 3 force y)" % self.QUELLTYP)
-        if self.QUELLTYPB not in (1, 2, 3):
-            raise MifwiError("QUELLTYPB=%s not implemented (1: x and y components, 2: y only, 3: x only)"
-                             % self.QUELLTYPB)
-        if self.SEISMO != 1:
-            raise MifwiError("SEISMO=%s: only particle-velocity seismograms are implemented" % self.SEISMO)
+        if self.QUELLTYPB not in (1, 2, 3, 4):
+            raise MifwiError("QUELLTYPB=%s not implemented (1: x and y components, 2: y only, 3: x only, "
+                             "4: pressure)" % self.QUELLTYPB)
+        # SEISMO: 1 particle velocities, 2 pressure, 4 both (3 = curl/div is not implemented); the propagator
+        # always returns the velocities, pressure on request
+        if self.SEISMO not in (1, 2, 4):
+            raise MifwiError("SEISMO=%s not implemented (1 velocities, 2 pressure, 4 both)" % self.SEISMO)
+        if self.QUELLTYPB == 4 and self.SEISMO == 1:
+            raise MifwiError("QUELLTYPB=4 (pressure adjoint sources) needs SEISMO 2 or 4")
         # explosive source: moment-rate density added to sxx and szz; a point force keeps the bare wavelet
         # here and gets dt/(h^2 rho) at the source node from elastic.force_amplitude (differentiable)
         scale = dt / (h * h) if self.QUELLTYP == 1 else 1.0
@@ -326,16 +333,19 @@ class Denise:
         kind = {1: "explosive", 2: "fx", 3: "fz"}[self.QUELLTYP]
         if kind != "explosive":
             f = elastic.force_amplitude(f, mat, g["sc"], g["sw"], h, kind)
-        return elastic.propagate(mat, f, pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw,
-                                 free_surface=fsurf, source_type=kind)
+        out = elastic.propagate(mat, f, pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw,
+                                free_surface=fsurf, source_type=kind, record_pressure=self.SEISMO in (2, 4))
+        # DENISE's pressure seismogram: p = -(sxx + syy) at the receiver node
+        return (out[0], out[1], -out[2]) if len(out) == 3 else (out[0], out[1], None)
 
     def forward(self, model, src, rec):
         """Forward modelling; seismograms are kept in memory (``get_shots``)."""
         dev, h, dt, nt, g, f, pz, px, fw, fsurf = self._setup(model, src, rec)
         with torch.no_grad():
             _, mat = self._materials(model, dev, dt, h, False, fsurf)
-            vx, vy = self._propagate(mat, f.to(dev), pz, px, g, fw, fsurf, h)
+            vx, vy, p = self._propagate(mat, f.to(dev), pz, px, g, fw, fsurf, h)
         self._shots = (vx.permute(1, 2, 0).cpu().numpy(), vy.permute(1, 2, 0).cpu().numpy())
+        self._shots_p = None if p is None else p.permute(1, 2, 0).cpu().numpy()
         self.DT_used = dt
         return self._shots
 
@@ -343,6 +353,12 @@ class Denise:
         """List of [nrec, nt] arrays, one per shot, for the component named in ``keys``."""
         if self._shots is None:
             raise MifwiError("run forward() first")
+        if any("_p" in k for k in keys):
+            if self._shots_p is None:
+                raise MifwiError("pressure seismograms need SEISMO = 2 or 4")
+            out = [a for a in self._shots_p]
+            names = ["su/seis_p.su.shot%d" % (i + 1) for i in range(len(out))]
+            return (out, names) if return_filenames else out
         comp = 0 if any("_x" in k for k in keys) else 1
         out = [a for a in self._shots[comp]]
         names = ["su/seis%s.su.shot%d" % ("_x" if comp == 0 else "_y", i + 1) for i in range(len(out))]
@@ -358,7 +374,7 @@ class Denise:
                 raise MifwiError("no observed data: call set_observed(vx, vy) or set DATA_DIR")
         dev, h, dt, nt, g, f, pz, px, fw, fsurf = self._setup(model, src, rec)
         prm, mat = self._materials(model, dev, dt, h, True, fsurf)
-        vx, vy = self._propagate(mat, f.to(dev), pz, px, g, fw, fsurf, h)
+        vx, vy, p = self._propagate(mat, f.to(dev), pz, px, g, fw, fsurf, h)
         ox, oy = (o.to(dev).permute(1, 0, 2) for o in self._observed)     # -> [nt, ns, nrec]
         if ox.shape != vx.shape:
             raise MifwiError("observed data %s do not match modelled %s (nt, nshot, nrec)"
@@ -372,6 +388,10 @@ class Denise:
             loss = loss + misfit.l2_half(fl(vy), fl(oy))
         if self.QUELLTYPB in (1, 3):
             loss = loss + misfit.l2_half(fl(vx), fl(ox))
+        if self.QUELLTYPB == 4:
+            if self._observed_p is None:
+                raise MifwiError("QUELLTYPB=4: pass the observed pressure with set_observed(vx, vy, p=...)")
+            loss = loss + misfit.l2_half(fl(p), fl(self._observed_p.to(dev).permute(1, 0, 2)))
         loss.backward()
         self.loss = float(loss.detach())
         with open("loss_curve_grad.out", "w") as fh:

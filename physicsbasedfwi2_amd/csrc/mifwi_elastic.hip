@@ -1105,6 +1105,48 @@ __global__ void el_sample_force(const ElParams p, int comp)
     p.smp_out0[e] = a;
 }
 
+// ---- pressure receivers (desc.record_pressure): launches of their own on the per-step path -----------------
+// forward: rec_p[n] = sum w (sxx + szz)[cell] after S and the source term, for the p.gs shots of this pass
+__global__ void el_sample_pressure(const ElParams p)
+{
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (idx >= p.gs * p.nsmp) return;
+    const int s = p.s0 + idx / p.nsmp;
+    if (s >= p.nshot) return;
+    const int e = s * p.nsmp + idx % p.nsmp;
+    const float *fl = p.fields + (long long)s * p.shot_stride;
+    float a = 0.f;
+    for (int t = 0; t < p.ntap_smp; ++t) {
+        const long long ee = (long long)e * p.ntap_smp + t;
+        const int cell = p.smp_cell[ee];
+        if (cell < 0) continue;
+        const int j = cell / p.nx, i = cell - j * p.nx;
+        const unsigned off = (unsigned)(j + 2) * p.pitch + 4 + i;
+        a = fmaf(p.smp_w[ee], fl[F_SXX * (long long)p.field_stride + off] + fl[F_SZZ * (long long)p.field_stride + off], a);
+    }
+    p.smp_out0[e] = a;
+}
+
+// adjoint: sxx_bar, szz_bar [cell] += w g_p[n] before S^T (receivers normally sit on distinct cells; taps that
+// share a cell add in hardware order, as in the LDS staging of the velocity receivers)
+__global__ void el_inject_pressure(const ElParams p)
+{
+    const int per = p.ninj * p.ntap_inj;
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (idx >= p.gs * per) return;
+    const int s = p.s0 + idx / per, r = idx % per;
+    if (s >= p.nshot) return;
+    const long long ee = (long long)s * per + r;
+    const int cell = p.inj_cell[ee];
+    if (cell < 0) return;
+    const int j = cell / p.nx, i = cell - j * p.nx;
+    const unsigned off = (unsigned)(j + 2) * p.pitch + 4 + i;
+    float *fl = p.fields + (long long)s * p.shot_stride;
+    const float a = p.inj_w[ee] * p.inj_amp0[(long long)s * p.ninj + r / p.ntap_inj];
+    atomicAdd(fl + F_SXX * (long long)p.field_stride + off, a);
+    atomicAdd(fl + F_SZZ * (long long)p.field_stride + off, a);
+}
+
 __global__ void el_points_bbox(const int *cell, int npts_per_shot, int n1, int *bbox)
 {
     __shared__ int red[4][kThreads];
@@ -1160,6 +1202,8 @@ struct mifwi_elastic_plan {
     int device;
     int ng, gp, pitch, lx, rz, gs, ngroups;
     int W, wl, xr0, wx, xcd;
+    float *rec_p;          // pressure receivers bound by mifwi_elastic_plan_bind_pressure (or null)
+    const float *g_p;
     int pass_shots;        // forward per-step family: shots per pass over the time range
     int pass_groups;       // adjoint per-step family: shot groups per pass
     int fused;             // forward V+S in one launch (second copy of the state in the work buffer)
@@ -1240,7 +1284,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
 {
     pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0; pl->xbuf_elems = 0;
     pl->cl_adj = 0; pl->adj_NW = 0; pl->adj_shots = 0; pl->adj_lds = 0; pl->adj_ng = 0; pl->adj_zrows = 0; pl->list_elems = 0;
-    if (pl->d.ntap != 1 || pl->d.source_type != 0) return;     // point forces: per-step kernels only
+    if (pl->d.ntap != 1 || pl->d.source_type != 0 || pl->d.record_pressure) return;   // per-step kernels only
     const bool want_fwd = env_int("MIFWI_EL_CLUSTER", 1) != 0;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device) != hipSuccess) return;
@@ -1367,6 +1411,8 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
         return mifwi::fail(MIFWI_EINVAL, "free_surface must be 0 or 1");
     if (d->free_surface && d->nz < 4) return mifwi::fail(MIFWI_EINVAL, "free surface needs nz >= 4");
     if (d->pml_width < 0) return mifwi::fail(MIFWI_EINVAL, "pml_width < 0");
+    if (d->record_pressure != 0 && d->record_pressure != 1)
+        return mifwi::fail(MIFWI_EINVAL, "record_pressure must be 0 or 1");
     if (d->source_type < 0 || d->source_type > 2)
         return mifwi::fail(MIFWI_EINVAL, "source_type must be 0 (explosive), 1 (force x) or 2 (force z)");
     int rc = mifwi::check_device(device);
@@ -1377,6 +1423,7 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     mifwi_elastic_plan *pl = new mifwi_elastic_plan;
     pl->d = *d;
     pl->device = device;
+    pl->rec_p = nullptr; pl->g_p = nullptr;
     pl->ng = mifwi::ceil_div(d->nx, 4);
     pl->gp = 4 * pl->ng;
     pl->pitch = (int)mifwi::round_up64(4 * (pl->ng + 3), 32);
@@ -1451,7 +1498,7 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
         k = env_int("MIFWI_EL_PASS_GROUPS", k);
         pl->pass_groups = std::min(pl->ngroups, std::max(1, k));
     }
-    pl->fused = !pl->cluster && d->source_type == 0 && env_int("MIFWI_EL_FUSED", 0) != 0;   // measured: no faster than two launches yet
+    pl->fused = !pl->cluster && d->source_type == 0 && !d->record_pressure && env_int("MIFWI_EL_FUSED", 0) != 0;   // measured: no faster than two launches yet
     if (pl->cl_adj) {                    // the adjoint cluster kernel keeps one accumulator set per shot
         pl->gs = 1;
         pl->ngroups = d->nshot;
@@ -1464,6 +1511,16 @@ int mifwi_elastic_plan_cluster_slabs(const mifwi_elastic_plan *plan, int32_t adj
 {
     if (!plan) return 0;
     return adjoint ? (plan->cl_adj ? plan->adj_NW : 0) : (plan->cluster ? plan->NW : 0);
+}
+
+int mifwi_elastic_plan_bind_pressure(mifwi_elastic_plan *plan, float *rec_p, const float *g_p)
+{
+    if (!plan) return mifwi::fail(MIFWI_EINVAL, "null plan");
+    if ((rec_p || g_p) && !plan->d.record_pressure)
+        return mifwi::fail(MIFWI_EINVAL, "the plan was created with record_pressure = 0");
+    plan->rec_p = rec_p;
+    plan->g_p = g_p;
+    return MIFWI_OK;
 }
 
 int mifwi_elastic_plan_destroy(mifwi_elastic_plan *plan)
@@ -1606,6 +1663,11 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
                                        d.source_type);
                 }
                 if (snap) launch_s<true>(pl, ps, cs, st); else launch_s<false>(pl, ps, cs, st);
+                if (pl->rec_p && want_rec) {
+                    ElParams pq = ps;
+                    pq.s0 = s0; pq.gs = cs; pq.smp_out0 = pl->rec_p + (long long)n * d.nshot * d.nrec;
+                    hipLaunchKernelGGL(el_sample_pressure, dim3(mifwi::ceil_div(cs * d.nrec, 64)), dim3(64), 0, st, pq);
+                }
             }
         }
     }
@@ -1727,6 +1789,12 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
             ps.tiles_z = tz;
             int ex = 0;
             if (want_f && !force) ex = mifwi::ceil_div(mifwi::ceil_div(ps.gs * ps.nsmp, kThreads), tx);
+            if (pl->g_p && d.nrec > 0) {
+                ElParams pq = ps;
+                pq.gs = cs; pq.inj_amp0 = pl->g_p + (long long)n * d.nshot * d.nrec;
+                hipLaunchKernelGGL(el_inject_pressure, dim3(mifwi::ceil_div(cs * d.nrec * d.ntap, 64)), dim3(64), 0,
+                                   st, pq);
+            }
             hipLaunchKernelGGL(el_adj_s, dim3(tx, tz + ex, cg), dim3(kThreads), 0, st, ps);
             if (want_f && force) {
                 ElParams pq = ps;

@@ -51,10 +51,10 @@ def staggered_materials(vp, vs, rho, dt, h, free_surface=False):
 
 class ElasticPlan:
     def __init__(self, nz, nx, nt, nshot, nsrc, nrec, ntap, pml_width, device_index,
-                 shots_per_group=0, free_surface=0, source_type=0):
+                 shots_per_group=0, free_surface=0, source_type=0, record_pressure=0):
         self._lib = _lib.load()
         self.desc = _lib.ElasticDesc(nz, nx, nt, nshot, nsrc, nrec, ntap, pml_width,
-                                     free_surface, shots_per_group, source_type)
+                                     free_surface, shots_per_group, source_type, record_pressure)
         self._h = ctypes.c_void_p()
         _lib.check(self._lib.mifwi_elastic_plan_create(ctypes.byref(self._h), device_index,
                                                        ctypes.byref(self.desc)))
@@ -84,7 +84,7 @@ class ElasticPlan:
 class _ElasticFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mat, f, pz, px, geom, pml_width, shots_per_group, snapshot_budget, free_surface,
-                source_type=0):
+                source_type=0, record_pressure=0):
         _require_cuda(mat, "mat")
         dev = mat.device
         lib = _lib.load()
@@ -100,7 +100,7 @@ class _ElasticFn(torch.autograd.Function):
             raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (nz, nx))
         with torch.cuda.device(dev):
             plan = ElasticPlan(nz, nx, nt, ns, nsrc, nrec, ntap, pml_width, dev.index,
-                               shots_per_group, free_surface, source_type)
+                               shots_per_group, free_surface, source_type, record_pressure)
             lay = plan.layout
             gp = lay.gp
             mat_p = torch.zeros((5, nz, gp), device=dev, dtype=torch.float32)
@@ -113,6 +113,10 @@ class _ElasticFn(torch.autograd.Function):
             f_d = f.detach().to(dtype=torch.float32).contiguous()
             rvx = torch.empty((nt, ns, nrec), device=dev, dtype=torch.float32)
             rvz = torch.empty((nt, ns, nrec), device=dev, dtype=torch.float32)
+            # pressure receivers: sum w (sxx + szz), bound to the plan (mifwi_elastic_plan_bind_pressure)
+            rp = torch.empty((nt, ns, nrec) if record_pressure else (0,), device=dev, dtype=torch.float32)
+            if record_pressure:
+                _lib.check(lib.mifwi_elastic_plan_bind_pressure(plan.handle, _lib.ptr(rp), None))
             work = torch.empty(lay.work_forward_elems, device=dev, dtype=torch.float32)
             need_grad = mat.requires_grad or f.requires_grad
             step_bytes = 4 * 5 * ns * lay.coef_elems
@@ -142,13 +146,14 @@ class _ElasticFn(torch.autograd.Function):
                 ctx.plan, ctx.geom, ctx.seg, ctx.ckpt, ctx.snap = plan, geom, seg, ckpt, snap
                 ctx.dims = (nz, nx, nt, ns, nsrc, nrec)
                 ctx.need_f = f.requires_grad
+                ctx.record_pressure = record_pressure
                 ctx.save_for_backward(mat_p, pz_d, px_p, f_d)
             else:
                 plan.close()
-        return rvx, rvz
+        return rvx, rvz, rp
 
     @staticmethod
-    def backward(ctx, g_vx, g_vz):
+    def backward(ctx, g_vx, g_vz, g_p=None):
         lib = _lib.load()
         mat_p, pz_d, px_p, f_d = ctx.saved_tensors
         plan, geom = ctx.plan, ctx.geom
@@ -160,6 +165,10 @@ class _ElasticFn(torch.autograd.Function):
                   else g_vx.to(dtype=torch.float32).contiguous())
             gz = (torch.zeros((nt, ns, nrec), device=dev) if g_vz is None
                   else g_vz.to(dtype=torch.float32).contiguous())
+            if ctx.record_pressure:
+                gp_ = (None if g_p is None or g_p.numel() == 0 else g_p.to(dtype=torch.float32).contiguous())
+                # the forward re-runs of a checkpointed backward must not sample again: rec_p unbound
+                _lib.check(lib.mifwi_elastic_plan_bind_pressure(plan.handle, None, _lib.ptr(gp_)))
             grad_mat = torch.empty((5, nz, lay.gp), device=dev, dtype=torch.float32)
             grad_f = (torch.zeros((nt, ns, nsrc), device=dev, dtype=torch.float32)
                       if ctx.need_f else None)
@@ -197,12 +206,12 @@ class _ElasticFn(torch.autograd.Function):
             plan.close()
             ctx.snap = None
             ctx.ckpt = None
-        return (grad_mat[:, :, :nx].contiguous(), grad_f, None, None, None, None, None, None, None, None)
+        return (grad_mat[:, :, :nx].contiguous(), grad_f, None, None, None, None, None, None, None, None, None)
 
 
 def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
               shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET, free_surface=False,
-              source_type="explosive"):
+              source_type="explosive", record_pressure=False):
     """Elastic forward modelling, differentiable w.r.t. ``mat`` and ``f``.
 
     mat [5,nz,nx] from :func:`staggered_materials`;  f [nt,nshot,nsrc] (added to sxx and szz);
@@ -212,7 +221,9 @@ def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
     pz [6,nz], px [6,nx] from :func:`profiles.cpml_tables`;  cells are iz*nx+ix.
     free_surface: row 0 is a stress-free surface (build ``mat`` with ``free_surface=True`` and
     ``pz`` with ``low=False``).
-    Returns (rec_vx, rec_vz), each [nt,nshot,nrec], sampled after the velocity update."""
+    Returns (rec_vx, rec_vz), each [nt,nshot,nrec], sampled after the velocity update; with
+    ``record_pressure`` also rec_p = sum w (sxx + szz) at the receivers after the stress update (DENISE's
+    pressure seismogram is ``-rec_p``; such runs use the one-launch-per-half-step kernels)."""
     _require_cuda(mat, "mat")
     geom = _Geometry(src_cell, src_w, rec_cell, rec_w, mat.device)
     f = f.to(device=mat.device)
@@ -220,8 +231,10 @@ def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
         st = SOURCE_TYPES[source_type]
     except KeyError:
         raise MifwiError("source_type must be one of %s" % sorted(k for k in SOURCE_TYPES if isinstance(k, str)))
-    return _ElasticFn.apply(mat, f, pz, px, geom, int(pml_width), int(shots_per_group),
-                            int(snapshot_budget), 1 if free_surface else 0, st)
+    rvx, rvz, rp = _ElasticFn.apply(mat, f, pz, px, geom, int(pml_width), int(shots_per_group),
+                                    int(snapshot_budget), 1 if free_surface else 0, st,
+                                    1 if record_pressure else 0)
+    return (rvx, rvz, rp) if record_pressure else (rvx, rvz)
 
 
 SOURCE_TYPES = {"explosive": 0, "fx": 1, "fz": 2, 0: 0, 1: 1, 2: 2}

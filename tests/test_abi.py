@@ -38,7 +38,7 @@ def test_header_symbols_exported_and_bound():
 def test_struct_layouts_match_header():
     from physicsbasedfwi2_amd import _lib
     assert ctypes.sizeof(_lib.AcousticDesc) == 11 * 4
-    assert ctypes.sizeof(_lib.ElasticDesc) == 11 * 4
+    assert ctypes.sizeof(_lib.ElasticDesc) == 12 * 4
     assert ctypes.sizeof(_lib.AcousticLayout) == 4 * 4 + 4 * 8
     assert ctypes.sizeof(_lib.ElasticLayout) == 4 * 4 + 4 * 8
 

@@ -244,3 +244,14 @@ def test_denise_point_force_and_adjoint_source_components(oracle32, tmp_path, mo
     d.QUELLTYPB = 4
     with pytest.raises(Exception, match="QUELLTYPB"):
         d.grad(model, src, rec)
+    # pressure seismograms and pressure adjoint sources (SEISMO 4, QUELLTYPB 4); the velocities do not change
+    d.QUELLTYP, d.SEISMO = 1, 4
+    px_, py_ = d.forward(model, src, rec)
+    assert np.array_equal(px_, ex) and np.array_equal(py_, ey)
+    sp = np.stack(d.get_shots(keys=["_p"]))
+    assert sp.shape == ey.shape and np.abs(sp).max() > 0
+    d.set_observed(np.transpose(ex, (0, 2, 1)), np.transpose(ey, (0, 2, 1)), p=0.7 * np.transpose(sp, (0, 2, 1)))
+    lp = d.grad(model, src, rec)
+    assert abs(lp - 0.5 * 0.09 * float((sp.astype(np.float64) ** 2).sum())) <= 1e-4 * lp
+    gp = d.get_fwi_gradients(["seis"])
+    assert all(np.isfinite(a).all() for a in gp) and np.abs(gp[1]).max() > 0

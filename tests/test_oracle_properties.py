@@ -305,3 +305,33 @@ def test_elastic_force_sources_adjoint_is_exact(oracle64, source_type, free_surf
     _, gq = o.elastic_backward(c["mat"], c["pz"], c["px"], *geo, dx, dz, S2, **kw)
     lhs, rhs = np.sum(a * dx) + np.sum(b * dz), np.sum(q * gq)
     assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
+
+
+def test_elastic_pressure_receivers_adjoint_is_exact(oracle64):
+    """Pressure seismograms (DENISE SEISMO 2 / 4): sum w (sxx + szz) after the stress update; dot-product
+    identity of the source -> (vx, vz, p) map and a second-order Taylor remainder with p in the objective."""
+    o = oracle64
+    c = elastic_case(seed=17, nsrc=2, free_surface=True)
+    geo = (c["sc"], c["sw"], c["rc"], c["rw"])
+    rng = np.random.default_rng(6)
+    vx, vz, S, p = o.elastic_forward(c["mat"], c["pz"], c["px"], c["f"], *geo, save=True, free_surface=1,
+                                     pressure=True)
+    assert np.abs(p).max() > 0
+    op = p + rng.standard_normal(p.shape) * 0.3 * np.abs(p).max()
+    gm, gf = o.elastic_backward(c["mat"], c["pz"], c["px"], *geo, np.zeros_like(vx), np.zeros_like(vz), S,
+                                free_surface=1, g_p=p - op)
+    dm = rng.standard_normal(c["mat"].shape) * c["mat"] * 0.02
+    df = rng.standard_normal(c["f"].shape) * np.abs(c["f"]).max() * 0.05
+
+    def J(h):
+        q = o.elastic_forward(c["mat"] + h * dm, c["pz"], c["px"], c["f"] + h * df, *geo, free_surface=1,
+                              pressure=True)[2]
+        return 0.5 * np.sum((q - op) ** 2)
+    _, p2 = _taylor(J, np.sum(gm * dm) + np.sum(gf * df), [1e-2, 1e-3, 1e-4])
+    assert abs(p2 - 2.0) < 0.02
+    q = rng.standard_normal(c["f"].shape)
+    a, b, S2, pp = o.elastic_forward(c["mat"], c["pz"], c["px"], q, *geo, save=True, free_surface=1, pressure=True)
+    dx, dz, dp = (rng.standard_normal(a.shape) for _ in range(3))
+    _, gq = o.elastic_backward(c["mat"], c["pz"], c["px"], *geo, dx, dz, S2, free_surface=1, g_p=dp)
+    lhs, rhs = np.sum(a * dx) + np.sum(b * dz) + np.sum(pp * dp), np.sum(q * gq)
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
