@@ -404,6 +404,17 @@ def run_workload(name, args, dev, rank, world, want_cpu):
                      "traffic": traffic},
         "kernels": kern,
     }
+    try:                       # record the device and its clocks next to the numbers
+        pr = torch.cuda.get_device_properties(dev)
+        import ctypes
+        from physicsbasedfwi2_amd import _lib
+        clk = [ctypes.c_int32(0) for _ in range(3)]
+        _lib.check(_lib.load().mifwi_device_info(dev.index or 0, *[ctypes.byref(c) for c in clk]))
+        out["device"] = {"name": pr.name, "arch": getattr(pr, "gcnArchName", ""), "cus": clk[2].value,
+                         "sclk_mhz": clk[0].value / 1e3, "mclk_mhz": clk[1].value / 1e3,
+                         "hbm_gib": round(pr.total_memory / 2 ** 30, 1)}
+    except Exception as exc:   # noqa: BLE001 - reporting only
+        out["device"] = {"error": str(exc)}
     if want_cpu:
         out["cpu_baseline"] = wl.cpu_baseline()
     del wl

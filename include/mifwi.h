@@ -43,6 +43,8 @@ enum {
 const char *mifwi_last_error(void);
 int mifwi_version(void);                 /* major*1000 + minor                  */
 int mifwi_device_count(void);            /* number of visible HIP devices, >=0  */
+/* engine / memory clock (kHz) and compute units of a device, for measurement reports; 0 where unknown */
+int mifwi_device_info(int device, int32_t *sclk_khz, int32_t *mclk_khz, int32_t *compute_units);
 
 /* ======================================================================================
  * 2-D constant-density ACOUSTIC propagator (forward + exact discrete adjoint)

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mifwi_last_error": (ctypes.c_char_p, []),
     "mifwi_version": (ctypes.c_int, []),
     "mifwi_device_count": (ctypes.c_int, []),
+    "mifwi_device_info": (ctypes.c_int, [ctypes.c_int, _P, _P, _P]),
     "mifwi_acoustic_plan_create": (ctypes.c_int, [ctypes.POINTER(_P), ctypes.c_int,
                                                   ctypes.POINTER(AcousticDesc)]),
     "mifwi_acoustic_plan_destroy": (ctypes.c_int, [_P]),

@@ -1128,6 +1128,19 @@ int mifwi_device_count(void)
     return n;
 }
 
+int mifwi_device_info(int device, int32_t *sclk_khz, int32_t *mclk_khz, int32_t *compute_units)
+{
+    int rc = mifwi::check_device(device);
+    if (rc) return rc;
+    int v = 0;
+    if (sclk_khz) *sclk_khz = hipDeviceGetAttribute(&v, hipDeviceAttributeClockRate, device) == hipSuccess ? v : 0;
+    if (mclk_khz) *mclk_khz = hipDeviceGetAttribute(&v, hipDeviceAttributeMemoryClockRate, device) == hipSuccess ? v : 0;
+    if (compute_units)
+        *compute_units = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess ? v : 0;
+    (void)hipGetLastError();
+    return MIFWI_OK;
+}
+
 int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
                                const mifwi_acoustic_desc *d)
 {
