@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/ab_seam.sh "ENV=.. ENV=.." ...   - times the SEAM-sized elastic workload once per environment string
+# usage: tools/ab_bench.sh "ENV=.. ENV=.." ...   - times one bench workload (WL, GRID, SHOTS, NT from the environment; default: the SEAM-sized elastic one) once per environment string
 # the first run on a fresh box is 2-3 % slow (clocks, cold caches): one throw-away run first
 timeout -k 10 200 python bench.py --workload ${WL:-elastic_seam} ${GRID:+--grid $GRID} --nt 20 ${SHOTS:+--shots $SHOTS} --steps 2 --warmup 1 --no-cpu-baseline --no-also > /dev/null 2>&1
 i=0

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/prof_seam.sh "ENV=.." ...  - rocprofv3 kernel stats of the SEAM-sized elastic workload per environment string
+# usage: tools/prof_bench.sh "ENV=.." ...  - rocprofv3 kernel stats of one bench workload (WL, GRID, SHOTS, NT) per environment string
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 for E in "$@"; do i=$((i+1)); export $E; rm -rf gpurun_out/prof_$i
