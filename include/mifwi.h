@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define MIFWI_VERSION_MAJOR 0
-#define MIFWI_VERSION_MINOR 1
+#define MIFWI_VERSION_MINOR 2   /* 2: elastic desc gained source_type, record_pressure; bind_pressure, device_info */
 
 enum {
     MIFWI_OK = 0,
