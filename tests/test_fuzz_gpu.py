@@ -1,0 +1,99 @@
+"""Seeded sweep over small random configurations of the elastic path (grid sizes off the tile sizes, C-PML width,
+free surface, source type, pressure receivers, shots per accumulator group, forced shot passes, both kernel
+families): seismograms and every gradient against oracle/elastic.c."""
+import numpy as np
+import pytest
+import torch
+
+from cases import acoustic_case, elastic_case, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _configs():
+    rng = np.random.default_rng(2026)
+    out = []
+    for k in range(14):
+        fs = bool(rng.integers(0, 2))
+        cfg = dict(nz=int(rng.integers(34, 75)), nx=int(rng.integers(40, 140)), fw=int(rng.choice([0, 5, 8])),
+                   ns=int(rng.integers(1, 6)), nsrc=int(rng.integers(1, 3)), nrec=int(rng.integers(1, 20)),
+                   nt=int(rng.integers(20, 70)), free_surface=fs, water=int(rng.choice([0, 6])))
+        opt = dict(source_type=int(rng.integers(0, 3)), pressure=bool(rng.integers(0, 2)),
+                   gs=int(rng.integers(0, 4)), cluster=str(int(rng.integers(0, 2))),
+                   pass_shots=str(int(rng.integers(1, 4))), pass_groups=str(int(rng.integers(1, 3))))
+        out.append((k, cfg, opt))
+    return out
+
+
+@pytest.mark.parametrize("k,cfg,opt", _configs())
+def test_random_elastic_configuration(oracle32, monkeypatch, k, cfg, opt):
+    from physicsbasedfwi2_amd import elastic
+    monkeypatch.setenv("MIFWI_EL_CLUSTER", opt["cluster"])
+    monkeypatch.setenv("MIFWI_EL_CLUSTER_ADJ", opt["cluster"])
+    monkeypatch.setenv("MIFWI_EL_PASS_SHOTS", opt["pass_shots"])
+    monkeypatch.setenv("MIFWI_EL_PASS_GROUPS", opt["pass_groups"])
+    case = elastic_case(seed=100 + k, **cfg)
+    if opt["source_type"]:
+        case["f"] = (case["f"] * 1e-3).astype(np.float32)
+    o, fs, st = oracle32, case["fs"], opt["source_type"]
+    geo = (case["sc"], case["sw"], case["rc"], case["rw"])
+    res = o.elastic_forward(case["mat"], case["pz"], case["px"], case["f"], *geo, save=True, free_surface=fs,
+                            source_type=st, pressure=opt["pressure"])
+    ovx, ovz, S = res[:3]
+    mat = torch.tensor(case["mat"], dtype=torch.float32, device=DEV, requires_grad=True)
+    f = torch.tensor(case["f"], dtype=torch.float32, device=DEV, requires_grad=True)
+    tg = [torch.tensor(case[n]) for n in ("pz", "px", "sc", "sw", "rc", "rw")]
+    out = elastic.propagate(mat, f, *tg, case["fw"], shots_per_group=opt["gs"], free_surface=bool(fs),
+                            source_type=st, record_pressure=opt["pressure"])
+    scale = max(np.abs(ovx).max(), np.abs(ovz).max())
+    assert scale > 0
+    for h, r in zip(out, res[:2] + ((res[3],) if opt["pressure"] else ())):
+        assert np.abs(h.detach().cpu().numpy() - r).max() <= 2e-5 * max(scale, np.abs(r).max())
+    rng = np.random.default_rng(k)
+    gs_ = [(rng.standard_normal(r.shape) * scale).astype(np.float32) for r in (ovx, ovz)]
+    gp = (rng.standard_normal(ovx.shape) * scale).astype(np.float32) if opt["pressure"] else None
+    torch.autograd.backward(list(out), [torch.tensor(g, device=DEV) for g in gs_ + ([gp] if gp is not None else [])])
+    gm_o, gf_o = o.elastic_backward(case["mat"], case["pz"], case["px"], *geo, gs_[0], gs_[1], S, free_surface=fs,
+                                    source_type=st, g_p=gp)
+    for j in range(5):
+        assert rel_l2(mat.grad[j].cpu().numpy(), gm_o[j]) <= 5e-5, (j, cfg, opt)
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 5e-5, (cfg, opt)
+
+
+def _acoustic_configs():
+    rng = np.random.default_rng(2027)
+    out = []
+    for k in range(12):
+        cfg = dict(n0=int(rng.integers(30, 90)), n1=int(rng.integers(36, 150)), nb=int(rng.choice([4, 8, 12])),
+                   ns=int(rng.integers(1, 7)), nsrc=int(rng.integers(1, 3)), nrec=int(rng.integers(1, 25)),
+                   nt=int(rng.integers(20, 80)), ntap=int(rng.choice([1, 1, 4])),
+                   h=(10.0, float(rng.choice([10.0, 12.5]))))
+        opt = dict(gs=int(rng.integers(0, 4)), cluster=str(int(rng.integers(0, 2))),
+                   groups=str(int(rng.integers(1, 3))), nw=str(int(rng.choice([0, 0, 2, 3]))))
+        out.append((k, cfg, opt))
+    return out
+
+
+@pytest.mark.parametrize("k,cfg,opt", _acoustic_configs())
+def test_random_acoustic_configuration(oracle32, monkeypatch, k, cfg, opt):
+    from physicsbasedfwi2_amd import acoustic
+    monkeypatch.setenv("MIFWI_AC_CLUSTER", opt["cluster"])
+    monkeypatch.setenv("MIFWI_AC_PASS_GROUPS", opt["groups"])
+    if opt["nw"] != "0":
+        monkeypatch.setenv("MIFWI_AC_NW", opt["nw"])
+    case = acoustic_case(seed=200 + k, **cfg)
+    o = oracle32
+    geo = (case["sc"], case["sw"], case["rc"], case["rw"])
+    rec_o, G = o.acoustic_forward(case["r"], case["q0"], case["q1"], case["f"], *geo, case["c0"], case["c1"], save=True)
+    r = torch.tensor(case["r"], dtype=torch.float32, device=DEV, requires_grad=True)
+    f = torch.tensor(case["f"], dtype=torch.float32, device=DEV, requires_grad=True)
+    rec = acoustic.propagate(r, f, torch.tensor(case["q0"]), torch.tensor(case["q1"]),
+                             *[torch.tensor(a) for a in geo], case["c0"], case["c1"], shots_per_group=opt["gs"])
+    scale = np.abs(rec_o).max()
+    assert scale > 0 and np.abs(rec.detach().cpu().numpy() - rec_o).max() <= 2e-5 * scale
+    g = (np.random.default_rng(k).standard_normal(rec_o.shape) * scale).astype(np.float32)
+    rec.backward(torch.tensor(g, device=DEV))
+    gr_o, gf_o = o.acoustic_backward(case["r"], case["q0"], case["q1"], *geo, g, G, case["c0"], case["c1"])
+    assert rel_l2(r.grad.cpu().numpy(), gr_o) <= 5e-5, (cfg, opt)
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 5e-5, (cfg, opt)
