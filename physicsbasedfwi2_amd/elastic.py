@@ -122,6 +122,9 @@ class _ElasticFn(torch.autograd.Function):
             step_bytes = 4 * 5 * ns * lay.coef_elems
             seg, snap, ckpt = nt, None, None
             if need_grad:
+                # never plan for more than most of the memory that is free right now (other tensors of
+                # the training loop share the device); segmentation does not change the results
+                snapshot_budget = min(snapshot_budget, int(0.8 * torch.cuda.mem_get_info(dev)[0]))
                 if nt * step_bytes > snapshot_budget:
                     seg = max(1, int(snapshot_budget // (2 * step_bytes)))
                 if seg >= nt:
