@@ -582,11 +582,16 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     // injected by me (slab list); source sampled by me for grad_f.
     int src_slot = -1, src_comp = 0, src_e = -1;        // forward injection (owner side)
     float src_wt = 0.f;
-    int smp_off = -1, smp_e = -1;                        // sampling of `cur`
+    int smp_off = -1;                                    // sampling of `cur` (point index = t)
     float smp_w = 0.f;
-    int inj_off = -1, inj_id = -1;                       // adjoint injection into LDS
-    bool inj_edge = false;
+    // adjoint injection into LDS: LDS offset (18 bits) | receiver id (12 bits, fast variant: nrec <= 1024) |
+    // "lies in a row the neighbours wait for" (bit 30), one register instead of three; -1 = none
+    int inj_pack = -1;
     float inj_scale = 0.f;
+    // unpacked from an opaque copy at every use: a hoisted field would take a register of its own again
+    auto inj_off = [&]() { return cl_opaque(inj_pack) & 0x3ffff; };
+    auto inj_id = [&]() { return (cl_opaque(inj_pack) >> 18) & 0xfff; };
+    auto inj_edge = [&]() { return (inj_pack >> 30) != 0; };
     constexpr bool slow_sparse = SLOW;                   // more points than one per thread: rescan per step
     if (!adj) {
         for (int e = 0; e < p.nsrc; ++e) {
@@ -604,7 +609,6 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         }
         if (p.rec_out != nullptr && t < p.nrec) {
             const int cell = p.rec_cell[(long long)s * p.nrec + t];
-            smp_e = t;
             if (cell >= 0) {
                 const int i0 = cell / p.n1, i1 = cell - i0 * p.n1;
                 if (i0 >= r0 && i0 < r0 + R) {
@@ -624,15 +628,13 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             const float rv = p.r[(long long)i0 * p.gp + i1];
             const float q = p.q0[i0] + p.q1[i1];
             const float inv = 1.0f / (1.0f + q * rv);
-            inj_off = (i0 - r0 + 2) * PL + 4 + i1;
-            inj_edge = (i0 - r0 < 2) || (i0 - r0 >= R - 2);       // lies in a row the neighbours wait for
-            inj_id = id;
+            const bool edge = (i0 - r0 < 2) || (i0 - r0 >= R - 2);
+            inj_pack = ((i0 - r0 + 2) * PL + 4 + i1) | ((id & 0xfff) << 18) | (edge ? (1 << 30) : 0);
             inj_scale = rv * inv;
             smp_w = p.rec_w[(long long)s * p.nrec + id];          // reused as the tap weight
         }
         if (p.grad_f != nullptr && t < p.nsrc) {
             const int cell = p.src_cell[(long long)s * p.nsrc + t];
-            smp_e = t;
             if (cell >= 0) {
                 const int i0 = cell / p.n1, i1 = cell - i0 * p.n1;
                 if (i0 >= r0 && i0 < r0 + R) {
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     // adjoint: the same, once the receivers that sit IN the boundary rows have been injected (the other
     // receivers are injected after the interior slots, as before)
     const bool early_adj = adj && do_x && 4 * p.ng <= kClThreads && !slow_sparse;
-    const bool edge_recv_any = early_adj && __syncthreads_or((inj_off >= 0 && inj_edge) ? 1 : 0) != 0;
+    const bool edge_recv_any = early_adj && __syncthreads_or((inj_pack >= 0 && inj_edge()) ? 1 : 0) != 0;
 
     // software prefetch of the next step's global operands (issued before this step's stores, so
     // that they do not queue behind them): source / adjoint-source amplitude and, in the adjoint,
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         if (!adj) {
             if (src_slot >= 0) amp_next = (p.f + ((long long)n_ * p.nshot + s) * p.nsrc)[cl_opaque(src_e)];
         } else {
-            if (inj_off >= 0) amp_next = (p.grad_rec + ((long long)n_ * p.nshot + s) * p.nrec)[cl_opaque(inj_id)];
+            if (inj_pack >= 0) amp_next = (p.grad_rec + ((long long)n_ * p.nshot + s) * p.nrec)[inj_id()];
         }
         if (adj || MODE == 3) {
             // adjoint: G^{n-1} for the imaging condition; Born: G^n, the source term of this step
@@ -737,8 +739,8 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             // uniform row base + a 32-bit lane offset: no per-lane 64-bit address to keep (or spill)
             float *out_n = adj ? p.grad_f + ((long long)n * p.nshot + s) * p.nsrc
                                : p.rec_out + ((long long)n * p.nshot + s) * p.nrec;
-            if (smp_off >= 0) out_n[cl_opaque(smp_e)] = fmaf(adj ? src_wt : smp_w, cur[cl_opaque(smp_off)], 0.f);
-            else if (smp_off == -2) out_n[cl_opaque(smp_e)] = 0.f;
+            if (smp_off >= 0) out_n[cl_opaque(t)] = fmaf(adj ? src_wt : smp_w, cur[cl_opaque(smp_off)], 0.f);
+            else if (smp_off == -2) out_n[cl_opaque(t)] = 0.f;
         } else if (!adj) {
             if (p.rec_out != nullptr)
                 for (int e = t; e < p.nrec; e += kClThreads) {
@@ -820,7 +822,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 // travels while the interior (slots 1..) is computed
                 __syncthreads();
                 if (edge_recv_any) {             // workgroup-uniform
-                    if (inj_off >= 0 && inj_edge) atomicAdd(&prv[cl_opaque(inj_off)], (smp_w * amp) * inj_scale);
+                    if (inj_pack >= 0 && inj_edge()) atomicAdd(&prv[inj_off()], (smp_w * amp) * inj_scale);
                     __syncthreads();
                 }
 #pragma unroll
@@ -835,8 +837,8 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         if (adj) {
             // ---- adjoint sources: receiver taps of this slab, z^k[cell] += (w g) (r inv) -------
             if (!slow_sparse) {
-                if (inj_off >= 0 && !(early_adj && inj_edge))
-                    atomicAdd(&prv[cl_opaque(inj_off)], (smp_w * amp) * inj_scale);
+                if (inj_pack >= 0 && !(early_adj && inj_edge()))
+                    atomicAdd(&prv[inj_off()], (smp_w * amp) * inj_scale);
             } else {
                 const int cnt = p.slab_cnt[s * p.NW + w];
                 const int *lst = p.slab_list + ((long long)s * p.NW + w) * p.nrec;
