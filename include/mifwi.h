@@ -91,6 +91,8 @@ typedef struct {
 } mifwi_acoustic_layout;
 
 int mifwi_acoustic_plan_layout(const mifwi_acoustic_plan *plan, mifwi_acoustic_layout *out);
+/* Shot groups per pass of the per-step kernels (forward, adjoint); introspection only. */
+int mifwi_acoustic_plan_pass_sizes(const mifwi_acoustic_plan *plan, int32_t *forward_groups, int32_t *adjoint_groups);
 
 /* flags for the time-range calls */
 #define MIFWI_ZERO_STATE 1   /* zero the wavefield state (and accumulators) in `work` first   */
@@ -186,6 +188,9 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device,
                               const mifwi_elastic_desc *desc);
 int mifwi_elastic_plan_destroy(mifwi_elastic_plan *plan);
 int mifwi_elastic_plan_layout(const mifwi_elastic_plan *plan, mifwi_elastic_layout *out);
+/* How the per-step kernels of this plan sweep the time range: shots per forward pass, shot groups per adjoint
+ * pass (Infinity Cache residency; nshot / ngroups when everything fits or nothing does).  Introspection only. */
+int mifwi_elastic_plan_pass_sizes(const mifwi_elastic_plan *plan, int32_t *forward_shots, int32_t *adjoint_groups);
 
 /* Pressure receivers of a plan created with record_pressure = 1 (same cells and weights as the velocity
  * receivers).  The buffers stay bound to the plan until the next call of this function:

@@ -70,6 +70,8 @@ SIGNATURES = {
     "mifwi_elastic_plan_destroy": (ctypes.c_int, [_P]),
     "mifwi_elastic_plan_layout": (ctypes.c_int, [_P, ctypes.POINTER(ElasticLayout)]),
     "mifwi_elastic_plan_bind_pressure": (ctypes.c_int, [_P, _P, _P]),
+    "mifwi_elastic_plan_pass_sizes": (ctypes.c_int, [_P, _P, _P]),
+    "mifwi_acoustic_plan_pass_sizes": (ctypes.c_int, [_P, _P, _P]),
     "mifwi_elastic_forward": (ctypes.c_int, [_P] * 13 + [ctypes.c_int32] * 3 + [_P]),
     "mifwi_elastic_backward": (ctypes.c_int, [_P] * 11 + [ctypes.c_int32] + [_P] * 3 +
                                [ctypes.c_int32] * 3 + [_P]),

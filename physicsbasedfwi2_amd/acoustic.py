@@ -35,6 +35,13 @@ class AcousticPlan:
     def handle(self):
         return self._h
 
+    def pass_sizes(self):
+        """(forward, adjoint) units per pass of the per-step kernels over the time range: shots / shot groups
+        (elastic), shot groups (acoustic) - what stays inside the Infinity Cache."""
+        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.check(self._lib.mifwi_acoustic_plan_pass_sizes(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def cluster_slabs(self, adjoint=False):
         """Row slabs per shot of the single-launch time loop (0: one launch per step)."""
         return int(self._lib.mifwi_acoustic_plan_cluster_slabs(self._h, int(bool(adjoint))))

@@ -1209,6 +1209,14 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
     return MIFWI_OK;
 }
 
+int mifwi_acoustic_plan_pass_sizes(const mifwi_acoustic_plan *plan, int32_t *forward_groups, int32_t *adjoint_groups)
+{
+    if (!plan) return mifwi::fail(MIFWI_EINVAL, "null plan");
+    if (forward_groups) *forward_groups = plan->pass_fwd;
+    if (adjoint_groups) *adjoint_groups = plan->pass_adj;
+    return MIFWI_OK;
+}
+
 int mifwi_acoustic_plan_cluster_slabs(const mifwi_acoustic_plan *plan, int32_t adjoint)
 {
     (void)adjoint;                       // one slab count serves both loops

@@ -1513,6 +1513,14 @@ int mifwi_elastic_plan_cluster_slabs(const mifwi_elastic_plan *plan, int32_t adj
     return adjoint ? (plan->cl_adj ? plan->adj_NW : 0) : (plan->cluster ? plan->NW : 0);
 }
 
+int mifwi_elastic_plan_pass_sizes(const mifwi_elastic_plan *plan, int32_t *forward_shots, int32_t *adjoint_groups)
+{
+    if (!plan) return mifwi::fail(MIFWI_EINVAL, "null plan");
+    if (forward_shots) *forward_shots = plan->pass_shots;
+    if (adjoint_groups) *adjoint_groups = plan->pass_groups;
+    return MIFWI_OK;
+}
+
 int mifwi_elastic_plan_bind_pressure(mifwi_elastic_plan *plan, float *rec_p, const float *g_p)
 {
     if (!plan) return mifwi::fail(MIFWI_EINVAL, "null plan");

@@ -268,3 +268,22 @@ def test_passes_over_shot_subsets_change_nothing(monkeypatch):
     for other in outs[1:]:
         for x, y in zip(outs[0], other):
             assert torch.equal(x, y)
+
+
+def test_large_grids_sweep_the_time_range_a_few_shots_at_a_time():
+    """Plans (no memory is allocated) for the SEAM-sized elastic grid and a large acoustic grid split their
+    16 shots into Infinity-Cache-sized passes; grids whose shots all fit take them in one pass."""
+    from physicsbasedfwi2_amd.acoustic import AcousticPlan
+    from physicsbasedfwi2_amd.elastic import ElasticPlan
+    pl = ElasticPlan(1000, 3000, 100, 16, 1, 300, 1, 10, 0)
+    assert pl.cluster_slabs(False) == 0 and pl.cluster_slabs(True) == 0
+    fwd, adj = pl.pass_sizes()
+    assert fwd == 3 and adj == 1 and pl.layout.shots_per_group == 2      # 3 x 60 MB state + 60 MB materials
+    small = ElasticPlan(350, 1700, 100, 8, 1, 300, 1, 10, 0)
+    assert small.pass_sizes() == (8, small.layout.ngroups) and small.layout.shots_per_group == 4
+    big_ac = AcousticPlan(1040, 3040, 100, 16, 1, 3000, 1, 1.0, 1.0, 0)
+    assert big_ac.cluster_slabs() == 0
+    f_ac, a_ac = big_ac.pass_sizes()
+    assert 1 <= a_ac <= f_ac < big_ac.layout.ngroups
+    c2 = AcousticPlan(214, 540, 100, 29, 1, 500, 1, 1.0, 1.0, 0)
+    assert c2.pass_sizes() == (c2.layout.ngroups, c2.layout.ngroups)
