@@ -1191,19 +1191,20 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
     {
         // Infinity Cache residency of the per-step family (same rule as the elastic plan): a pass over the time
         // range takes the shot groups whose wavefields (+ accumulators) fit 250 MB together with the model
-        constexpr double kResident = 250e6;
+        // forward: 200 MB (1000x3000, 2-shot groups: 3 groups = 165 MB run 126 us per step on every box tried,
+        // 4 groups = 216 MB between 119 and 141 us, all 8 groups 165-200 us); adjoint: 250 MB as in the elastic plan
         const double model = 4.0 * (double)pl->coef_elems;
         const double gstate = 4.0 * 2.0 * (double)pl->shot_stride * pl->gs;
-        auto fit = [&](double per_group) {
+        auto fit = [&](double per_group, double resident) {
             int k = pl->ngroups;
-            if (pl->ngroups * per_group + model > kResident) {
-                k = (int)std::floor((kResident - model) / per_group);
+            if (pl->ngroups * per_group + model > resident) {
+                k = (int)std::floor((resident - model) / per_group);
                 if (k < 1) k = pl->ngroups;
             }
             return k;
         };
-        pl->pass_fwd = std::min(pl->ngroups, std::max(1, env_int("MIFWI_AC_PASS_GROUPS", fit(gstate))));
-        pl->pass_adj = std::min(pl->ngroups, std::max(1, env_int("MIFWI_AC_PASS_GROUPS", fit(gstate + model))));
+        pl->pass_fwd = std::min(pl->ngroups, std::max(1, env_int("MIFWI_AC_PASS_GROUPS", fit(gstate, 200e6))));
+        pl->pass_adj = std::min(pl->ngroups, std::max(1, env_int("MIFWI_AC_PASS_GROUPS", fit(gstate + model, 250e6))));
     }
     *plan = pl;
     return MIFWI_OK;
