@@ -278,7 +278,7 @@ def test_large_grids_sweep_the_time_range_a_few_shots_at_a_time():
     pl = ElasticPlan(1000, 3000, 100, 16, 1, 300, 1, 10, 0)
     assert pl.cluster_slabs(False) == 0 and pl.cluster_slabs(True) == 0
     fwd, adj = pl.pass_sizes()
-    assert fwd == 3 and adj == 1 and pl.layout.shots_per_group == 2      # 3 x 60 MB state + 60 MB materials
+    assert fwd == 2 and adj == 1 and pl.layout.shots_per_group == 2      # 2 x 60 MB state + 60 MB materials
     small = ElasticPlan(350, 1700, 100, 8, 1, 300, 1, 10, 0)
     assert small.pass_sizes() == (8, small.layout.ngroups) and small.layout.shots_per_group == 4
     big_ac = AcousticPlan(1040, 3040, 100, 16, 1, 3000, 1, 1.0, 1.0, 0)
