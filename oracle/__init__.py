@@ -123,6 +123,50 @@ class Oracle:
         return grad_r, grad_f
 
 
+def _acoustic_forward_order(self, order, r, q0, q1, f, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
+                            save_u=False):
+    """Forward modelling with a space-order-`order` Laplacian (2..20, Devito's Taylor weights);
+    returns rec [nt,ns,nrec] (and U [nt,ns,n0,n1] = u^n when save_u).  Reference runs only."""
+    r = self._r(r); q0 = self._r(q0); q1 = self._r(q1); f = self._r(f)
+    src_cell = self._i(src_cell); rec_cell = self._i(rec_cell)
+    src_w = self._r(src_w); rec_w = self._r(rec_w)
+    n0, n1 = r.shape
+    nt, ns, nsrc = f.shape
+    nrec, ntap = rec_cell.shape[1], rec_cell.shape[2]
+    cfg = self.AcCfg(n0, n1, nt, ns, nsrc, nrec, ntap, c0, c1)
+    rec = np.zeros((nt, ns, nrec), dtype=self.dtype)
+    U = np.zeros((nt, ns, n0, n1), dtype=self.dtype) if save_u else None
+    st = self.lib.oracle_acoustic_forward_order(ctypes.byref(cfg), int(order), self._p(r), self._p(q0),
+                                                self._p(q1), self._p(f), self._p(src_cell), self._p(src_w),
+                                                self._p(rec_cell), self._p(rec_w), self._p(rec), self._p(U))
+    if st != 0:
+        raise RuntimeError("oracle_acoustic_forward_order failed (%d)" % st)
+    return (rec, U) if save_u else rec
+
+
+def _acoustic_gradient_devito(self, r, q0, q1, rec_cell, rec_w, res, U_dev, s, h, c0=1.0, c1=1.0):
+    """Devito's `grad -= u.dt2 * v` (operators.py:127-165) in Devito's time indexing: res [nt,ns,nrec]
+    is the residual at Devito time index, U_dev [nt,ns,n0,n1] Devito's saved u[time].  Returns the
+    gradient w.r.t. square slowness on the padded grid, summed over shots."""
+    r = self._r(r); q0 = self._r(q0); q1 = self._r(q1); res = self._r(res); U_dev = self._r(U_dev)
+    rec_cell = self._i(rec_cell); rec_w = self._r(rec_w)
+    n0, n1 = r.shape
+    nt, ns, nrec = res.shape
+    ntap = rec_cell.shape[2]
+    cfg = self.AcCfg(n0, n1, nt, ns, 0, nrec, ntap, c0, c1)
+    grad = np.zeros((n0, n1), dtype=self.dtype)
+    st = self.lib.oracle_acoustic_gradient_devito(ctypes.byref(cfg), self._p(r), self._p(q0), self._p(q1),
+                                                  self._p(rec_cell), self._p(rec_w), self._p(res),
+                                                  self._p(U_dev), self.creal(s), self.creal(h), self._p(grad))
+    if st != 0:
+        raise MemoryError("oracle_acoustic_gradient_devito failed")
+    return grad
+
+
+Oracle.acoustic_forward_order = _acoustic_forward_order
+Oracle.acoustic_gradient_devito = _acoustic_gradient_devito
+
+
 def _el_cfg():
     class ElCfg(ctypes.Structure):
         _fields_ = [("nz", ctypes.c_int), ("nx", ctypes.c_int), ("nt", ctypes.c_int),

@@ -15,15 +15,20 @@
  *   - receiver     rec[t] = sum_taps w * u[t][x]          : operators.py:85
  *   - adjoint time stepping with the damping sign flipped : operators.py:41-47,113
  *   - imaging condition (model gradient)                  : operators.py:152-153
- *     -- restated here as the EXACT discrete adjoint of the forward recursion
- *        (Devito's `grad -= u.dt2*v` is its one-step-shifted approximation).
+ *     -- restated here as the EXACT discrete adjoint of the forward recursion in the
+ *        variable r; Devito's `grad -= u.dt2*v` is the same gradient expressed in m
+ *        (oracle_acoustic_gradient_devito below evaluates it literally; the two agree to
+ *        round-off, tests/test_reference_pins.py).
  *
  * Parity status: the third-party arithmetic (Devito ~3.x / deepwave <=0.0.9) is
  * absent from /root/reference and from this image, so PARITY WITH THOSE PACKAGES
  * IS UNPINNED.  What is pinned: the numpy helpers of seisgan (damping profile,
- * Ricker, critical_dt, TimeAxis: tests/golden/seisgan_helpers.npz), the
- * analytical 2-D Green's function (accuracy.ipynb cell 9) and the Taylor
- * gradient criterion (gradient_example.py:143-146).
+ * Ricker, critical_dt, TimeAxis: tests/golden/seisgan_helpers.npz), the published
+ * numbers of accuracy.ipynb reproduced with the notebook's own order-20 reference run
+ * (RMS vs the analytical Green's function to 1.7 %, the space-order table to 0.2 %, the
+ * time-convergence errors to 2-6 %), Devito's imaging condition evaluated literally
+ * (equal to this file's gradient to round-off) and the Taylor gradient criterion
+ * (gradient_example.py:143-146) - tests/test_reference_pins.py.
  *
  * Parametrisation (one kernel serves the seisgan- and the deepwave-shaped API):
  *   r[i0][i1] = s^2 / (m h^2) = vp^2 dt^2 / h^2      (h = reference spacing)
@@ -273,6 +278,149 @@ int oracle_acoustic_born(const oracle_acoustic_cfg *c, const real *r, const real
         }
         free(ua); free(ub);
     }
+    return status;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Reference-literal pieces used ONLY to pin / bound the scheme above (never compared bitwise):
+ *
+ * (1) forward modelling with a space order 2M Laplacian (M = 1..10, Taylor weights as Devito's
+ *     `u.laplace` at space_order = 2M), optional save of every wavefield u^n.  accuracy.ipynb cells 7
+ *     and 14 use space_order=20 at h = 0.5 m as THE reference of the published space-order table.
+ * (2) Devito's imaging condition `grad -= u.dt2 * v` (operators.py:152-153) with the adjoint
+ *     recursion and receiver injection of operators.py:127-165 in Devito's own time indexing:
+ *        for time = nt-2 .. 1:  v[time-1]  = stencil(v[time], v[time+1])        (operators.py:144)
+ *                               v[time-1] += interp^T(res[time]) * s^2/m         (operators.py:155)
+ *                               grad      -= (u[time+1]-2u[time]+u[time-1])/s^2 * v[time]   (:147)
+ *     U_dev [nt][nshot][n0][n1] holds Devito's u[time] (= this file's u^{time-1}, u[0] = 0); the
+ *     gradient is with respect to the square slowness m on the padded grid, summed over shots
+ *     (layers.py:169-183 passes one `grad` Function to every shot).
+ * ---------------------------------------------------------------------------------------------- */
+static void fd2_weights(int M, double *c)       /* c[0..M]: centred 2nd-derivative weights, order 2M */
+{
+    double fM = 1.0;
+    for (int i = 2; i <= M; ++i) fM *= i;
+    c[0] = 0.0;
+    for (int k = 1; k <= M; ++k) {
+        double a = 1.0, b = 1.0;                /* (M-k)!, (M+k)! */
+        for (int i = 2; i <= M - k; ++i) a *= i;
+        for (int i = 2; i <= M + k; ++i) b *= i;
+        c[k] = ((k & 1) ? 2.0 : -2.0) * fM * fM / ((double)k * k * a * b);
+        c[0] -= 2.0 * c[k];
+    }
+}
+
+int oracle_acoustic_forward_order(const oracle_acoustic_cfg *c, int order, const real *r, const real *q0,
+                                  const real *q1, const real *f, const int *src_cell, const real *src_w,
+                                  const int *rec_cell, const real *rec_w, real *rec_out, real *U)
+{
+    const int M = order / 2;
+    if (order < 2 || order > 20 || (order & 1)) return 2;
+    double w[11];
+    fd2_weights(M, w);
+    const int n0 = c->n0, n1 = c->n1, ns = c->nshot;
+    const size_t ncell = (size_t)n0 * n1;
+    const size_t p = (size_t)(n1 + 2 * M);
+    const size_t npad = (size_t)(n0 + 2 * M) * p;
+    int status = 0;
+#define PIX(i0, i1) ((size_t)((i0) + M) * p + (size_t)((i1) + M))
+#pragma omp parallel for schedule(dynamic)
+    for (int s = 0; s < ns; ++s) {
+        real *ua = (real *)calloc(npad, sizeof(real));
+        real *ub = (real *)calloc(npad, sizeof(real));
+        if (!ua || !ub) { status = 1; free(ua); free(ub); continue; }
+        real *ucur = ua, *uprev = ub;
+        for (int n = 0; n < c->nt; ++n) {
+            for (int ir = 0; ir < c->nrec; ++ir) {
+                real acc = 0;
+                for (int t = 0; t < c->ntap; ++t) {
+                    const size_t e = ((size_t)s * c->nrec + ir) * c->ntap + t;
+                    const int cell = rec_cell[e];
+                    if (cell >= 0) acc += rec_w[e] * ucur[PIX(cell / n1, cell % n1)];
+                }
+                rec_out[((size_t)n * ns + s) * c->nrec + ir] = acc;
+            }
+            if (U) {
+                real *Un = U + ((size_t)n * ns + s) * ncell;
+                for (int i0 = 0; i0 < n0; ++i0)
+                    for (int i1 = 0; i1 < n1; ++i1) Un[(size_t)i0 * n1 + i1] = ucur[PIX(i0, i1)];
+            }
+            for (int i0 = 0; i0 < n0; ++i0)
+                for (int i1 = 0; i1 < n1; ++i1) {
+                    const size_t k = PIX(i0, i1);
+                    const real uc = ucur[k];
+                    real l0 = (real)w[0] * uc, l1 = (real)w[0] * uc;
+                    for (int m = 1; m <= M; ++m) {
+                        l0 += (real)w[m] * (ucur[k - m * p] + ucur[k + m * p]);
+                        l1 += (real)w[m] * (ucur[k - m] + ucur[k + m]);
+                    }
+                    const real lap = c->c0 * l0 + c->c1 * l1;
+                    const real rr = r[(size_t)i0 * n1 + i1];
+                    const real qr = (q0[i0] + q1[i1]) * rr;
+                    uprev[k] = ((real)2 * uc - ((real)1 - qr) * uprev[k] + rr * lap) / ((real)1 + qr);
+                }
+            for (int is = 0; is < c->nsrc; ++is) {
+                const real amp = f[((size_t)n * ns + s) * c->nsrc + is];
+                for (int t = 0; t < c->ntap; ++t) {
+                    const size_t e = ((size_t)s * c->nsrc + is) * c->ntap + t;
+                    const int cell = src_cell[e];
+                    if (cell >= 0) uprev[PIX(cell / n1, cell % n1)] += src_w[e] * amp * r[cell];
+                }
+            }
+            real *tmp = ucur; ucur = uprev; uprev = tmp;
+        }
+        free(ua); free(ub);
+    }
+#undef PIX
+    return status;
+}
+
+int oracle_acoustic_gradient_devito(const oracle_acoustic_cfg *c, const real *r, const real *q0,
+                                    const real *q1, const int *rec_cell, const real *rec_w,
+                                    const real *res, const real *U_dev, real s, real h, real *grad_m)
+{
+    const int n0 = c->n0, n1 = c->n1, ns = c->nshot, nt = c->nt;
+    const size_t ncell = (size_t)n0 * n1;
+    const size_t npad = (size_t)(n0 + 2 * HALO) * (n1 + 2 * HALO);
+    real *acc_all = (real *)calloc(ncell * ns, sizeof(real));
+    if (!acc_all) return 1;
+    int status = 0;
+#pragma omp parallel for schedule(dynamic)
+    for (int sh = 0; sh < ns; ++sh) {
+        real *va = (real *)calloc(npad, sizeof(real));
+        real *vb = (real *)calloc(npad, sizeof(real));
+        if (!va || !vb) { status = 1; free(va); free(vb); continue; }
+        real *vcur = va, *vnext = vb;          /* v[time], v[time+1] */
+        real *acc = acc_all + (size_t)sh * ncell;
+        for (int time = nt - 2; time >= 1; --time) {
+            /* grad -= u.dt2[time] * v[time]   (reads v[time] only: order inside the iteration is free) */
+            const real *up = U_dev + ((size_t)(time + 1) * ns + sh) * ncell;
+            const real *u0 = U_dev + ((size_t)time * ns + sh) * ncell;
+            const real *um = U_dev + ((size_t)(time - 1) * ns + sh) * ncell;
+            for (int i0 = 0; i0 < n0; ++i0)
+                for (int i1 = 0; i1 < n1; ++i1) {
+                    const size_t ci = (size_t)i0 * n1 + i1;
+                    acc[ci] -= (up[ci] - (real)2 * u0[ci] + um[ci]) / (s * s) * vcur[pidx(c, i0, i1)];
+                }
+            step_shot(c, r, q0, q1, vcur, vnext, NULL);            /* vnext <- v[time-1] */
+            for (int ir = 0; ir < c->nrec; ++ir) {
+                const real gv = res[((size_t)time * ns + sh) * c->nrec + ir];
+                for (int t = 0; t < c->ntap; ++t) {
+                    const size_t e = ((size_t)sh * c->nrec + ir) * c->ntap + t;
+                    const int cell = rec_cell[e];
+                    if (cell >= 0) vnext[pidx(c, cell / n1, cell % n1)] += rec_w[e] * gv * (r[cell] * h * h);
+                }
+            }
+            real *tmp = vcur; vcur = vnext; vnext = tmp;
+        }
+        free(va); free(vb);
+    }
+    for (size_t ci = 0; ci < ncell; ++ci) {
+        real a = 0;
+        for (int sh = 0; sh < ns; ++sh) a += acc_all[(size_t)sh * ncell + ci];
+        grad_m[ci] = a;
+    }
+    free(acc_all);
     return status;
 }
 

@@ -12,8 +12,9 @@ literal ``int(nx/2)`` metres of line 89), receiver line of layers.py:137-142, bi
 operators with offset nbpml, Devito's time loop (time = 1..nt-2: src[time] -> u[time+1],
 rec[time] <- u[time]), objective 0.5||syn-obs||^2 summed over shots, gradient cropped to the
 physical domain and max-normalised in backward (layers.py:185-197).
-Deliberate difference: the model gradient is the exact discrete adjoint of the forward recursion
-(Devito's ``grad -= u.dt2*v`` is its one-step-shifted approximation, operators.py:152-153).
+The model gradient is the exact discrete adjoint of the forward recursion, which is what Devito's
+``grad -= u.dt2*v`` (operators.py:152-153) evaluates: the two agree to round-off on the whole padded grid
+(tests/test_reference_pins.py::test_devito_imaging_condition_is_the_exact_discrete_adjoint, fp64, 1e-11).
 """
 import numpy as np
 import torch

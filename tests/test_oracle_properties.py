@@ -41,8 +41,10 @@ def test_analytical_green_function_and_published_error_table(oracle64):
     err = {}
     for nn, h in ((201, 2.0), (161, 2.5), (101, 4.0)):
         err[h] = np.abs(_notebook_run(oracle64, nn, h) - U).max()
-        # the notebook measures against its own order-20 run, itself 1.3e-3 RMS off the analytical
-        assert abs(err[h] - published[h]) <= 0.2 * published[h], (h, err[h])
+        # the notebook measures against its own order-20 run, whose L-inf distance to the analytical solution
+        # is 7.83e-3 (reproduced in test_reference_pins.py, where the table itself is matched to 0.2 %): by
+        # the triangle inequality the error against the analytical solution is within that of the table
+        assert abs(err[h] - published[h]) <= 8e-3, (h, err[h])
     order = np.log(err[4.0] / err[2.0]) / np.log(2.0)
     assert 3.6 <= order <= 4.4            # notebook: observed order ~3.9
     assert err[2.0] / np.abs(U).max() < 0.02
