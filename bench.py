@@ -5,13 +5,26 @@
 
 A "step" is one full gradient evaluation over the rank's shots.  value = interior
 cells x time steps x shots (all ranks) / wall second, in Mcells*steps/s (BASELINE.json metric).
+Every rate in the line uses that one cell convention: INTERIOR cells of the physical grid (the
+acoustic kernels also update the 20-cell sponge around it; those cells are work, not units).
 Shots are independent => weak scaling: every rank runs the workload's per-GPU shot count and
 the only collective is one all-reduce of the model gradient (RCCL) inside the timed step.
 Inputs are synthetic and resident in HBM before timing starts.
+
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself, as child processes,
+before this process touches the GPU; under torchrun it is one of the ranks.
+
+Default invocation: headline = elastic Marmousi-II (BASELINE configs[2], the stencil the
+north-star roofline target is stated on); `also` = acoustic configs[1] and the elastic survey
+on the 10 m grid 350x1700 (per-step kernels, HBM-bound).
 """
 import argparse
+import contextlib
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_ROUND = "r02"      # profiles/<round>_pmc_traffic.json, profiles/<round>_latency_floor.json
 
 
 def sized_cpu_sample(run, nt0, nt_full, budget_s, bytes_per_step, mem_cap=6e9):
@@ -37,6 +51,48 @@ def sized_cpu_sample(run, nt0, nt_full, budget_s, bytes_per_step, mem_cap=6e9):
     return nt, reps, el
 
 
+def csrc_sha16():
+    """Fingerprint of the kernel sources: committed counter / ablation summaries are only quoted next to a
+    bench line while they describe the kernels that produced it."""
+    base = os.path.join(ROOT, "physicsbasedfwi2_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(base)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(base, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def _profile_record(fname, workload, kernel):
+    """Record of (workload, kernel) in a committed profiles/ summary, or (None, reason)."""
+    path = os.path.join(ROOT, "profiles", fname)
+    try:
+        with open(path) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return None, "no " + fname
+    if doc.get("csrc_sha16") != csrc_sha16():
+        return None, "%s describes other kernels (csrc %s, now %s)" % (fname, doc.get("csrc_sha16"), csrc_sha16())
+    rec = doc.get(workload, {}).get(kernel)
+    return (rec, doc.get("commit", "")) if rec else (None, "workload not in " + fname)
+
+
+def measured_traffic(workload, kernel):
+    """HBM bytes per interior cell-step of a time-loop kernel from the committed rocprofv3 PMC passes
+    (profiles/<round>_pmc_traffic.json, written by tools/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes).  (None, why) when no summary exists for the kernels as they are now."""
+    rec, tag = _profile_record(PROFILE_ROUND + "_pmc_traffic.json", workload, kernel)
+    return (rec["bytes_per_cell_step"], tag) if rec else (None, tag)
+
+
+def latency_floor(workload, kernel):
+    """Seconds per step of the single-launch kernel with hand-off waits and the snapshot stream ablated
+    (profiles/<round>_latency_floor.json, tools/latency_floor.py: a -DMIFWI_ABLATIONS build): what is left is
+    the chain of barrier-separated LDS phases, the bound of an LDS-resident time loop."""
+    rec, tag = _profile_record(PROFILE_ROUND + "_latency_floor.json", workload, kernel)
+    return (rec["floor_s_per_step"], tag) if rec else (None, tag)
+
+
 def synth_vp(nz, nx, seed, water_rows=26):
     """1500 + 2500 z/nz + Gaussian-smoothed (sigma=5) N(0,150^2), clipped to
     [1500,4500], water layer on top."""
@@ -49,6 +105,20 @@ def synth_vp(nz, nx, seed, water_rows=26):
     return vp.astype(np.float32)
 
 
+@contextlib.contextmanager
+def _env(**kw):
+    old = {k: os.environ.get(k) for k in kw}
+    os.environ.update({k: str(v) for k, v in kw.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 class AcousticMarmousi:
     """BASELINE.json configs[1]: 2-D acoustic Marmousi-like 174x500, 29 shots, 2000 steps,
     deepwave-shaped call protocol + the L1 trace-normalised misfit of networks.py:5467-5476."""
@@ -56,19 +126,23 @@ class AcousticMarmousi:
     nz, nx, h, dt, nt, freq = 174, 500, 10.0, 0.001, 2000, 8.0
     shots_per_gpu = 29
     pml = 20
-    fwd_bytes, adj_bytes = 16.0, 20.0          # SURVEY.md 8d algorithmic B / cell-step
+    fwd_bytes, adj_bytes = 16.0, 20.0          # SURVEY.md 8d algorithmic B / cell-step, one launch per step
+    # an LDS-resident time loop only has to move the snapshot stream (G^n, 4 B/cell-step out, 4 back in)
+    resident_fwd_bytes, resident_adj_bytes = 4.0, 4.0
 
     def __init__(self, dev, rank, world, nt=None, shots=None, grid=None):
         import torch
         import physicsbasedfwi2_amd.compat.deepwave as deepwave
         from physicsbasedfwi2_amd import misfit
         self.torch, self.deepwave, self.dev, self.misfit = torch, deepwave, dev, misfit
+        self.full_nt = type(self).nt
         if nt:
             self.nt = nt
         if grid:
             self.nz, self.nx = grid
-            self.name = "acoustic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, shots or self.shots_per_gpu, self.nt)
         ns = shots or self.shots_per_gpu
+        if grid or shots or nt:
+            self.name = "acoustic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, ns, self.nt)
         self.ns = ns
         total = ns * world
         xs_all = np.linspace(0.0, (self.nx - 1) * self.h, total)
@@ -87,13 +161,16 @@ class AcousticMarmousi:
                 self.wav, self.x_s, self.x_r, self.dt)
             omax, _ = obs.abs().max(dim=0, keepdim=True)
             self.obs = obs / (omax + 1e-10)
-        self.t_fwd = self.t_bwd = 0.0
-        self.n_timed = 0
+        self._ev = []
+        self.last_rec = None
 
-    # cells one kernel launch updates (computational grid incl. absorbing layer, all shots)
     @property
-    def cells_per_launch(self):
-        return (self.nz + 2 * self.pml) * (self.nx + 2 * self.pml) * self.ns
+    def profile_key(self):
+        return "acoustic_%dx%d" % (self.nz, self.nx)
+
+    @property
+    def interior_cells(self):
+        return self.nz * self.nx * self.ns
 
     @property
     def units_per_step(self):
@@ -113,19 +190,38 @@ class AcousticMarmousi:
         rec.backward(grec)
         ev[3].record()
         if timed:
-            self._ev = getattr(self, "_ev", []) + [ev]
+            self._ev.append(ev)
+        self.last_rec = rec.detach()
         return self.vp.grad, loss
 
-    def kernel_family(self):
+    def _slabs(self):
         from physicsbasedfwi2_amd.acoustic import AcousticPlan
         P = self.pml
-        nw = AcousticPlan(self.nz + 2 * P, self.nx + 2 * P, self.nt, self.ns, 1, self.nx, 1, 1.0, 1.0,
-                          self.dev.index or 0).cluster_slabs()
+        pl = AcousticPlan(self.nz + 2 * P, self.nx + 2 * P, self.nt, self.ns, 1, self.nx, 1, 1.0, 1.0,
+                          self.dev.index or 0)
+        nw = pl.cluster_slabs()
+        pl.close()
+        return nw, nw
+
+    def resident(self):
+        """(forward, adjoint): True where the time loop runs LDS-resident in one launch."""
+        f, a = self._slabs()
+        return bool(f), bool(a)
+
+    def kernel_family(self):
+        nw = self._slabs()[0]
         return "single-launch time loop, %d row slabs per shot" % nw if nw else "one launch per step"
 
+    def other_family_env(self):
+        """Environment that makes the plan pick the other kernel family (the in-run cross-check)."""
+        return ({"MIFWI_AC_CLUSTER": "0"}, "one launch per step") if self._slabs()[0] else (None, None)
+
+    def resident_nt(self):
+        return None
+
     def kernel_times(self):
-        """avg per-launch duration (s) of the forward(+save) and adjoint(+imaging) kernels from
-        the HIP events recorded on the launch stream around the two time loops."""
+        """avg per-step duration (s) of the forward(+save) and adjoint(+imaging) time loops from the HIP
+        events recorded on the launch stream around them."""
         tf = np.mean([e[0].elapsed_time(e[1]) for e in self._ev]) * 1e-3
         tb = np.mean([e[2].elapsed_time(e[3]) for e in self._ev]) * 1e-3
         return tf / self.nt, tb / max(1, self.nt - 1)
@@ -185,6 +281,7 @@ class ElasticMarmousi:
     shots_per_gpu = 32
     pml = 10
     fwd_bytes, adj_bytes = 60.0, 80.0    # fused forward 60 B, adjoint + correlation 80 B
+    resident_fwd_bytes, resident_adj_bytes = 20.0, 20.0      # LDS-resident: the five snapshot planes only
     # acquisition (networks.py:7612-7631): sources every 80 m at z = 40 m, receivers every 20 m at z = 460 m
     src_depth, rec_depth, rec_dx, x_first, x_margin, rec_x_max = 40.0, 460.0, 20.0, 380.0, 120.0, 5880.0
     free_surface = False
@@ -193,27 +290,39 @@ class ElasticMarmousi:
         import torch
         from physicsbasedfwi2_amd import elastic, misfit, profiles
         self.torch, self.elastic, self.dev, self.misfit = torch, elastic, dev, misfit
+        self.full_nt = type(self).nt
         if nt:
             self.nt = nt
         if os.environ.get("TUNE_PML"):
             self.pml = int(os.environ["TUNE_PML"])
         if grid:
             self.nz, self.nx = grid
-            self.name = "elastic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, shots or self.shots_per_gpu, self.nt)
         ns = shots or self.shots_per_gpu
+        if grid or shots or nt:
+            self.name = "elastic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, ns, self.nt)
         self.ns = ns
+        # A shortened time axis (kernel measurements on the big grids) would end before the source wavelet has
+        # peaked and long before anything reaches the receiver line: such samples compress the acquisition so
+        # that the misfit and the gradient are real numbers, not denormals - receivers three cells below the
+        # sources, wavelet peak within the first quarter of the run.
+        t_arrive = abs(self.rec_depth - self.src_depth) / 1500.0 + 1.5 / self.freq
+        self.sample_acquisition = self.nt * self.dt < 1.5 * t_arrive
+        rec_depth, freq = self.rec_depth, self.freq
+        if self.sample_acquisition:
+            rec_depth = self.src_depth + 3 * self.h
+            freq = max(self.freq, 6.0 / (self.nt * self.dt))
         total = ns * world
         xs_all = np.linspace(self.x_first, (self.nx - 1) * self.h - self.x_margin, total)
         xs = xs_all[rank * ns:(rank + 1) * ns]
         _, _, sc = profiles.cells_round(xs, np.full(ns, self.src_depth), self.h, self.nx)
         xr = np.arange(self.x_first, min(self.rec_x_max, (self.nx - 2) * self.h) + self.h, self.rec_dx)
-        _, _, rc = profiles.cells_round(xr, np.full(xr.size, self.rec_depth), self.h, self.nx)
+        _, _, rc = profiles.cells_round(xr, np.full(xr.size, rec_depth), self.h, self.nx)
         self.nrec = xr.size
         self.sc = torch.tensor(sc).view(ns, 1, 1)
         self.sw = torch.ones(ns, 1, 1)
         self.rc = torch.tensor(rc).view(1, -1, 1).repeat(ns, 1, 1)
         self.rw = torch.ones(ns, self.nrec, 1)
-        wav = profiles.ricker(self.freq, self.nt, self.dt, 1.0 / self.freq) * (self.dt / self.h ** 2) * 1e9
+        wav = profiles.ricker(freq, self.nt, self.dt, 1.0 / freq) * (self.dt / self.h ** 2) * 1e9
         self.f = wav.reshape(-1, 1, 1).repeat(1, ns, 1).to(dev)
         vmax = 4500.0
         assert self.dt <= profiles.elastic_cfl_limit(self.h, vmax)
@@ -228,9 +337,14 @@ class ElasticMarmousi:
             self.ox, self.oz = elastic.propagate(mat, self.f, self.pz, self.px, self.sc, self.sw,
                                                  self.rc, self.rw, self.pml, free_surface=self.free_surface)
         self._ev = []
+        self.last_rec = None
 
     @property
-    def cells_per_launch(self):
+    def profile_key(self):
+        return "elastic_%dx%d%s" % (self.nz, self.nx, "_fs" if self.free_surface else "")
+
+    @property
+    def interior_cells(self):
         return self.nz * self.nx * self.ns
 
     @property
@@ -254,26 +368,41 @@ class ElasticMarmousi:
         ev[3].record()
         if timed:
             self._ev.append(ev)
+        self.last_rec = torch.stack([rvx.detach(), rvz.detach()])
         return torch.stack([p.grad for p in self.prm]), loss
 
     def resident_nt(self):
         """None when all snapshots fit the default budget; otherwise a step count that does."""
-        per_step = 20.0 * self.ns * self.nz * (4 * ((self.nx + 3) // 4))
+        per_step = self.elastic.snapshot_bytes_per_cell() * self.ns * self.nz * (4 * ((self.nx + 3) // 4))
         if self.nt * per_step <= self.elastic.DEFAULT_SNAPSHOT_BUDGET:
             return None
         return int(max(20, min(200, 0.25 * self.elastic.DEFAULT_SNAPSHOT_BUDGET // per_step)))
 
-    def kernel_family(self):
+    def _slabs(self):
         from physicsbasedfwi2_amd.elastic import ElasticPlan
         pl = ElasticPlan(self.nz, self.nx, self.nt, self.ns, 1, self.nrec, 1, self.pml, self.dev.index or 0,
                          0, int(self.free_surface))
-        f, a = pl.cluster_slabs(False), pl.cluster_slabs(True)
+        out = pl.cluster_slabs(False), pl.cluster_slabs(True)
+        pl.close()
+        return out
+
+    def resident(self):
+        f, a = self._slabs()
+        return bool(f), bool(a)
+
+    def kernel_family(self):
         return "forward: %s; adjoint: %s" % tuple(
-            "single-launch time loop, %d row slabs per shot" % n if n else "one launch per half step"
-            for n in (f, a))
+            "single-launch time loop, %d row slabs per shot" % n if n else self.elastic.per_step_family()
+            for n in self._slabs())
+
+    def other_family_env(self):
+        f, a = self._slabs()
+        if f or a:
+            return {"MIFWI_EL_CLUSTER": "0", "MIFWI_EL_CLUSTER_ADJ": "0"}, "one launch per half step"
+        return self.elastic.other_per_step_env()
 
     def kernel_times(self):
-        """avg duration (s) of one forward step (V+S launches) and one adjoint step (S^T+V^T)."""
+        """avg duration (s) of one forward step and one adjoint step of the time loops."""
         tf = np.mean([e[0].elapsed_time(e[1]) for e in self._ev]) * 1e-3
         tb = np.mean([e[2].elapsed_time(e[3]) for e in self._ev]) * 1e-3
         return tf / self.nt, tb / self.nt
@@ -324,20 +453,82 @@ WORKLOADS = {"acoustic_marmousi": AcousticMarmousi, "elastic_marmousi": ElasticM
              "elastic_seam": ElasticSEAM}
 
 
-def measured_traffic(workload, kernel, cells):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json, written by tools/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE as
-    MI355X_MICROARCH.md prescribes), normalised like `achieved` to one time step of all shots.
-    None when no PMC summary exists for this workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            rec = json.load(fh).get(workload, {}).get(kernel)
-    except (OSError, ValueError):
-        return None
-    if not rec:
-        return None
-    return rec["bytes_per_cell_step"] * cells
+def kernel_report(wl_key, label, t_step, interior, streaming_bytes, resident_bytes, is_resident):
+    """Rates of one time-loop kernel, all on interior cells.  `alg` = the algorithmic bytes of the
+    formulation that runs: SURVEY 8d's per-step streaming figure for one launch per (half) step; for an
+    LDS-resident time loop only the snapshot stream has to cross HBM."""
+    alg = resident_bytes if is_resident else streaming_bytes
+    hbm, tag = measured_traffic(wl_key, label)
+    k = {"avg_step_s": t_step, "lds_resident": bool(is_resident),
+         "alg_bytes_per_cell_step": alg, "alg_GBs": alg * interior / t_step / 1e9,
+         "streaming_bytes_per_cell_step": streaming_bytes,
+         "streaming_equivalent_GBs": streaming_bytes * interior / t_step / 1e9,
+         "Mcells_steps_per_s": interior / t_step / 1e6,
+         "hbm_bytes_per_cell_step_measured": hbm,
+         "hbm_GBs_measured": None if hbm is None else hbm * interior / t_step / 1e9,
+         "traffic_profiled_at": tag if hbm is not None else None}
+    if hbm is None:
+        k["traffic_note"] = tag
+    if is_resident:
+        floor, ftag = latency_floor(wl_key, label)
+        if floor is not None:
+            k["latency"] = {"bound": "latency", "floor_us_per_step": floor * 1e6,
+                            "achieved_us_per_step": t_step * 1e6, "frac": min(1.0, floor / t_step),
+                            "floor_profiled_at": ftag,
+                            "note": "floor = the same kernel with hand-off waits and the snapshot stream ablated"}
+        else:
+            k["latency"] = {"bound": "latency", "floor_us_per_step": None, "note": ftag}
+    return k
+
+
+def roofline_of(kern, dom, interior):
+    """The contract's roofline object for the dominant kernel: achieved = algorithmic bytes of one step of
+    all shots / its duration (HIP events on the launch stream); traffic = measured HBM bytes of the same
+    unit (committed PMC passes of these very kernels) or null."""
+    k = kern[dom]
+    r = {"bound": "hbm", "kernel": dom, "achieved": k["alg_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": k["alg_GBs"] / HBM_PEAK_GBS,
+         "traffic": None if k["hbm_bytes_per_cell_step_measured"] is None
+         else k["hbm_bytes_per_cell_step_measured"] * interior,
+         "traffic_profiled_at": k["traffic_profiled_at"],
+         "alg_bytes_per_launch_step": k["alg_bytes_per_cell_step"] * interior,
+         "cells": "interior",
+         "formulation": ("LDS-resident time loop in one launch: only the snapshot stream must cross HBM "
+                         "(%.0f B/cell-step); its bound is the latency chain, see `latency`"
+                         % k["alg_bytes_per_cell_step"]) if k["lds_resident"] else
+                        "one launch per (half) step: SURVEY 8d streaming bytes (%.0f B/cell-step)"
+                        % k["alg_bytes_per_cell_step"]}
+    if k["lds_resident"]:
+        r["streaming_equivalent_GBs"] = k["streaming_equivalent_GBs"]
+        r["latency"] = k.get("latency")
+    assert r["frac"] <= 1.0 + 1e-9, "a roofline fraction above 1 means the byte count does not describe the kernel"
+    return r
+
+
+def cross_check(wl, name, dev, kw):
+    """Untimed, after the timed loop: one shot of the same workload through the family that was timed and
+    through the other one (environment switch read at plan creation); traces must agree bit for bit, the
+    gradient to fp32 summation order."""
+    import torch
+    env, label = wl.other_family_env()
+    if env is None:
+        return {"verified": None, "note": "this plan has one kernel family only"}
+    nt = min(wl.nt, 400) if wl.resident_nt() else wl.nt
+    outs = []
+    for e in ({}, env):
+        with _env(**e):
+            one = WORKLOADS[name](dev, 0, 1, nt=nt, shots=1, **kw)
+            grad, _ = one.step(False)
+            outs.append((one.last_rec.clone(), grad.detach().clone()))
+            del one
+    torch.cuda.synchronize()
+    (ra, ga), (rb, gb) = outs
+    tr = float((ra - rb).abs().max())
+    den = float(gb.double().norm())
+    gr = float((ga.double() - gb.double()).norm()) / (den if den > 0 else 1.0)
+    ok = bool(float(ra.abs().max()) > 0 and tr == 0.0 and gr <= 2e-5)
+    return {"verified": ok, "against": label, "shots": 1, "nt": nt, "trace_max_abs_diff": tr,
+            "gradient_rel_l2": gr}
 
 
 def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, warmup=None):
@@ -385,15 +576,17 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
         el = float(t.item())
     if rank != 0:
         return None
+    if not (np.isfinite(losses[0]) and losses[0] > 1e-12 and gsums[0] > 1e-12):
+        raise SystemExit("bench: the timed pass produced loss %.3g, |grad| sum %.3g - nothing reached the receivers, "
+                         "the kernels were timed on zeros" % (losses[0], gsums[0]))
     value = wl.units_per_step * world * args.steps / el / 1e6
     t_f, t_b = wl.kernel_times()
     kernel_note = None
-    nt_res = getattr(wl, "resident_nt", lambda: None)()
+    nt_res = wl.resident_nt()
     if nt_res:
         # time-checkpointed run: the backward call re-runs the forward, so its events do not isolate the adjoint
         # kernels; the per-kernel durations come from a short run of the same workload with resident snapshots
-        kw2 = dict(kw)
-        short = WORKLOADS[name](dev, rank, world, nt=nt_res, shots=args.shots or None, **kw2)
+        short = WORKLOADS[name](dev, rank, world, nt=nt_res, shots=args.shots or None, **kw)
         short.step(False)
         for _ in range(2):
             short.step(True)
@@ -401,18 +594,18 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
         t_f, t_b = short.kernel_times()
         del short
         kernel_note = "per-kernel durations from a %d-step run of the same workload (snapshots resident)" % nt_res
-    cells = wl.cells_per_launch
-    interior = wl.nz * wl.nx * wl.ns          # the metric counts interior cells x user time steps
+    interior = wl.interior_cells              # the metric counts interior cells x user time steps
+    res_f, res_a = wl.resident()
     kern = {
-        "forward+save": {"avg_step_s": t_f, "alg_bytes_per_cell_step": wl.fwd_bytes,
-                         "achieved_GBs": wl.fwd_bytes * cells / t_f / 1e9,
-                         "Mcells_steps_per_s": interior / t_f / 1e6},
-        "adjoint+imaging": {"avg_step_s": t_b, "alg_bytes_per_cell_step": wl.adj_bytes,
-                            "achieved_GBs": wl.adj_bytes * cells / t_b / 1e9,
-                            "Mcells_steps_per_s": interior / t_b / 1e6},
+        "forward+save": kernel_report(wl.profile_key, "forward+save", t_f, interior, wl.fwd_bytes,
+                                      wl.resident_fwd_bytes, res_f),
+        "adjoint+imaging": kernel_report(wl.profile_key, "adjoint+imaging", t_b, interior, wl.adj_bytes,
+                                         wl.resident_adj_bytes, res_a),
     }
     dom = "adjoint+imaging" if t_b >= t_f else "forward+save"
-    traffic = measured_traffic(wl.name, dom, cells)
+    check = {"loss": losses[0], "grad_abs_sum": gsums[0], "bitwise_repeatable": deterministic}
+    if not args.no_verify:
+        check.update(cross_check(wl, name, dev, kw))
     out = {
         "metric": "grid-cells*timesteps/sec (forward+adjoint gradient pass)",
         "value": value, "unit": "Mcells*steps/s", "n_gpus": world, "steps": args.steps,
@@ -421,14 +614,16 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
         "data": "synthetic",
         "config": {"workload": wl.name, "shots_per_gpu": wl.ns, "nt": wl.nt,
                    "grid": [wl.nz, wl.nx], "parallelism": "shots x%d" % world,
-                   "kernel_family": wl.kernel_family()},
-        "check": {"loss": losses[0], "grad_abs_sum": gsums[0], "bitwise_repeatable": deterministic},
-        "roofline": {"bound": "hbm", "kernel": dom,
-                     "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS,
-                     "traffic": traffic},
+                   "cells": "interior cells of the physical grid in value, kernels and roofline alike",
+                   "kernel_family": wl.kernel_family(),
+                   "snapshots": getattr(wl, "elastic", None) and wl.elastic.snapshot_mode() or "f32"},
+        "check": check,
+        "roofline": roofline_of(kern, dom, interior),
         "kernels": kern,
     }
+    if getattr(wl, "sample_acquisition", False):
+        out["config"]["acquisition"] = ("sample: %d of %d steps, receivers 3 cells below the sources, wavelet "
+                                        "compressed into the run" % (wl.nt, wl.full_nt))
     if kernel_note:
         out["kernels_note"] = kernel_note
     try:                       # record the device and its clocks next to the numbers
@@ -449,6 +644,41 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
     return out
 
 
+def self_launch(args, argv):
+    """--gpus N without a launcher: start N ranks of this script (one per GPU, rendezvous on 127.0.0.1) from a
+    parent that never touches the GPU, pass rank 0's JSON line through, fail if any rank fails."""
+    import torch
+    n = args.gpus
+    if args.device_index < 0 and args.backend == "nccl":
+        have = torch.cuda.device_count()            # does not initialise the GPU on this image
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (n, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for r, p in enumerate(procs):
+            code = p.wait()
+            if code != 0 and rc == 0:
+                rc = code
+                print("bench.py: rank %d of %d exited with code %d" % (r, n, code), file=sys.stderr)
+                for q in procs:                     # the others would wait for it at the next collective
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -463,16 +693,23 @@ def main():
                     help="collective backend for --gpus > 1 (gloo: rehearsal of the multi-rank path)")
     ap.add_argument("--device-index", type=int, default=-1,
                     help="HIP device of this rank (default LOCAL_RANK; rehearsals put every rank on 0)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the untimed cross-check of the two kernel families (counter / ablation runs)")
     ap.add_argument("--no-also", action="store_true",
-                    help="skip the secondary (elastic) workload of the default invocation")
+                    help="skip the secondary workloads of the default invocation")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))    # before anything here touches the GPU
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
@@ -485,17 +722,18 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
     want_cpu = (not args.no_cpu_baseline) and world == 1
-    primary = args.workload or "acoustic_marmousi"
+    primary = args.workload or "elastic_marmousi"
     out = run_workload(primary, args, dev, rank, world, want_cpu)
     if args.workload is None and not args.no_also:
-        # the north-star roofline target is stated on the elastic stencil: report it alongside
         keys = ("config", "value", "unit", "steps", "warmup", "ms_per_step", "check", "roofline", "kernels",
                 "kernels_note", "cpu_baseline", "note")
-        also = [run_workload("elastic_marmousi", args, dev, rank, world, want_cpu)]
+        also = [run_workload("acoustic_marmousi", args, dev, rank, world, want_cpu)]
         # BASELINE names no elastic grid - the same survey on the 10 m Marmousi-II grid 350x1700, where
-        # the per-step kernels run and the 3000 snapshots do not fit (time checkpointing); fewer timed passes
+        # the per-step kernels run HBM-bound and the 3000 snapshots do not fit (time checkpointing); fewer passes
         also.append(run_workload("elastic_marmousi", args, dev, rank, world, want_cpu, grid=(350, 1700),
                                  steps=min(args.steps, 3), warmup=1))
         if rank == 0:
@@ -503,6 +741,7 @@ def main():
             out["also"] = [{k: a[k] for k in keys if k in a} for a in also]
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

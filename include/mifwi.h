@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define MIFWI_VERSION_MAJOR 0
-#define MIFWI_VERSION_MINOR 2   /* 2: elastic desc gained source_type, record_pressure; bind_pressure, device_info */
+#define MIFWI_VERSION_MINOR 3   /* 3: elastic desc gained snapshot_format; layout snap_step_elems, snapshot_format */
 
 enum {
     MIFWI_OK = 0,
@@ -171,7 +171,16 @@ typedef struct {
     int32_t record_pressure; /* 1: the plan also serves pressure receivers (DENISE SEISMO 2 / 4, adjoint source
                                 type QUELLTYPB 4) through mifwi_elastic_plan_bind_pressure; such plans run on
                                 the one-launch-per-half-step kernels.                                     */
+    int32_t snapshot_format; /* MIFWI_SNAPSHOT_F32 (exact discrete adjoint) or MIFWI_SNAPSHOT_BF16: the five
+                                forward snapshot planes are rounded to bf16 on their way to memory (10 instead of
+                                20 B per cell-step each way, twice the steps per checkpoint segment; material
+                                gradients within 2e-3 rel-L2 of the f32 form, seismograms unchanged) - the
+                                counterpart of the wavefield compression / decimation DENISE and deepwave apply to
+                                their stored fields.  Honoured by plans that run the per-step
+                                kernels; single-launch plans keep f32 (layout.snapshot_format says which).     */
 } mifwi_elastic_desc;
+
+enum { MIFWI_SNAPSHOT_F32 = 0, MIFWI_SNAPSHOT_BF16 = 1 };
 
 typedef struct {
     int32_t gp, pitch, ngroups, shots_per_group;
@@ -180,6 +189,9 @@ typedef struct {
                                      of `work`: what a time checkpoint copies                  */
     int64_t work_forward_elems;
     int64_t work_backward_elems;
+    int64_t snap_step_elems;      /* floats one time step of the snapshot buffer takes (all shots)  */
+    int32_t snapshot_format;      /* the format this plan writes and reads                          */
+    int32_t reserved0;
 } mifwi_elastic_layout;
 
 typedef struct mifwi_elastic_plan mifwi_elastic_plan;
@@ -203,8 +215,9 @@ int mifwi_elastic_plan_bind_pressure(mifwi_elastic_plan *plan, float *rec_p, con
 /* Steps n = n_begin .. n_end-1.
  *   f [nt][nshot][nsrc] (added to sxx and szz - or to vx / vz, desc.source_type - pre-scaled by the host)
  *   rec_vx, rec_vz [nt][nshot][nrec] or both NULL
- *   snap NULL or [n_end-n_begin][nshot][5][nz][gp]: the five PML-filtered derivative sums the
- *        material gradient needs (exx', ezz', exz', and the two force terms)                 */
+ *   snap NULL or [n_end-n_begin][layout.snap_step_elems]: per step and shot the five PML-filtered derivative
+ *        sums the material gradient needs (exx', ezz', exz', and the two force terms); f32 format:
+ *        [nshot][5][nz][gp]                                                                   */
 int mifwi_elastic_forward(mifwi_elastic_plan *plan, const float *mat, const float *pz,
                           const float *px, const float *f, const int32_t *src_cell,
                           const float *src_w, const int32_t *rec_cell, const float *rec_w,
@@ -212,7 +225,7 @@ int mifwi_elastic_forward(mifwi_elastic_plan *plan, const float *mat, const floa
                           int32_t n_end, int32_t flags, void *stream);
 
 /* Adjoint steps n = n_hi down to n_lo (full run: nt-1 .. 0, ZERO_STATE|FINALIZE).
- *   g_vx, g_vz [nt][nshot][nrec] = dJ/d rec;  snapshot of step n at snap+(n-snap_first)*5*nshot*nz*gp
+ *   g_vx, g_vz [nt][nshot][nrec] = dJ/d rec;  snapshot of step n at snap+(n-snap_first)*layout.snap_step_elems
  *   grad_mat [5][nz][gp] (on FINALIZE): dJ/d mat summed over the plan's shots
  *   grad_f NULL or [nt][nshot][nsrc]                                                        */
 int mifwi_elastic_backward(mifwi_elastic_plan *plan, const float *mat, const float *pz,

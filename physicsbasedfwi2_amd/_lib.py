@@ -39,16 +39,19 @@ class ElasticDesc(ctypes.Structure):
                 ("nshot", ctypes.c_int32), ("nsrc", ctypes.c_int32), ("nrec", ctypes.c_int32),
                 ("ntap", ctypes.c_int32), ("pml_width", ctypes.c_int32),
                 ("free_surface", ctypes.c_int32), ("shots_per_group", ctypes.c_int32),
-                ("source_type", ctypes.c_int32), ("record_pressure", ctypes.c_int32)]
+                ("source_type", ctypes.c_int32), ("record_pressure", ctypes.c_int32),
+                ("snapshot_format", ctypes.c_int32)]
 
 
 class ElasticLayout(ctypes.Structure):
     _fields_ = [("gp", ctypes.c_int32), ("pitch", ctypes.c_int32), ("ngroups", ctypes.c_int32),
                 ("shots_per_group", ctypes.c_int32), ("coef_elems", ctypes.c_int64),
                 ("state_elems", ctypes.c_int64), ("work_forward_elems", ctypes.c_int64),
-                ("work_backward_elems", ctypes.c_int64)]
+                ("work_backward_elems", ctypes.c_int64), ("snap_step_elems", ctypes.c_int64),
+                ("snapshot_format", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
+SNAPSHOT_F32, SNAPSHOT_BF16 = 0, 1
 _P = ctypes.c_void_p
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against

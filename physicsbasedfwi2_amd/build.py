@@ -32,14 +32,15 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """`out`: build another copy (e.g. an ablation build loaded through MIFWI_LIB) instead of the in-tree library."""
+    if out is None and not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", LIB] + sources()
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", out or LIB] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -59,7 +59,8 @@ struct ElParams {
     float *fields_out;           // fused forward step: the copy of the state this launch writes
     float *psix, *psiz;          // forward: updated in place; adjoint: read side
     float *psix_out, *psiz_out;  // adjoint: write side (ping-pong)
-    float *S;                    // snapshot slice of this step [nshot][5][nz][gp]
+    float *S;                    // snapshot slice of this step: f32 [nshot][5][nz][gp]; bf16: snap_shot floats per shot
+    long long snap_shot;         // floats per shot of one snapshot step (5*nz*gp for f32)
     float *acc;                  // [ngroups][5][nz][gp]
     // injection (S launch: sxx,szz += a ; S^T launch: vx += ax, vz += az)
     int ninj, ntap_inj;
@@ -105,6 +106,45 @@ __device__ __forceinline__ float pmlT(float psib, float a, float b, float ik, fl
     psib_new = b * P;
     return fmaf(ik, db, a * P);
 }
+
+// ---- bf16 snapshot planes (plan snapshot_format = 1): the five per-step planes the material gradient needs are
+// rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32) on their way to memory and widened again by the
+// adjoint: 10 instead of 20 B per cell-step each way.  Arithmetic stays f32.  Layout of one shot-step, in
+// 4-cell groups g = (j*gp + 4*i)/4:  [g][S1 x4, S2 x4] 16 B | [g][S4 x4, S5 x4] 16 B | [g][S3 x4] 8 B.
+typedef __bf16 mifwi_bf2 __attribute__((ext_vector_type(2)));
+typedef float mifwi_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned mifwi_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned mifwi_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf_pack(float a, float b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(mifwi_f2{a, b}, mifwi_bf2));
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void bf_store2(float *base, unsigned grp, const float *a, const float *b)
+{
+    const mifwi_u4 v{bf_pack(a[0], a[1]), bf_pack(a[2], a[3]), bf_pack(b[0], b[1]), bf_pack(b[2], b[3])};
+    __builtin_nontemporal_store(v, reinterpret_cast<mifwi_u4 *>(base) + grp);
+}
+__device__ __forceinline__ void bf_store1(float *base, unsigned grp, const float *a)
+{
+    const mifwi_u2 v{bf_pack(a[0], a[1]), bf_pack(a[2], a[3])};
+    __builtin_nontemporal_store(v, reinterpret_cast<mifwi_u2 *>(base) + grp);
+}
+__device__ __forceinline__ void bf_load2(const float *base, unsigned grp, float4 &a, float4 &b)
+{
+    const mifwi_u4 v = __builtin_nontemporal_load(reinterpret_cast<const mifwi_u4 *>(base) + grp);
+    a = make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
+    b = make_float4(bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w));
+}
+__device__ __forceinline__ void bf_load1(const float *base, unsigned grp, float4 &a)
+{
+    const mifwi_u2 v = __builtin_nontemporal_load(reinterpret_cast<const mifwi_u2 *>(base) + grp);
+    a = make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
+}
+// offsets (in floats) of the three regions of a bf16 shot-step
+__device__ __forceinline__ long long bf_reg_de(unsigned ncell) { return (long long)ncell; }
+__device__ __forceinline__ long long bf_reg_c(unsigned ncell) { return 2LL * ncell; }
 
 // x-strip column offset of group g (or -1)
 __device__ __forceinline__ int xstrip(const ElParams &p, int g)
@@ -206,7 +246,7 @@ __device__ bool stage_injection(const ElParams &p, int s, int tile_j, int tile_i
 // ================================================================================================
 // forward V launch:  vx += bxs (Dp_x sxx' + Dm_z sxz'),  vz += bzs (Dm_x sxz' + Dp_z szz')
 // ================================================================================================
-template <int LX, int RZ, bool SAVE>
+template <int LX, int RZ, int SAVE>       // SAVE 0: no snapshots, 1: f32 planes, 2: bf16 planes
 __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const ElParams p)
 {
     constexpr int LZ = kThreads / LX;
@@ -318,10 +358,12 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
             vzv.z = fmaf(bzs.z, s5v[2], vzv.z); vzv.w = fmaf(bzs.w, s5v[3], vzv.w);
             st4(vx + o, vxv);
             st4(vz + o, vzv);
-            if (SAVE) {
-                float *Sp = p.S + (long long)s * 5 * ncell + cc;
+            if (SAVE == 1) {
+                float *Sp = p.S + (long long)s * p.snap_shot + cc;
                 mifwi::stnt4(Sp + 3 * (long long)ncell, make_float4(s4v[0], s4v[1], s4v[2], s4v[3]));
                 mifwi::stnt4(Sp + 4 * (long long)ncell, make_float4(s5v[0], s5v[1], s5v[2], s5v[3]));
+            } else if (SAVE == 2) {
+                bf_store2(p.S + (long long)s * p.snap_shot + bf_reg_de(ncell), cc >> 2, s4v, s5v);
             }
             a0 = a1; a1 = a2; a2 = a3;
             b0 = b1; b1 = b2; b2 = b3;
@@ -332,7 +374,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
 // ================================================================================================
 // forward S launch: stresses from the new velocities + source injection + receiver sampling
 // ================================================================================================
-template <int LX, int RZ, bool SAVE>
+template <int LX, int RZ, int SAVE>
 __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const ElParams p)
 {
     constexpr int LZ = kThreads / LX;
@@ -443,11 +485,15 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const E
                     st4(sxx + o, make_float4(nxx[0], nxx[1], nxx[2], nxx[3]));
                     st4(szz + o, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
                     st4(sxz + o, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
-                    if (SAVE) {
-                        float *Sp = p.S + (long long)s * 5 * ncell + cc;
+                    if (SAVE == 1) {
+                        float *Sp = p.S + (long long)s * p.snap_shot + cc;
                         mifwi::stnt4(Sp, make_float4(e1[0], e1[1], e1[2], e1[3]));
                         mifwi::stnt4(Sp + (long long)ncell, make_float4(e2[0], e2[1], e2[2], e2[3]));
                         mifwi::stnt4(Sp + 2 * (long long)ncell, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
+                    } else if (SAVE == 2) {
+                        float *Sp = p.S + (long long)s * p.snap_shot;
+                        bf_store2(Sp, cc >> 2, e1, e2);
+                        bf_store1(Sp + bf_reg_c(ncell), cc >> 2, s3v);
                     }
                     a0 = a1; a1 = a2; a2 = a3;
                     b0 = b1; b1 = b2; b2 = b3;
@@ -551,6 +597,7 @@ __device__ __forceinline__ void stage_E(const ElParams &p, int s, int j, int g, 
 //       all five material-gradient accumulators.
 // Every global load of a shot (own group, halo group, adjoint velocities, the five snapshot planes) is
 // requested before the first use: one memory round trip per shot instead of three.
+template <bool BF16>
 __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
 {
     int bx, by;
@@ -623,10 +670,15 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
             st4(&E[2][hr][4 * hg], E3); st4(&E[3][hr][4 * hg], E4);
         }
         // the snapshot planes are only needed after the barrier: requested last, they do not delay the staging
-        if (own_ok) {
-            const float *Sp = p.S + (long long)s * 5 * ncell + occ;
+        if (own_ok && !BF16) {
+            const float *Sp = p.S + (long long)s * p.snap_shot + occ;
             S1 = mifwi::ldnt4(Sp); S2 = mifwi::ldnt4(Sp + (long long)ncell); S3 = mifwi::ldnt4(Sp + 2 * (long long)ncell);
             S4 = mifwi::ldnt4(Sp + 3 * (long long)ncell); S5 = mifwi::ldnt4(Sp + 4 * (long long)ncell);
+        } else if (own_ok) {
+            const float *Sp = p.S + (long long)s * p.snap_shot;
+            bf_load2(Sp, occ >> 2, S1, S2);
+            bf_load2(Sp + bf_reg_de(ncell), occ >> 2, S4, S5);
+            bf_load1(Sp + bf_reg_c(ncell), occ >> 2, S3);
         }
         __syncthreads();
         // ---- stencils from LDS + injection + gradient accumulation ---------------------------
@@ -973,7 +1025,7 @@ __global__ __launch_bounds__(kThreads) void el_step_fused(const ElParams p)
             st4(fout + F_VX * fs + oo, vxn);
             st4(fout + F_VZ * fs + oo, vzn);
             if (SAVE) {
-                float *Sp = p.S + (long long)s * 5 * ncell + occ;
+                float *Sp = p.S + (long long)s * p.snap_shot + occ;
                 mifwi::stnt4(Sp + 3 * (long long)ncell, s4);
                 mifwi::stnt4(Sp + 4 * (long long)ncell, s5);
             }
@@ -1054,7 +1106,7 @@ __global__ __launch_bounds__(kThreads) void el_step_fused(const ElParams p)
         st4(fout + F_SZZ * fs + oo, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
         st4(fout + F_SXZ * fs + oo, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
         if (SAVE) {
-            float *Sp = p.S + (long long)s * 5 * ncell + occ;
+            float *Sp = p.S + (long long)s * p.snap_shot + occ;
             mifwi::stnt4(Sp, make_float4(e1[0], e1[1], e1[2], e1[3]));
             mifwi::stnt4(Sp + (long long)ncell, make_float4(e2[0], e2[1], e2[2], e2[3]));
             mifwi::stnt4(Sp + 2 * (long long)ncell, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
@@ -1204,6 +1256,8 @@ struct mifwi_elastic_plan {
     int W, wl, xr0, wx, xcd;
     float *rec_p;          // pressure receivers bound by mifwi_elastic_plan_bind_pressure (or null)
     const float *g_p;
+    int snap_bf16;         // snapshot planes as bf16 (per-step kernels on both sides only)
+    long long snap_shot;   // floats per shot of one snapshot step
     int pass_shots;        // forward per-step family: shots per pass over the time range
     int pass_groups;       // adjoint per-step family: shot groups per pass
     int fused;             // forward V+S in one launch (second copy of the state in the work buffer)
@@ -1230,53 +1284,38 @@ ElParams el_base(const mifwi_elastic_plan *pl, const float *mat, const float *pz
     p.psix_shot = 4LL * pl->d.nz * pl->wx; p.psiz_shot = 4LL * 2 * pl->W * pl->gp;
     p.mat = mat; p.pz = pz; p.px = px;
     p.xcd = pl->xcd;
+    p.snap_shot = pl->snap_shot;
     return p;
 }
 
-template <bool SAVE>
+template <int SAVE>
 void launch_v(const mifwi_elastic_plan *pl, const ElParams &p, int nshot, hipStream_t st)
 {
     const int lz = kThreads / pl->lx;
-    dim3 grid(mifwi::ceil_div(pl->ng, pl->lx), mifwi::ceil_div(pl->d.nz, lz * pl->rz), nshot);
+    dim3 grid(mifwi::ceil_div(pl->ng, pl->lx), mifwi::ceil_div(pl->d.nz, lz), nshot);
     dim3 block(kThreads);
-    if (pl->rz == 1) {
-        switch (pl->lx) {
-            case 64: hipLaunchKernelGGL((el_step_v<64, 1, SAVE>), grid, block, 0, st, p); break;
-            case 32: hipLaunchKernelGGL((el_step_v<32, 1, SAVE>), grid, block, 0, st, p); break;
-            default: hipLaunchKernelGGL((el_step_v<16, 1, SAVE>), grid, block, 0, st, p); break;
-        }
-        return;
-    }
     switch (pl->lx) {
-        case 64: hipLaunchKernelGGL((el_step_v<64, 2, SAVE>), grid, block, 0, st, p); break;
-        case 32: hipLaunchKernelGGL((el_step_v<32, 2, SAVE>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((el_step_v<16, 2, SAVE>), grid, block, 0, st, p); break;
+        case 64: hipLaunchKernelGGL((el_step_v<64, 1, SAVE>), grid, block, 0, st, p); break;
+        case 32: hipLaunchKernelGGL((el_step_v<32, 1, SAVE>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((el_step_v<16, 1, SAVE>), grid, block, 0, st, p); break;
     }
 }
 
-template <bool SAVE>
+template <int SAVE>
 void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, int nshot, hipStream_t st)
 {
     const int lz = kThreads / pl->lx;
     const int tiles_x = mifwi::ceil_div(pl->ng, pl->lx);
     ElParams p = p0;
-    p.tiles_z = mifwi::ceil_div(pl->d.nz, lz * pl->rz);
+    p.tiles_z = mifwi::ceil_div(pl->d.nz, lz);
     int extra = 0;
     if (p.smp_out0 != nullptr && p.nsmp > 0)
         extra = mifwi::ceil_div(mifwi::ceil_div(p.gs * p.nsmp, kThreads), tiles_x);
     dim3 grid(tiles_x, p.tiles_z + extra, mifwi::ceil_div(nshot, p.gs)), block(kThreads);
-    if (pl->rz == 1) {
-        switch (pl->lx) {
-            case 64: hipLaunchKernelGGL((el_step_s<64, 1, SAVE>), grid, block, 0, st, p); break;
-            case 32: hipLaunchKernelGGL((el_step_s<32, 1, SAVE>), grid, block, 0, st, p); break;
-            default: hipLaunchKernelGGL((el_step_s<16, 1, SAVE>), grid, block, 0, st, p); break;
-        }
-        return;
-    }
     switch (pl->lx) {
-        case 64: hipLaunchKernelGGL((el_step_s<64, 2, SAVE>), grid, block, 0, st, p); break;
-        case 32: hipLaunchKernelGGL((el_step_s<32, 2, SAVE>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((el_step_s<16, 2, SAVE>), grid, block, 0, st, p); break;
+        case 64: hipLaunchKernelGGL((el_step_s<64, 1, SAVE>), grid, block, 0, st, p); break;
+        case 32: hipLaunchKernelGGL((el_step_s<32, 1, SAVE>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((el_step_s<16, 1, SAVE>), grid, block, 0, st, p); break;
     }
 }
 
@@ -1415,6 +1454,8 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
         return mifwi::fail(MIFWI_EINVAL, "record_pressure must be 0 or 1");
     if (d->source_type < 0 || d->source_type > 2)
         return mifwi::fail(MIFWI_EINVAL, "source_type must be 0 (explosive), 1 (force x) or 2 (force z)");
+    if (d->snapshot_format != MIFWI_SNAPSHOT_F32 && d->snapshot_format != MIFWI_SNAPSHOT_BF16)
+        return mifwi::fail(MIFWI_EINVAL, "snapshot_format must be MIFWI_SNAPSHOT_F32 or MIFWI_SNAPSHOT_BF16");
     int rc = mifwi::check_device(device);
     if (rc) return rc;
     // function attributes and CU counts queried during set-up belong to THIS device (one process per
@@ -1463,6 +1504,10 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     pl->ngroups = mifwi::ceil_div(d->nshot, gs);
     pl->psi_elems = mifwi::round_up64(pl->psix_elems + pl->psiz_elems, 64);
     el_cluster_setup(pl);
+    // bf16 snapshot planes: the per-step kernels only (the single-launch time loops are not bound by the
+    // snapshot stream, and their grids' snapshots fit in memory many times over)
+    pl->snap_bf16 = d->snapshot_format == MIFWI_SNAPSHOT_BF16 && !pl->cluster && !pl->cl_adj;
+    pl->snap_shot = pl->snap_bf16 ? mifwi::round_up64(5 * pl->coef_elems / 2, 4) : 5 * pl->coef_elems;
     {
         // Infinity Cache residency (per-step family, large grids): a pass over the time range takes only as
         // many shots as keep state + materials (+ gradient accumulators) under kResident bytes; measured on
@@ -1500,7 +1545,7 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
         k = env_int("MIFWI_EL_PASS_GROUPS", k);
         pl->pass_groups = std::min(pl->ngroups, std::max(1, k));
     }
-    pl->fused = !pl->cluster && d->source_type == 0 && !d->record_pressure && env_int("MIFWI_EL_FUSED", 0) != 0;   // measured: no faster than two launches yet
+    pl->fused = !pl->cluster && !pl->snap_bf16 && d->source_type == 0 && !d->record_pressure && env_int("MIFWI_EL_FUSED", 0) != 0;   // measured: no faster than two launches yet
     if (pl->cl_adj) {                    // the adjoint cluster kernel keeps one accumulator set per shot
         pl->gs = 1;
         pl->ngroups = d->nshot;
@@ -1545,6 +1590,8 @@ int mifwi_elastic_plan_layout(const mifwi_elastic_plan *pl, mifwi_elastic_layout
     out->gp = pl->gp; out->pitch = pl->pitch; out->ngroups = pl->ngroups;
     out->shots_per_group = pl->gs;
     out->coef_elems = pl->coef_elems;
+    out->snap_step_elems = pl->snap_shot * pl->d.nshot;
+    out->snapshot_format = pl->snap_bf16 ? MIFWI_SNAPSHOT_BF16 : MIFWI_SNAPSHOT_F32;
     const long long psi = pl->psi_elems;
     const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
     out->state_elems = pl->fields_elems + psi;
@@ -1583,7 +1630,8 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
         hipLaunchKernelGGL(el_points_bbox, dim3(d.nshot), dim3(kThreads), 0, st, src_cell,
                            d.nsrc * d.ntap, d.nx, bbox);
     ElParams p = el_base(pl, mat, pz, px);
-    const long long snap_step = 5LL * d.nshot * pl->coef_elems;
+    const long long snap_step = pl->snap_shot * d.nshot;
+    const int save = !snap ? 0 : pl->snap_bf16 ? 2 : 1;
     const bool want_rec = rec_vx != nullptr && d.nrec > 0;
     if (pl->cluster && n_end > n_begin) {
         float *xbuf = work + pl->fields_elems + psi + mifwi::round_up64(4LL * d.nshot, 64);
@@ -1666,13 +1714,17 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
                 ps.inj_amp0 = f ? f + (long long)n * d.nshot * d.nsrc : nullptr;
                 ps.smp_out0 = want_rec ? rec_vx + (long long)n * d.nshot * d.nrec : nullptr;
                 ps.smp_out1 = want_rec ? rec_vz + (long long)n * d.nshot * d.nrec : nullptr;
-                if (snap) launch_v<true>(pl, p, cs, st); else launch_v<false>(pl, p, cs, st);
+                if (save == 2) launch_v<2>(pl, p, cs, st);
+                else if (save == 1) launch_v<1>(pl, p, cs, st);
+                else launch_v<0>(pl, p, cs, st);
                 if (force && d.nsrc > 0 && f) {
                     pf.s0 = s0; pf.gs = cs; pf.inj_amp0 = ps.inj_amp0;
                     hipLaunchKernelGGL(el_inject_force, dim3(mifwi::ceil_div(cs, 64)), dim3(64), 0, st, pf,
                                        d.source_type);
                 }
-                if (snap) launch_s<true>(pl, ps, cs, st); else launch_s<false>(pl, ps, cs, st);
+                if (save == 2) launch_s<2>(pl, ps, cs, st);
+                else if (save == 1) launch_s<1>(pl, ps, cs, st);
+                else launch_s<0>(pl, ps, cs, st);
                 if (pl->rec_p && want_rec) {
                     ElParams pq = ps;
                     pq.s0 = s0; pq.gs = cs; pq.smp_out0 = pl->rec_p + (long long)n * d.nshot * d.nrec;
@@ -1727,7 +1779,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
     ps.inj_bbox = bbox;
     const bool want_f = grad_f != nullptr && d.nsrc > 0;
     ps.nsmp = want_f ? d.nsrc : 0; ps.ntap_smp = d.ntap; ps.smp_cell = src_cell; ps.smp_w = src_w;
-    const long long snap_step = 5LL * d.nshot * pl->coef_elems;
+    const long long snap_step = pl->snap_shot * d.nshot;
     bool per_step = true;
     if (pl->cl_adj && n_hi >= n_lo) {
         float *xbuf = reinterpret_cast<float *>(bbox) + mifwi::round_up64(4LL * d.nshot, 64);
@@ -1805,7 +1857,8 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
                 hipLaunchKernelGGL(el_inject_pressure, dim3(mifwi::ceil_div(cs * d.nrec * d.ntap, 64)), dim3(64), 0,
                                    st, pq);
             }
-            hipLaunchKernelGGL(el_adj_s, dim3(tx, tz + ex, cg), dim3(kThreads), 0, st, ps);
+            if (pl->snap_bf16) hipLaunchKernelGGL(el_adj_s<true>, dim3(tx, tz + ex, cg), dim3(kThreads), 0, st, ps);
+            else hipLaunchKernelGGL(el_adj_s<false>, dim3(tx, tz + ex, cg), dim3(kThreads), 0, st, ps);
             if (want_f && force) {
                 ElParams pq = ps;
                 pq.gs = cs; pq.smp_out0 = grad_f + (long long)n * d.nshot * d.nsrc;

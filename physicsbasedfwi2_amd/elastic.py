@@ -17,6 +17,40 @@ from .acoustic import _Geometry, _require_cuda, _stream
 DEFAULT_SNAPSHOT_BUDGET = 96 << 30
 
 
+SNAPSHOT_FORMATS = {"f32": _lib.SNAPSHOT_F32, "bf16": _lib.SNAPSHOT_BF16}
+
+
+def snapshot_mode():
+    """Default storage of the five forward snapshot planes between the forward and the adjoint pass:
+    "f32" (exact discrete adjoint) unless MIFWI_EL_SNAP=bf16 asks for the compressed planes (see
+    :func:`propagate`, ``snapshot_format``)."""
+    import os
+    v = os.environ.get("MIFWI_EL_SNAP", "f32").lower()
+    if v not in SNAPSHOT_FORMATS:
+        raise MifwiError("MIFWI_EL_SNAP must be f32 or bf16 (got %r)" % v)
+    return v
+
+
+def snapshot_bytes_per_cell(fmt=None):
+    return 10.0 if (fmt or snapshot_mode()) == "bf16" else 20.0
+
+
+def per_step_family():
+    """Name of the per-step (large-grid) kernel family the plan picks when a shot does not fit the LDS."""
+    import os
+    return ("one fused V+S launch per step (forward)" if os.environ.get("MIFWI_EL_FUSED", "0") == "1"
+            else "one launch per half step")
+
+
+def other_per_step_env():
+    """(environment, label) selecting the other formulation of the per-step family: bench.py's in-run
+    cross-check runs one shot through both."""
+    import os
+    if os.environ.get("MIFWI_EL_FUSED", "0") == "1":
+        return {"MIFWI_EL_FUSED": "0"}, "one launch per half step"
+    return {"MIFWI_EL_FUSED": "1"}, "fused V+S forward launch"
+
+
 def staggered_materials(vp, vs, rho, dt, h, free_surface=False):
     """[5, nz, nx] = lambda dt/h, (lambda+2mu) dt/h, mu_xz dt/h, dt/(h rho_x), dt/(h rho_z).
     With ``free_surface`` row 0 of the first two planes is put in the effective form the
@@ -51,10 +85,11 @@ def staggered_materials(vp, vs, rho, dt, h, free_surface=False):
 
 class ElasticPlan:
     def __init__(self, nz, nx, nt, nshot, nsrc, nrec, ntap, pml_width, device_index,
-                 shots_per_group=0, free_surface=0, source_type=0, record_pressure=0):
+                 shots_per_group=0, free_surface=0, source_type=0, record_pressure=0, snapshot_format=None):
         self._lib = _lib.load()
+        fmt = SNAPSHOT_FORMATS[snapshot_format or snapshot_mode()]
         self.desc = _lib.ElasticDesc(nz, nx, nt, nshot, nsrc, nrec, ntap, pml_width,
-                                     free_surface, shots_per_group, source_type, record_pressure)
+                                     free_surface, shots_per_group, source_type, record_pressure, fmt)
         self._h = ctypes.c_void_p()
         _lib.check(self._lib.mifwi_elastic_plan_create(ctypes.byref(self._h), device_index,
                                                        ctypes.byref(self.desc)))
@@ -91,7 +126,7 @@ class ElasticPlan:
 class _ElasticFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mat, f, pz, px, geom, pml_width, shots_per_group, snapshot_budget, free_surface,
-                source_type=0, record_pressure=0):
+                source_type=0, record_pressure=0, snapshot_format=None):
         _require_cuda(mat, "mat")
         dev = mat.device
         lib = _lib.load()
@@ -107,7 +142,7 @@ class _ElasticFn(torch.autograd.Function):
             raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (nz, nx))
         with torch.cuda.device(dev):
             plan = ElasticPlan(nz, nx, nt, ns, nsrc, nrec, ntap, pml_width, dev.index,
-                               shots_per_group, free_surface, source_type, record_pressure)
+                               shots_per_group, free_surface, source_type, record_pressure, snapshot_format)
             lay = plan.layout
             gp = lay.gp
             mat_p = torch.zeros((5, nz, gp), device=dev, dtype=torch.float32)
@@ -126,7 +161,7 @@ class _ElasticFn(torch.autograd.Function):
                 _lib.check(lib.mifwi_elastic_plan_bind_pressure(plan.handle, _lib.ptr(rp), None))
             work = torch.empty(lay.work_forward_elems, device=dev, dtype=torch.float32)
             need_grad = mat.requires_grad or f.requires_grad
-            step_bytes = 4 * 5 * ns * lay.coef_elems
+            step_bytes = 4 * lay.snap_step_elems
             seg, snap, ckpt = nt, None, None
             if need_grad:
                 # never plan for more than most of the memory that is free right now (other tensors of
@@ -136,7 +171,7 @@ class _ElasticFn(torch.autograd.Function):
                     seg = max(1, int(snapshot_budget // (2 * step_bytes)))
                 if seg >= nt:
                     seg = nt
-                    snap = torch.empty((nt, ns, 5, nz, gp), device=dev, dtype=torch.float32)
+                    snap = torch.empty((nt, lay.snap_step_elems), device=dev, dtype=torch.float32)
             args = (plan.handle, _lib.ptr(mat_p), _lib.ptr(pz_d), _lib.ptr(px_p), _lib.ptr(f_d),
                     _lib.ptr(geom.src_cell), _lib.ptr(geom.src_w), _lib.ptr(geom.rec_cell),
                     _lib.ptr(geom.rec_w), _lib.ptr(rvx), _lib.ptr(rvz))
@@ -193,7 +228,7 @@ class _ElasticFn(torch.autograd.Function):
             else:
                 seg = ctx.seg
                 fwork = torch.empty(lay.work_forward_elems, device=dev, dtype=torch.float32)
-                snap = torch.empty((seg, ns, 5, nz, lay.gp), device=dev, dtype=torch.float32)
+                snap = torch.empty((seg, lay.snap_step_elems), device=dev, dtype=torch.float32)
                 starts = list(range(0, nt, seg))
                 first = True
                 for si in reversed(range(len(starts))):
@@ -216,12 +251,12 @@ class _ElasticFn(torch.autograd.Function):
             plan.close()
             ctx.snap = None
             ctx.ckpt = None
-        return (grad_mat[:, :, :nx].contiguous(), grad_f, None, None, None, None, None, None, None, None, None)
+        return (grad_mat[:, :, :nx].contiguous(), grad_f) + (None,) * 10
 
 
 def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
               shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET, free_surface=False,
-              source_type="explosive", record_pressure=False):
+              source_type="explosive", record_pressure=False, snapshot_format=None):
     """Elastic forward modelling, differentiable w.r.t. ``mat`` and ``f``.
 
     mat [5,nz,nx] from :func:`staggered_materials`;  f [nt,nshot,nsrc] (added to sxx and szz);
@@ -231,6 +266,9 @@ def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
     pz [6,nz], px [6,nx] from :func:`profiles.cpml_tables`;  cells are iz*nx+ix.
     free_surface: row 0 is a stress-free surface (build ``mat`` with ``free_surface=True`` and
     ``pz`` with ``low=False``).
+    snapshot_format: "f32" (default; the gradient is the exact discrete adjoint) or "bf16": the forward snapshot
+    planes are kept as bf16 (half the snapshot stream and memory; material gradients within 2e-3 rel-L2 of the
+    f32 form, seismograms unchanged) on grids that run the per-step kernels; None = MIFWI_EL_SNAP or "f32".
     Returns (rec_vx, rec_vz), each [nt,nshot,nrec], sampled after the velocity update; with
     ``record_pressure`` also rec_p = sum w (sxx + szz) at the receivers after the stress update (DENISE's
     pressure seismogram is ``-rec_p``; such runs use the one-launch-per-half-step kernels)."""
@@ -241,9 +279,11 @@ def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
         st = SOURCE_TYPES[source_type]
     except KeyError:
         raise MifwiError("source_type must be one of %s" % sorted(k for k in SOURCE_TYPES if isinstance(k, str)))
+    if snapshot_format is not None and snapshot_format not in SNAPSHOT_FORMATS:
+        raise MifwiError("snapshot_format must be one of %s" % sorted(SNAPSHOT_FORMATS))
     rvx, rvz, rp = _ElasticFn.apply(mat, f, pz, px, geom, int(pml_width), int(shots_per_group),
                                     int(snapshot_budget), 1 if free_surface else 0, st,
-                                    1 if record_pressure else 0)
+                                    1 if record_pressure else 0, snapshot_format)
     return (rvx, rvz, rp) if record_pressure else (rvx, rvz)
 
 

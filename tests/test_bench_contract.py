@@ -23,49 +23,136 @@ def test_cpu_sample_sizing_fills_the_budget_within_the_caps():
     assert nt == 100 and reps == 1             # calibration already exceeds the budget
 
 
-def test_traffic_lookup_reads_the_committed_pmc_summary():
-    cells = 960000
-    t = bench.measured_traffic(bench.ElasticMarmousi.name, "adjoint+imaging", cells)
-    with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-        ref = json.load(fh)[bench.ElasticMarmousi.name]["adjoint+imaging"]["bytes_per_cell_step"]
-    assert t == ref * cells and bench.measured_traffic("no_such_workload", "x", 1) is None
+def _fake_tree(tmp_path, monkeypatch, body=b"kernel v1"):
+    """A throw-away repo root with one kernel source, so that the fingerprint logic can be driven."""
+    (tmp_path / "physicsbasedfwi2_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "physicsbasedfwi2_amd" / "csrc" / "k.hip").write_bytes(body)
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    return tmp_path
+
+
+def test_profile_summaries_are_quoted_only_for_the_kernels_they_describe(tmp_path, monkeypatch):
+    """roofline.traffic and the latency floor come from committed rocprofv3 / ablation summaries that carry the
+    fingerprint of the kernel sources; once a kernel file changes they are dropped, never quoted stale."""
+    root = _fake_tree(tmp_path, monkeypatch)
+    sha = bench.csrc_sha16()
+    doc = {"csrc_sha16": sha, "commit": "abc1234",
+           "elastic_100x300": {"adjoint+imaging": {"bytes_per_cell_step": 42.5}}}
+    (root / "profiles" / (bench.PROFILE_ROUND + "_pmc_traffic.json")).write_text(json.dumps(doc))
+    floor = {"csrc_sha16": sha, "commit": "abc1234",
+             "elastic_100x300": {"adjoint+imaging": {"floor_s_per_step": 9.3e-6}}}
+    (root / "profiles" / (bench.PROFILE_ROUND + "_latency_floor.json")).write_text(json.dumps(floor))
+    assert bench.measured_traffic("elastic_100x300", "adjoint+imaging") == (42.5, "abc1234")
+    assert bench.latency_floor("elastic_100x300", "adjoint+imaging") == (9.3e-6, "abc1234")
+    assert bench.measured_traffic("no_such_workload", "x")[0] is None
+    (root / "physicsbasedfwi2_amd" / "csrc" / "k.hip").write_bytes(b"kernel v2")
+    assert bench.csrc_sha16() != sha
+    val, why = bench.measured_traffic("elastic_100x300", "adjoint+imaging")
+    assert val is None and "other kernels" in why
+    assert bench.latency_floor("elastic_100x300", "adjoint+imaging")[0] is None
+
+
+def test_roofline_objects_use_one_cell_convention_and_never_exceed_one(tmp_path, monkeypatch):
+    root = _fake_tree(tmp_path, monkeypatch)
+    sha = bench.csrc_sha16()
+    (root / "profiles" / (bench.PROFILE_ROUND + "_pmc_traffic.json")).write_text(json.dumps(
+        {"csrc_sha16": sha, "commit": "c0ffee0", "elastic_100x300": {
+            "adjoint+imaging": {"bytes_per_cell_step": 42.5}, "forward+save": {"bytes_per_cell_step": 36.5}}}))
+    (root / "profiles" / (bench.PROFILE_ROUND + "_latency_floor.json")).write_text(json.dumps(
+        {"csrc_sha16": sha, "commit": "c0ffee0", "elastic_100x300": {
+            "adjoint+imaging": {"floor_s_per_step": 9.3e-6}, "forward+save": {"floor_s_per_step": 6.2e-6}}}))
+    interior = 100 * 300 * 32
+    kern = {"forward+save": bench.kernel_report("elastic_100x300", "forward+save", 7.6e-6, interior, 60.0, 20.0, True),
+            "adjoint+imaging": bench.kernel_report("elastic_100x300", "adjoint+imaging", 11.7e-6, interior, 80.0, 20.0,
+                                                   True)}
+    r = bench.roofline_of(kern, "adjoint+imaging", interior)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["cells"] == "interior"
+    assert abs(r["achieved"] - 20.0 * interior / 11.7e-6 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert r["frac"] < 1.0 and r["traffic"] == 42.5 * interior and r["traffic_profiled_at"] == "c0ffee0"
+    assert abs(r["streaming_equivalent_GBs"] - 80.0 * interior / 11.7e-6 / 1e9) < 1e-6
+    lat = r["latency"]
+    assert lat["bound"] == "latency" and abs(lat["frac"] - 9.3 / 11.7) < 1e-9 and lat["floor_profiled_at"] == "c0ffee0"
+    # per-step streaming family: SURVEY 8d bytes, no latency object
+    k2 = {"adjoint+imaging": bench.kernel_report("elastic_350x1700", "adjoint+imaging", 323e-6, 350 * 1700 * 32, 80.0,
+                                                 20.0, False)}
+    r2 = bench.roofline_of(k2, "adjoint+imaging", 350 * 1700 * 32)
+    assert "latency" not in r2 and r2["traffic"] is None and 0.55 < r2["frac"] < 0.62
+    assert k2["adjoint+imaging"]["traffic_note"].startswith("workload not in")
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r01_bench_default_output.json")) as fh:
+    path = os.path.join(ROOT, "profiles", bench.PROFILE_ROUND + "_bench_default_output.json")
+    with open(path) as fh:
         d = json.load(fh)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "check"):
         assert k in d, k
-    assert d["config"]["workload"] == bench.AcousticMarmousi.name and "model" not in d["config"]
+    assert d["config"]["workload"] == bench.ElasticMarmousi.name and "model" not in d["config"]
     assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["vs_baseline"] is None
-    r = d["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["traffic"] is None or r["traffic"] > 0
-    c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "C oracle" in c["sample"]
-    # whole-job throughput = cells*steps of all shots / wall time
-    wl = bench.AcousticMarmousi
+    entries = [d] + d.get("also", [])
+    assert [e["config"]["workload"] for e in entries[1:]][:1] == [bench.AcousticMarmousi.name]
+    for e in entries:
+        r = e["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        assert 0 < r["frac"] <= 1.0 and r["cells"] == "interior"
+        assert r["traffic"] is None or (r["traffic"] > 0 and r["traffic_profiled_at"])
+        assert e["check"]["bitwise_repeatable"] is True and e["check"]["verified"] is True
+        assert e["check"]["loss"] > 1e-12 and e["check"]["grad_abs_sum"] > 1e-12
+        c = e["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "C oracle" in c["sample"]
+        for k in e["kernels"].values():
+            if k["lds_resident"]:
+                assert k["latency"]["bound"] == "latency"
+    # whole-job throughput = interior cells*steps of all shots / wall time
+    wl = bench.ElasticMarmousi
     units = wl.nz * wl.nx * wl.nt * wl.shots_per_gpu * d["steps"]
     assert abs(d["value"] - units / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6) <= 1e-6 * d["value"]
 
 
 def test_pmc_tool_knows_the_kernels_the_bench_runs():
-    """tools/pmc_traffic.py maps kernel-name prefixes to bench labels: every prefix must match a kernel
-    of the committed kernel-trace summary, and the traffic file must cover both workloads."""
+    """tools/pmc_traffic.py maps kernel names to bench labels by regular expression: every time-loop kernel of
+    the committed kernel-trace summaries must fall under exactly one label of its physics, set-up kernels
+    under none."""
     import csv
+    import re
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_traffic
-    names = [r["Name"].replace("void ", "").replace("(anonymous namespace)::", "")
-             for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_bench_default_kernel_stats.csv")))]
-    for pre in pmc_traffic.KERNELS:
-        assert any(n.startswith(pre) for n in names), pre
-    with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-        t = json.load(fh)
-    for wl in (bench.AcousticMarmousi, bench.ElasticMarmousi):
-        assert set(t[wl.name]) == {"forward+save", "adjoint+imaging"}
-        for rec in t[wl.name].values():
-            assert 0 < rec["bytes_per_cell_step"] < 80.0      # below the algorithmic figures of SURVEY 8d
+    seen = {}
+    for fname in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if not fname.endswith("kernel_stats.csv"):
+            continue
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fname))):
+            seen[pmc_traffic.clean(r["Name"])] = fname
+    assert any(n.startswith("el_cluster_adj<") for n in seen) and any(n.startswith("ac_cluster<2,") for n in seen)
+    for n in seen:
+        phys = "acoustic" if n.startswith("ac_") else "elastic" if n.startswith("el_") else None
+        if phys is None:
+            continue
+        hits = [lab for lab, pats in pmc_traffic.LABELS[phys].items() if any(re.search(p, n) for p in pats)]
+        loop = re.match(r"(ac_cluster<[12],|ac_step<\d+, \d+, (true, false|false, true)>|el_cluster_fwd<true|el_cluster_adj<|"
+                        r"el_step_[vs]<\d+, \d+, true>|el_adj_[sv]$|el_fwd_fused<true|el_adj_fused)", n)
+        assert len(hits) == (1 if loop else 0), (n, hits)
+
+
+def test_gpus_without_a_launcher_starts_the_ranks_and_fails_loudly_when_one_fails():
+    """`bench.py --gpus 2` with WORLD_SIZE unset spawns two ranks before touching the GPU; here (no GPU) every rank
+    exits with an error and the parent must report it with a non-zero exit code instead of printing a line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--device-index", "0", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        assert res.returncode == 0 and json.loads(res.stdout.strip().splitlines()[-1])["n_gpus"] == 2
+    else:
+        assert res.returncode != 0 and "exited with code" in res.stderr and "n_gpus" not in res.stdout
+    # a launcher-provided world that disagrees with --gpus is an error, not a silent one-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "--gpus 4 but WORLD_SIZE=1" in res.stderr
 
 
 def test_xcd_tile_order_is_a_bijection_with_contiguous_runs():

@@ -67,6 +67,98 @@ def test_c2_acoustic_both_kernel_families_agree_and_are_deterministic(monkeypatc
     assert rel_l2(outs[0][2].cpu().numpy(), outs[2][2].cpu().numpy()) <= 2e-5
 
 
+@pytest.mark.parametrize("ns,nt", [(2, 300), (29, 120)])
+def test_c2_acoustic_full_grid_vs_oracle(oracle32, ns, nt):
+    """BASELINE config 2's grid (174x500 + 20-cell sponge = 214x540, 500 receivers per shot) through the
+    plan the product picks by itself (single-launch time loop: many thin slabs for 2 shots, the 8-slab
+    layout of the bench for 29) against the C oracle: traces bit for bit, gradients <= 2e-5."""
+    from physicsbasedfwi2_amd.acoustic import AcousticPlan
+    from oracle import helpers as H
+    case = acoustic_case(seed=47, n0=174, n1=500, nb=20, nt=nt, ns=ns, nrec=500)
+    # the acquisition of networks.py:5339-5355: sources and the 500 receivers on the top row of the model
+    case["sc"], case["sw"] = H.cell_taps(np.full((ns, 1), 20), 20 + np.linspace(0, 499, ns).astype(int)[:, None], 540)
+    case["rc"], case["rw"] = H.cell_taps(np.full((ns, 500), 20), np.tile(20 + np.arange(500), (ns, 1)), 540)
+    assert AcousticPlan(214, 540, nt, ns, 1, 500, 1, 1.0, 1.0, 0).cluster_slabs() >= 1
+    o = oracle32
+    rec_o, G_o = o.acoustic_forward(case["r"], case["q0"], case["q1"], case["f"], case["sc"], case["sw"],
+                                    case["rc"], case["rw"], case["c0"], case["c1"], save=True)
+    r, f, rec = _acoustic(case)
+    rec_h = rec.detach().cpu().numpy()
+    for s in range(ns):
+        assert np.abs(rec_o[:, s]).max() > 0
+    assert np.abs(rec_h - rec_o).max() == 0.0
+    g = np.sign(rec_o).astype(np.float32)
+    rec.backward(torch.tensor(g, device=DEV))
+    gr_o, gf_o = o.acoustic_backward(case["r"], case["q0"], case["q1"], case["sc"], case["sw"], case["rc"],
+                                     case["rw"], g, G_o, case["c0"], case["c1"])
+    assert rel_l2(r.grad.cpu().numpy(), gr_o) <= 2e-5
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 2e-5
+
+
+def _seam_case(ns=2, nt=40, nz=1000, nx=3000, fw=10):
+    """BASELINE config 5's grid and set-up (networks.py:9638, 9792-9811: 1000x3000, h = 30 m, dt = 2.5 ms,
+    FREE_SURF = 1, C-PML on the other three sides) with a time axis the oracle finishes in seconds.  In 40
+    steps a wave travels a few cells, so the acquisition is packed around the sources: shot 0 under the
+    free surface (source at 180 m depth as in the reference, receivers ON the surface row and ten rows
+    down), shot 1 in the bottom-left corner inside both C-PML strips."""
+    from oracle import helpers as H
+    rng = np.random.default_rng(7)
+    h, dt = 30.0, 0.0025
+    vp = 1500.0 + 3000.0 * np.linspace(0, 1, nz)[:, None] + 50.0 * rng.standard_normal((nz, nx))
+    vs = vp / np.sqrt(3.0)
+    rho = 310.0 * vp ** 0.25
+    vs[:20] = 0.0; vp[:20] = 1500.0; rho[:20] = 1000.0
+    mat = H.elastic_materials(vp, vs, rho, dt, h, free_surface=True)
+    pz = H.cpml_profiles(nz, fw, h, dt, 1500.0, 5.0, lo=False)
+    px = H.cpml_profiles(nx, fw, h, dt, 1500.0, 5.0)
+    f = np.zeros((nt, ns, 1))
+    f[:, :, 0] = (H.ricker_deepwave(20.0, nt, dt, 0.02) * 1e6)[:, None] * (1.0 + 0.25 * np.arange(ns))[None]
+    xs = np.arange(1440, 1563, 3)
+    sz, sx = [[6]], [[1500]]
+    rz, rx = [np.r_[np.zeros(41, int), np.full(41, 10)]], [np.r_[xs, xs]]
+    if ns > 1:
+        sz.append([nz - 7]); sx.append([5])
+        xc = np.arange(2, 84, 2)
+        rz.append(np.r_[np.full(41, nz - 4), np.full(41, nz - 12)]); rx.append(np.r_[xc, xc])
+    sc, sw = H.cell_taps(np.array(sz), np.array(sx), nx)
+    rc, rw = H.cell_taps(np.array(rz), np.array(rx), nx)
+    return dict(mat=mat, pz=pz, px=px, f=f, sc=sc, sw=sw, rc=rc, rw=rw, fw=fw)
+
+
+def test_c5_seam_grid_free_surface_vs_oracle(oracle32):
+    """1000x3000 with the free surface, one launch per half step (no LDS-resident plan at this size):
+    seismograms bit for bit, the five material gradients and the source gradient <= 2e-5 against
+    oracle/elastic.c."""
+    from physicsbasedfwi2_amd import elastic
+    from physicsbasedfwi2_amd.elastic import ElasticPlan
+    c = _seam_case()
+    nt, ns = c["f"].shape[:2]
+    pl = ElasticPlan(1000, 3000, nt, ns, 1, c["rc"].shape[1], 1, c["fw"], 0, 0, 1)
+    assert pl.cluster_slabs(False) == 0 and pl.cluster_slabs(True) == 0
+    o = oracle32
+    ovx, ovz, S = o.elastic_forward(c["mat"], c["pz"], c["px"], c["f"], c["sc"], c["sw"], c["rc"], c["rw"],
+                                    save=True, free_surface=1)
+    dev = torch.device(DEV)
+    mat = torch.tensor(c["mat"], dtype=torch.float32, device=dev, requires_grad=True)
+    f = torch.tensor(c["f"], dtype=torch.float32, device=dev, requires_grad=True)
+    rvx, rvz = elastic.propagate(mat, f, torch.tensor(c["pz"]), torch.tensor(c["px"]), torch.tensor(c["sc"]),
+                                 torch.tensor(c["sw"]), torch.tensor(c["rc"]), torch.tensor(c["rw"]), c["fw"],
+                                 free_surface=True)
+    hx, hz = rvx.detach().cpu().numpy(), rvz.detach().cpu().numpy()
+    for s in range(ns):                                   # every shot records something on both components
+        assert np.abs(ovx[:, s]).max() > 0 and np.abs(ovz[:, s]).max() > 0
+    assert np.abs(hx - ovx).max() == 0.0 and np.abs(hz - ovz).max() == 0.0
+    gx, gz = np.sign(ovx).astype(np.float32), np.sign(ovz).astype(np.float32)
+    torch.autograd.backward([rvx, rvz], [torch.tensor(gx, device=dev), torch.tensor(gz, device=dev)])
+    gm_o, gf_o = o.elastic_backward(c["mat"], c["pz"], c["px"], c["sc"], c["sw"], c["rc"], c["rw"], gx, gz, S,
+                                    free_surface=1)
+    del S
+    gm_h = mat.grad.cpu().numpy()
+    for k in range(5):
+        assert np.abs(gm_o[k]).max() > 0 and rel_l2(gm_h[k], gm_o[k]) <= 2e-5, k
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 2e-5
+
+
 def test_c3_elastic_full_grid_vs_oracle(oracle32):
     case = elastic_case(seed=43, nz=100, nx=300, fw=10, ns=4, nrec=276, nt=160)
     o = oracle32

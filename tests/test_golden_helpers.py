@@ -129,3 +129,39 @@ def test_gaussian_smooth_matches_scipy_and_device_conditioning_matches_host():
     dev = C.condition_elastic_gradients_on_device(*(torch.tensor(a) for a in gs), *(torch.tensor(a) for a in (vp, vs, rho)))
     for a, b in zip(host, dev):
         assert torch.allclose(a, b, rtol=1e-6, atol=0)
+
+
+def test_shuffle_and_pick_reproduces_the_seeded_permutation(golden_dir):
+    """networks.py:5434-5461: `idx = torch.randperm(num_shots)` permutes x_s, the observed data and the
+    direct wave, then batch `it` is the strided pick `[it::num_batches]`.  Under the RNG state the fixture
+    was minted with (torch.manual_seed(1234) followed by the three randn draws of make_golden.py:111-113)
+    `conditioning.shuffle_and_pick` returns the fixture's permutation bit for bit, and its `picked` list is
+    what the reference's two-stage indexing selects."""
+    from physicsbasedfwi2_amd import conditioning as C
+    g = _g(golden_dir, "prop_expressions.npz")
+    nt, ns, nr = g["obs"].shape
+    nb = int(g["num_batches"])
+    torch.manual_seed(1234)
+    obs = torch.randn(nt, ns, nr)
+    pred = torch.randn(nt, ns, nr)
+    cte = 0.3 * torch.randn(nt, ns, nr)
+    assert np.array_equal(obs.numpy(), g["obs"]) and np.array_equal(pred.numpy(), g["pred"])
+    assert np.array_equal(cte.numpy(), g["cte"])
+    idx, picked = C.shuffle_and_pick(ns, nb, it=0)
+    assert idx.dtype == torch.int64 and np.array_equal(idx.numpy(), g["idx"])
+    assert sorted(idx.tolist()) == list(range(ns))
+    # the reference's own two-stage selection (shuffle everything, then stride)
+    x_s = torch.zeros(ns, 1, 2)
+    x_s[:, 0, 1] = torch.linspace(0, 1990.0, ns)
+    x_s_shuf = x_s.view(-1, 2)[idx].view(x_s.size())
+    for it in range(nb):
+        _, pk = torch.manual_seed(1234), None
+        torch.randn(nt, ns, nr), torch.randn(nt, ns, nr), torch.randn(nt, ns, nr)
+        idx2, pk = C.shuffle_and_pick(ns, nb, it=it)
+        assert torch.equal(idx2, idx) and torch.equal(pk, idx[it::nb])
+        assert torch.equal(x_s_shuf[it::nb], x_s[pk])
+        assert torch.equal(obs[:, idx, :][:, it::nb], obs[:, pk, :])
+    # a private generator gives the same stream as the global one seeded alike
+    gen = torch.Generator().manual_seed(77)
+    torch.manual_seed(77)
+    assert torch.equal(C.shuffle_and_pick(18, 2, generator=gen)[0], torch.randperm(18))

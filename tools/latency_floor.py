@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Latency floor of the single-launch (LDS-resident) time-loop kernels: the same kernels built with
+-DMIFWI_ABLATIONS and run with the halo hand-off and the snapshot stream switched off (MIFWI_*_CL_DBG=3;
+wrong results, timing only).  What remains is the chain of barrier-separated LDS phases of a step - the
+bound these kernels can be measured against (bench.py `latency`).  Run on the GPU box:
+
+    python tools/latency_floor.py            ->  profiles/r02_latency_floor.json
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from physicsbasedfwi2_amd import build  # noqa: E402
+
+
+def main():
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, "libmifwi_ablations.so")
+    build.build(out=lib, extra_flags=["-DMIFWI_ABLATIONS"])
+    doc = {"csrc_sha16": bench.csrc_sha16(),
+           "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True,
+                                    text=True).stdout.strip() or os.environ.get("GRAFT_COMMIT", ""),
+           "how": "bench.py --steps 3 --warmup 1 --no-verify with -DMIFWI_ABLATIONS, MIFWI_EL_CL_DBG=3 / MIFWI_AC_CL_DBG=3 "
+                  "(no halo hand-off, no snapshot stores)"}
+    for wl in ("elastic_marmousi", "acoustic_marmousi"):
+        env = dict(os.environ, MIFWI_LIB=lib, MIFWI_EL_CL_DBG="3", MIFWI_AC_CL_DBG="3")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", "3", "--warmup", "1",
+               "--no-cpu-baseline", "--no-also", "--no-verify"]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        if res.returncode != 0:
+            raise SystemExit("ablation run of %s failed:\n%s" % (wl, res.stderr[-2000:]))
+        line = json.loads(res.stdout.strip().splitlines()[-1])
+        key = "%s_%dx%d" % (wl.split("_")[0], *line["config"]["grid"])
+        doc[key] = {lab: {"floor_s_per_step": k["avg_step_s"]} for lab, k in line["kernels"].items()
+                    if k["lds_resident"]}
+    path = os.path.join(ROOT, "profiles", bench.PROFILE_ROUND + "_latency_floor.json")
+    if len(sys.argv) > 1:
+        path = sys.argv[1]
+    with open(path, "w") as fh:
+        json.dump(doc, fh, indent=1, sort_keys=True)
+    print(json.dumps(doc, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

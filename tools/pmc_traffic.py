@@ -1,26 +1,45 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 0` (one with FETCH_SIZE, one with
-WRITE_SIZE; --output-format csv) into profiles/r01_pmc_traffic.json: HBM bytes per cell-step of the
-time-loop kernels, 2 x FETCH_SIZE + WRITE_SIZE (both in KiB; FETCH_SIZE counts 64 B per 128-B
-request on gfx950 - MI355X_MICROARCH.md, section HBM).
-usage: pmc_traffic.py FETCH_DIR WRITE_DIR OUT.json
+"""Turn two rocprofv3 --pmc passes of ONE bench workload (one pass with FETCH_SIZE, one with WRITE_SIZE;
+--output-format csv; `bench.py --workload W [--grid G --nt N --shots S] --steps 1 --warmup 0 --no-cpu-baseline
+--no-also --no-verify`) into an entry of profiles/<round>_pmc_traffic.json: measured HBM bytes per INTERIOR
+cell-step of the forward(+save) and adjoint(+imaging) time loops = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 /
+(interior cells x steps) - FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, section HBM).
+A time loop may be one launch (single-launch kernels) or many (two launches per step, a few shots per pass):
+all launches of the label's kernels are summed.  The file carries the fingerprint of the kernel sources;
+bench.py quotes it only while the fingerprint matches.
+
+usage: pmc_traffic.py FETCH_DIR WRITE_DIR OUT.json --workload W [--grid NZxNX] [--nt N] [--shots S]
 """
+import argparse
 import csv
 import glob
 import json
 import os
+import re
+import subprocess
 import sys
 from collections import defaultdict
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-KERNELS = {   # kernel-name prefix -> (workload class, bench kernel label)
-    "ac_cluster<1,": (bench.AcousticMarmousi, "forward+save"),
-    "ac_cluster<2,": (bench.AcousticMarmousi, "adjoint+imaging"),
-    "el_cluster_fwd<true": (bench.ElasticMarmousi, "forward+save"),
-    "el_cluster_adj<": (bench.ElasticMarmousi, "adjoint+imaging"),
+# label -> regexes on the kernel name (namespace and "void " stripped).  SAVE = true instantiations only: the
+# observed-data forward run of the bench set-up (SAVE = false) is not part of the gradient pass.
+LABELS = {
+    "acoustic": {
+        "forward+save": [r"^ac_cluster<1,", r"^ac_step<\d+, \d+, true, false>"],
+        "adjoint+imaging": [r"^ac_cluster<2,", r"^ac_step<\d+, \d+, false, true>"],
+    },
+    "elastic": {
+        "forward+save": [r"^el_cluster_fwd<true", r"^el_step_v<\d+, \d+, true>", r"^el_step_s<\d+, \d+, true>",
+                         r"^el_fwd_fused<true"],
+        "adjoint+imaging": [r"^el_cluster_adj<", r"^el_adj_s\b", r"^el_adj_v\b", r"^el_adj_fused\b"],
+    },
 }
+
+
+def clean(name):
+    return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
 
 
 def totals(path, counter):
@@ -30,28 +49,58 @@ def totals(path, counter):
         raise SystemExit("no counter_collection.csv under " + path)
     for f in files:
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter:
-                continue
-            name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
-            for pre in KERNELS:
-                if name.startswith(pre):
-                    acc[pre] += float(r["Counter_Value"])
+            if r["Counter_Name"] == counter:
+                acc[clean(r["Kernel_Name"])] += float(r["Counter_Value"])
     return acc
 
 
-if __name__ == "__main__":
-    fetch, write = totals(sys.argv[1], "FETCH_SIZE"), totals(sys.argv[2], "WRITE_SIZE")
-    out = {}
-    for pre, (cls, label) in KERNELS.items():
-        if pre not in fetch and pre not in write:
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_dir")
+    ap.add_argument("write_dir")
+    ap.add_argument("out")
+    ap.add_argument("--workload", required=True, choices=sorted(bench.WORKLOADS))
+    ap.add_argument("--grid", default="")
+    ap.add_argument("--nt", type=int, default=0)
+    ap.add_argument("--shots", type=int, default=0)
+    a = ap.parse_args()
+    cls = bench.WORKLOADS[a.workload]
+    nz, nx = (int(v) for v in a.grid.lower().split("x")) if a.grid else (cls.nz, cls.nx)
+    nt, ns = a.nt or cls.nt, a.shots or cls.shots_per_gpu
+    physics = a.workload.split("_")[0]
+    key = "%s_%dx%d%s" % (physics, nz, nx, "_fs" if getattr(cls, "free_surface", False) else "")
+    fetch, write = totals(a.fetch_dir, "FETCH_SIZE"), totals(a.write_dir, "WRITE_SIZE")
+    try:
+        with open(a.out) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        doc = {}
+    sha = bench.csrc_sha16()
+    if doc.get("csrc_sha16") != sha:
+        doc = {}                                    # entries of other kernels do not mix with these
+    doc["csrc_sha16"] = sha
+    doc["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                   cwd=bench.ROOT).stdout.strip() or doc.get("commit", "")
+    entry = {}
+    for label, pats in LABELS[physics].items():
+        names = sorted(n for n in set(fetch) | set(write) if any(re.search(p, n) for p in pats))
+        if not names:
             continue
-        P = cls.pml if cls is bench.AcousticMarmousi else 0
-        cells = (cls.nz + 2 * P) * (cls.nx + 2 * P) * cls.shots_per_gpu
-        steps = cls.nt
-        rd, wr = 2.0 * fetch.get(pre, 0.0) * 1024.0, write.get(pre, 0.0) * 1024.0
-        out.setdefault(cls.name, {})[label] = {
-            "kernel": pre, "read_bytes": rd, "write_bytes": wr,
-            "bytes_per_cell_step": (rd + wr) / (cells * steps),
-            "note": "one pass of the time loop over all shots; 2*FETCH_SIZE + WRITE_SIZE (KiB counters)"}
-    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
-    print(json.dumps(out, indent=1, sort_keys=True))
+        rd = sum(2.0 * 1024.0 * fetch.get(n, 0.0) for n in names)
+        wr = sum(1024.0 * write.get(n, 0.0) for n in names)
+        entry[label] = {"kernels": names, "read_bytes": rd, "write_bytes": wr,
+                        "bytes_per_cell_step": (rd + wr) / (float(nz) * nx * ns * nt),
+                        "read_bytes_per_cell_step": rd / (float(nz) * nx * ns * nt),
+                        "write_bytes_per_cell_step": wr / (float(nz) * nx * ns * nt),
+                        "units": "%d x %d interior cells x %d shots x %d steps, one gradient pass" % (nz, nx, ns, nt),
+                        "note": "2*FETCH_SIZE + WRITE_SIZE (KiB counters), all launches of these kernels"}
+    if not entry:
+        raise SystemExit("no time-loop kernel of %s found in the counter files" % a.workload)
+    doc[key] = entry
+    with open(a.out, "w") as fh:
+        json.dump(doc, fh, indent=1, sort_keys=True)
+    print(json.dumps({key: entry}, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
