@@ -174,7 +174,7 @@ typedef struct {
     int32_t snapshot_format; /* MIFWI_SNAPSHOT_F32 (exact discrete adjoint) or MIFWI_SNAPSHOT_BF16: the five
                                 forward snapshot planes are rounded to bf16 on their way to memory (10 instead of
                                 20 B per cell-step each way, twice the steps per checkpoint segment; material
-                                gradients within 2e-3 rel-L2 of the f32 form, seismograms unchanged) - the
+                                gradients within 4e-3 rel-L2 of the f32 form in the worst case, seismograms unchanged) - the
                                 counterpart of the wavefield compression / decimation DENISE and deepwave apply to
                                 their stored fields.  Honoured by plans that run the per-step
                                 kernels; single-launch plans keep f32 (layout.snapshot_format says which).     */

@@ -19,15 +19,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
 
+def _sanitized():
+    """ORACLE_ASAN=1: load the AddressSanitizer + UBSan builds (`make -C oracle asan`; the interpreter must have
+    been started with libasan preloaded - tools/cpu_suite_asan.sh does both)."""
+    return os.environ.get("ORACLE_ASAN", "0") == "1"
+
+
 def build(force=False):
     """Compile the C oracle (gcc).  Building the checker is not using it."""
-    want = [os.path.join(_HERE, "liboracle_f32.so"), os.path.join(_HERE, "liboracle_f64.so")]
+    sfx = "_asan" if _sanitized() else ""
+    want = [os.path.join(_HERE, "liboracle_f32%s.so" % sfx), os.path.join(_HERE, "liboracle_f64%s.so" % sfx)]
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
     stale = force or any(
         (not os.path.exists(w)) or any(os.path.getmtime(s) > os.path.getmtime(w) for s in srcs)
         for w in want)
     if stale:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", "asan" if sfx else "all"], stdout=subprocess.DEVNULL)
     return want
 
 
@@ -47,7 +54,7 @@ class Oracle:
         self.precision = precision
         self.dtype = np.float32 if precision == "f32" else np.float64
         self.creal = ctypes.c_float if precision == "f32" else ctypes.c_double
-        self.lib = ctypes.CDLL(os.path.join(_HERE, "liboracle_%s.so" % precision))
+        self.lib = ctypes.CDLL(os.path.join(_HERE, "liboracle_%s%s.so" % (precision, "_asan" if _sanitized() else "")))
         assert self.lib.oracle_real_bytes() == np.dtype(self.dtype).itemsize
         self.AcCfg = _cfg_struct(self.creal)
 

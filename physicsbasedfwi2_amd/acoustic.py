@@ -162,6 +162,9 @@ class _AcousticFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_rec):
         lib = _lib.load()
+        if ctx.plan is None:
+            raise MifwiError("backward through the acoustic propagator was called twice: the forward snapshots "
+                             "(or checkpoints) are freed by the first call - run the forward again")
         r_p, q0_d, q1_p, f_d = ctx.saved_tensors
         plan, geom = ctx.plan, ctx.geom
         lay = plan.layout
@@ -211,6 +214,7 @@ class _AcousticFn(torch.autograd.Function):
                         *common, _lib.ptr(snap), b, _lib.ptr(grad_r), _lib.ptr(grad_f),
                         _lib.ptr(work), k_hi, k_lo, flags, _stream()))
             plan.close()
+            ctx.plan = None
             ctx.snap = None
             ctx.ckpt = None
         return (grad_r[:, :n1].contiguous(), grad_f, None, None, None, None, None, None, None, None)

@@ -515,6 +515,9 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     const int xcd = L & 7, k = L >> 3;
     const int w = k % p.NW, s = p.shot0 + xcd + 8 * (k / p.NW);
     if (s >= p.shot1) return;
+    // ablation builds only: slab 1 of the first shot never shows up (a workgroup that was not resident in time) -
+    // its neighbours must time out, publish the error word and let the host fall back
+    if ((kDbg(p) & 64) && w == 1 && s == p.shot0) return;
     const int t = (int)threadIdx.x;
     constexpr bool adj = (MODE == 2);
     int r0, R;
@@ -894,9 +897,12 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
 #pragma unroll
                 for (int kk = 0; kk < kGr; ++kk)
                     if (rcv_lo[kk] >= 0) ok = ok && (unsigned)(v[kk] >> 32) == epoch;
-                if (ok) break;
+                if (ok || failed) break;            // once failed: one pass per step, garbage forward until the check
                 if (spins > kClMaxSpin ||
                     ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    // publish at once: every other workgroup of the launch bails within 256 spins instead of
+                    // running into its own time-out, one hand-off after the other
+                    if (spins > kClMaxSpin) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     failed = true;
                     break;
                 }
@@ -1084,7 +1090,7 @@ ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const flo
 template <int MODE>
 int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStream_t st)
 {
-    if (mifwi::fake_timeout()) return mifwi::kClusterTimedOut;
+    if (mifwi::fake_timeout() == 1) return mifwi::kClusterTimedOut;
     MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
     for (int s0 = 0; s0 < pl->d.nshot; s0 += pl->cl_shots) {
         c.shot0 = s0;
@@ -1102,19 +1108,24 @@ int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStrea
     int err = 0;
     MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
     MIFWI_HIP_TRY(hipStreamSynchronize(st));
-    return err != 0 ? mifwi::kClusterTimedOut : MIFWI_OK;
+    return (err != 0 || mifwi::fake_timeout() == 2) ? mifwi::kClusterTimedOut : MIFWI_OK;
 }
 
-// outcome of a single-launch attempt: done (return rc), or fall back to one launch per step
-bool cluster_done(int rc, int32_t flags, int *out)
+// A single-launch attempt may time out (some workgroup was not resident in time) after it has advanced the state by
+// an unknown number of steps.  A call that starts from the zero state is simply zeroed again; a resumed call (time
+// checkpointing) keeps a copy of its input state behind the work buffer's other regions and gets it back.  Either
+// way the per-step family then runs the range.
+int cluster_backup(float *work, long long state_elems, float *backup, int32_t flags, hipStream_t st)
 {
-    if (rc != mifwi::kClusterTimedOut) { *out = rc; return true; }
-    if (!(flags & MIFWI_ZERO_STATE)) {
-        *out = mifwi::fail(MIFWI_EHIP, "single-launch time loop: a halo hand-off timed out (not every workgroup was "
-                           "resident in time) on a resumed call; set MIFWI_AC_CLUSTER=0 to use one launch per step");
-        return true;
-    }
-    return false;                          // caller re-zeroes the state and runs the per-step family
+    if (flags & MIFWI_ZERO_STATE) return MIFWI_OK;
+    MIFWI_HIP_TRY(hipMemcpyAsync(backup, work, sizeof(float) * state_elems, hipMemcpyDeviceToDevice, st));
+    return MIFWI_OK;
+}
+int cluster_restore(float *work, long long state_elems, const float *backup, int32_t flags, hipStream_t st)
+{
+    if (flags & MIFWI_ZERO_STATE) MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * state_elems, st));
+    else MIFWI_HIP_TRY(hipMemcpyAsync(work, backup, sizeof(float) * state_elems, hipMemcpyDeviceToDevice, st));
+    return MIFWI_OK;
 }
 
 }  // namespace
@@ -1241,8 +1252,10 @@ int mifwi_acoustic_plan_layout(const mifwi_acoustic_plan *pl, mifwi_acoustic_lay
     out->coef_elems = pl->coef_elems;
     const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
     const long long cl = pl->cluster ? pl->xbuf_elems + pl->list_elems : 0;
-    out->work_forward_elems = 2 * pl->field_elems + bbox + cl;
-    out->work_backward_elems = 2 * pl->field_elems + pl->ngroups * pl->coef_elems + bbox + cl;
+    // single-launch plans: room for a copy of the input state of a resumed call (cluster_backup)
+    out->work_forward_elems = 2 * pl->field_elems + bbox + cl + (pl->cluster ? 2 * pl->field_elems : 0);
+    out->work_backward_elems = 2 * pl->field_elems + pl->ngroups * pl->coef_elems + bbox + cl +
+                               (pl->cluster ? 2 * pl->field_elems + pl->ngroups * pl->coef_elems : 0);
     return MIFWI_OK;
 }
 
@@ -1284,9 +1297,13 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *pl, const float *r, const float 
         c.src_cell = src_cell; c.src_w = src_w; c.f = f;
         c.rec_cell = rec_cell; c.rec_w = rec_w; c.rec_out = (rec_out && d.nrec > 0) ? rec_out : nullptr;
         c.G = snap; c.g_first = n_begin; c.g_step = snap_step;
-        int out = 0;
-        if (cluster_done(snap ? cluster_run<1>(pl, c, xbuf, st) : cluster_run<0>(pl, c, xbuf, st), flags, &out)) return out;
-        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * 2 * pl->field_elems, st));
+        float *backup = xbuf + pl->xbuf_elems + pl->list_elems;
+        rc = cluster_backup(work, 2 * pl->field_elems, backup, flags, st);
+        if (rc) return rc;
+        rc = snap ? cluster_run<1>(pl, c, xbuf, st) : cluster_run<0>(pl, c, xbuf, st);
+        if (rc != mifwi::kClusterTimedOut) return rc;
+        rc = cluster_restore(work, 2 * pl->field_elems, backup, flags, st);
+        if (rc) return rc;
     }
     // shot groups are independent: a few at a time keep wavefields and model inside the Infinity Cache
     for (int g0 = 0; g0 < pl->ngroups; g0 += pl->pass_fwd)
@@ -1336,9 +1353,13 @@ int mifwi_acoustic_born(mifwi_acoustic_plan *pl, const float *r, const float *q0
         c.rec_cell = rec_cell; c.rec_w = rec_w; c.rec_out = d.nrec > 0 ? drec_out : nullptr;
         c.G = const_cast<float *>(snap); c.g_first = snap_first; c.g_step = snap_step;
         c.born_dr = dr;
-        int out = 0;
-        if (cluster_done(cluster_run<3>(pl, c, xbuf, st), flags, &out)) return out;
-        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * 2 * pl->field_elems, st));
+        float *backup = xbuf + pl->xbuf_elems + pl->list_elems;
+        rc = cluster_backup(work, 2 * pl->field_elems, backup, flags, st);
+        if (rc) return rc;
+        rc = cluster_run<3>(pl, c, xbuf, st);
+        if (rc != mifwi::kClusterTimedOut) return rc;
+        rc = cluster_restore(work, 2 * pl->field_elems, backup, flags, st);
+        if (rc) return rc;
     }
     AcParams p = base_params(pl, r, q0, q1);
     p.ninj = 0;
@@ -1409,13 +1430,17 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
         c.G = const_cast<float *>(snap); c.g_first = snap_first; c.g_step = snap_step;
         c.acc = acc;
         c.slab_cnt = lists; c.slab_list = lists + (long long)d.nshot * pl->NW;
-        int out = 0;
-        if (cluster_done(cluster_run<2>(pl, c, xbuf, st), flags, &out)) {
-            if (out) return out;
-            per_step = false;
+        const long long state = 2 * pl->field_elems + pl->ngroups * pl->coef_elems;     // adjoint fields + accumulators
+        float *backup = reinterpret_cast<float *>(lists) + pl->list_elems;
+        rc = cluster_backup(work, state, backup, flags, st);
+        if (rc) return rc;
+        rc = cluster_run<2>(pl, c, xbuf, st);
+        if (rc == mifwi::kClusterTimedOut) {
+            rc = cluster_restore(work, state, backup, flags, st);
+            if (rc) return rc;
         } else {
-            MIFWI_HIP_TRY(hipMemsetAsync(
-                work, 0, sizeof(float) * (2 * pl->field_elems + pl->ngroups * pl->coef_elems), st));
+            if (rc) return rc;
+            per_step = false;
         }
     }
     for (int g0 = 0; per_step && g0 < pl->ngroups; g0 += pl->pass_adj)

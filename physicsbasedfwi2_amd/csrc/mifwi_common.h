@@ -35,15 +35,17 @@ inline int fail(int code, const char *fmt, ...)
     } while (0)
 
 // Internal status of a single-launch time loop whose hand-off timed out (some workgroups were not
-// resident in time, e.g. another stream held CUs for a long kernel).  A call that started from a zero
-// state is then simply re-run with one launch per step; a resumed call cannot be (its input state has
-// been overwritten) and reports MIFWI_EHIP.
+// resident in time, e.g. another stream held CUs for a long kernel).  The call is then re-run with one
+// launch per (half) step: from the zero state when it started there, otherwise from the copy of its
+// input state that resumed calls keep (time checkpointing).
 constexpr int kClusterTimedOut = 1;
 
-inline bool fake_timeout()          // test hook: MIFWI_TEST_FAKE_TIMEOUT=1 exercises the fall-back on the host
+// test hook, read per call: MIFWI_TEST_FAKE_TIMEOUT=1 treats every single-launch attempt as timed out before it
+// runs, =2 after it has run (the state has been advanced and must really be restored)
+inline int fake_timeout()
 {
     const char *v = getenv("MIFWI_TEST_FAKE_TIMEOUT");
-    return v && *v == '1';
+    return (v && (*v == '1' || *v == '2')) ? *v - '0' : 0;
 }
 
 inline int check_device(int device)

@@ -131,20 +131,32 @@ __device__ __forceinline__ void bf_store1(float *base, unsigned grp, const float
     const mifwi_u2 v{bf_pack(a[0], a[1]), bf_pack(a[2], a[3])};
     __builtin_nontemporal_store(v, reinterpret_cast<mifwi_u2 *>(base) + grp);
 }
-__device__ __forceinline__ void bf_load2(const float *base, unsigned grp, float4 &a, float4 &b)
-{
-    const mifwi_u4 v = __builtin_nontemporal_load(reinterpret_cast<const mifwi_u4 *>(base) + grp);
-    a = make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
-    b = make_float4(bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w));
-}
-__device__ __forceinline__ void bf_load1(const float *base, unsigned grp, float4 &a)
-{
-    const mifwi_u2 v = __builtin_nontemporal_load(reinterpret_cast<const mifwi_u2 *>(base) + grp);
-    a = make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
-}
 // offsets (in floats) of the three regions of a bf16 shot-step
 __device__ __forceinline__ long long bf_reg_de(unsigned ncell) { return (long long)ncell; }
 __device__ __forceinline__ long long bf_reg_c(unsigned ncell) { return 2LL * ncell; }
+// The packed planes of one group.  Loading and widening are two steps: the loads are requested before a barrier
+// and consumed after it, and the widening must stay behind the barrier too (`bf_pin`) - scheduled in front of it,
+// the wave would sit out the latency of the snapshot stream, the one stream that always comes from HBM, before
+// every barrier (measured: el_adj_s 80 instead of 72 us per launch on 350x1700 although it reads 10 B less).
+struct BfPlanes { mifwi_u4 ab, de; mifwi_u2 c; };
+__device__ __forceinline__ void bf_request(const float *shot_base, unsigned ncell, unsigned grp, BfPlanes &q)
+{
+    q.ab = __builtin_nontemporal_load(reinterpret_cast<const mifwi_u4 *>(shot_base) + grp);
+    q.de = __builtin_nontemporal_load(reinterpret_cast<const mifwi_u4 *>(shot_base + bf_reg_de(ncell)) + grp);
+    q.c = __builtin_nontemporal_load(reinterpret_cast<const mifwi_u2 *>(shot_base + bf_reg_c(ncell)) + grp);
+}
+__device__ __forceinline__ void bf_pin(BfPlanes &q)
+{
+    asm volatile("" : "+v"(q.ab), "+v"(q.de), "+v"(q.c));
+}
+__device__ __forceinline__ void bf_widen(const BfPlanes &q, float4 &S1, float4 &S2, float4 &S3, float4 &S4, float4 &S5)
+{
+    S1 = make_float4(bf_lo(q.ab.x), bf_hi(q.ab.x), bf_lo(q.ab.y), bf_hi(q.ab.y));
+    S2 = make_float4(bf_lo(q.ab.z), bf_hi(q.ab.z), bf_lo(q.ab.w), bf_hi(q.ab.w));
+    S4 = make_float4(bf_lo(q.de.x), bf_hi(q.de.x), bf_lo(q.de.y), bf_hi(q.de.y));
+    S5 = make_float4(bf_lo(q.de.z), bf_hi(q.de.z), bf_lo(q.de.w), bf_hi(q.de.w));
+    S3 = make_float4(bf_lo(q.c.x), bf_hi(q.c.x), bf_lo(q.c.y), bf_hi(q.c.y));
+}
 
 // x-strip column offset of group g (or -1)
 __device__ __forceinline__ int xstrip(const ElParams &p, int g)
@@ -593,8 +605,9 @@ __device__ __forceinline__ void stage_E(const ElParams &p, int s, int j, int g, 
     E3 = make_float4(e3[0], e3[1], e3[2], e3[3]); E4 = make_float4(e4[0], e4[1], e4[2], e4[3]);
 }
 
-// S^T:  E = C^T sigma_bar through the transposed C-PML;  v_bar -= stencils(E);  v_bar += R^T g;
-//       all five material-gradient accumulators.
+// S^T:  E = C^T sigma_bar through the transposed C-PML;  v_bar -= stencils(E);  all five material-gradient
+//       accumulators.  (v_bar += R^T g has been applied to the state by el_inject_adjsrc, as the oracle does at
+//       the head of an adjoint step.)
 // Every global load of a shot (own group, halo group, adjoint velocities, the five snapshot planes) is
 // requested before the first use: one memory round trip per shot instead of three.
 template <bool BF16>
@@ -607,7 +620,6 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
         return;
     }
     __shared__ float E[4][ASZ][ASX];
-    __shared__ float inj[2 * ATZ * 4 * AGO];
     const int tile_j = by * ATZ;
     const int tile_g = bx * AGO;           // first owned group
     const unsigned fs = p.field_stride;
@@ -644,6 +656,9 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
         if (s >= p.nshot) break;
         float *fl = p.fields + (long long)s * p.shot_stride;
         float4 vxb = zero4, vzb = zero4, S1 = zero4, S2 = zero4, S3 = zero4, S4 = zero4, S5 = zero4;
+        BfPlanes packed;
+        packed.ab = packed.de = mifwi_u4{0u, 0u, 0u, 0u};
+        packed.c = mifwi_u2{0u, 0u};
         own.a = own.b = own.c = halo.a = halo.b = halo.c = zero4;
         if (own_ok) {
             own.a = ld4(fl + F_SXX * fs + oo); own.b = ld4(fl + F_SZZ * fs + oo); own.c = ld4(fl + F_SXZ * fs + oo);
@@ -652,7 +667,6 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
             halo.a = ld4(fl + F_SXX * fs + ho); halo.b = ld4(fl + F_SZZ * fs + ho); halo.c = ld4(fl + F_SXZ * fs + ho);
         }
         if (own_ok) { vxb = ld4(fl + F_VX * fs + oo); vzb = ld4(fl + F_VZ * fs + oo); }
-        const bool has_inj = stage_injection<ATZ, 4 * AGO, 2>(p, s, tile_j, 4 * tile_g, inj);
         // ---- stage E1..E4 on the tile + halo -------------------------------------------------
         if (p.fsurf && oj == 0) own.b = zero4;            // adjoint of szz(0,.) is discarded
         if (p.fsurf && hj == 0) halo.b = zero4;
@@ -675,10 +689,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
             S1 = mifwi::ldnt4(Sp); S2 = mifwi::ldnt4(Sp + (long long)ncell); S3 = mifwi::ldnt4(Sp + 2 * (long long)ncell);
             S4 = mifwi::ldnt4(Sp + 3 * (long long)ncell); S5 = mifwi::ldnt4(Sp + 4 * (long long)ncell);
         } else if (own_ok) {
-            const float *Sp = p.S + (long long)s * p.snap_shot;
-            bf_load2(Sp, occ >> 2, S1, S2);
-            bf_load2(Sp + bf_reg_de(ncell), occ >> 2, S4, S5);
-            bf_load1(Sp + bf_reg_c(ncell), occ >> 2, S3);
+            bf_request(p.S + (long long)s * p.snap_shot, ncell, occ >> 2, packed);
         }
         __syncthreads();
         // ---- stencils from LDS + injection + gradient accumulation ---------------------------
@@ -699,16 +710,16 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
                 const float dx4 = dbw(x4.v[c], x4.v[c + 1], x4.v[c + 2], x4.v[c + 3]);
                 float ax = comp(vxb, c) - (dx1 + dz3);
                 float az = comp(vzb, c) - (dz2 + dx4);
-                if (has_inj) {
-                    ax += inj[orow * 4 * AGO + 4 * ogrp + c];
-                    az += inj[ATZ * 4 * AGO + orow * 4 * AGO + 4 * ogrp + c];
-                }
                 if (4 * og + c >= p.nx) { ax = 0.f; az = 0.f; }
                 nvx[c] = ax; nvz[c] = az;
             }
             st4(fl + F_VX * fs + oo, make_float4(nvx[0], nvx[1], nvx[2], nvx[3]));
             st4(fl + F_VZ * fs + oo, make_float4(nvz[0], nvz[1], nvz[2], nvz[3]));
             // gradients (oracle order): Ms, Ls, mus from sigma_bar; bxs, bzs from the new v_bar
+            if (BF16) {
+                bf_pin(packed);
+                bf_widen(packed, S1, S2, S3, S4, S5);
+            }
 #define ACC3(dst, a, b, c_, d) dst = fmaf(a, b, fmaf(c_, d, dst))
             ACC3(acc[M_M].x, S1.x, bxx.x, S2.x, bzz.x); ACC3(acc[M_M].y, S1.y, bxx.y, S2.y, bzz.y);
             ACC3(acc[M_M].z, S1.z, bxx.z, S2.z, bzz.z); ACC3(acc[M_M].w, S1.w, bxx.w, S2.w, bzz.w);
@@ -722,7 +733,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
             acc[M_BZ].x = fmaf(S5.x, nvz[0], acc[M_BZ].x); acc[M_BZ].y = fmaf(S5.y, nvz[1], acc[M_BZ].y);
             acc[M_BZ].z = fmaf(S5.z, nvz[2], acc[M_BZ].z); acc[M_BZ].w = fmaf(S5.w, nvz[3], acc[M_BZ].w);
         }
-        __syncthreads();          // E and inj are reused by the next shot
+        __syncthreads();          // E is reused by the next shot
     }
     if (own_ok) {
 #pragma unroll
@@ -867,252 +878,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_v(const ElParams p)
     }
 }
 
-// ================================================================================================
-// fused forward step: V and S of one time step in ONE launch (large grids, HBM-bound regime).
-// A workgroup owns 16 rows x 64 cells.  It computes the new velocities on its tile plus a two-row /
-// one-group halo (recomputing what the neighbours also compute) into LDS, then the new stresses of its
-// tile from LDS.  Nothing is updated in place: a neighbour may still need the old value of a cell this
-// workgroup owns, so the launch reads one copy of the state (fields + C-PML memory variables) and
-// writes the other.  HBM traffic per cell-step: 40 B read + 20 B written (+20 B snapshot) instead of the
-// 61 + 21 B of the two-launch form; the arithmetic is the same fmaf chain, term by term.
-// Opt-in (MIFWI_EL_FUSED=1): on 1000x3000x16 shots it moves 86 instead of 102 B/cell but takes 0.80-0.84 ms
-// against 0.78 ms for the two launches - two workgroups per CU with a barrier in the middle keep fewer
-// loads in flight than twelve independent streaming waves.
-// Receivers sample the INPUT state, i.e. the velocities of the previous step (the driver shifts the output
-// row by one and samples the last step with a launch of its own).
-// ================================================================================================
-struct VIn {
-    float4 cxx, a0, a1, a2, a3, b0, b1, b2, b3, vx, vz, bx, bz;
-    float2 Lxx, Rxx, Lxz, Rxz;
-};
-
-__device__ __forceinline__ void v_load(const ElParams &p, const float *fl, int j, int g, VIn &in)
-{
-    const unsigned fs = p.field_stride;
-    const float *sxx = fl + F_SXX * fs, *szz = fl + F_SZZ * fs, *sxz = fl + F_SXZ * fs;
-    const unsigned o = (unsigned)(j + 2) * p.pitch + 4 + 4 * g;
-    const unsigned cc = (unsigned)j * p.gp + 4 * g;
-    const unsigned ncell = (unsigned)p.nz * p.gp;
-    in.a0 = ld4(sxz + o - 2 * p.pitch); in.a1 = ld4(sxz + o - p.pitch);
-    in.a2 = ld4(sxz + o); in.a3 = ld4(sxz + o + p.pitch);
-    in.b0 = ld4(szz + o - p.pitch); in.b1 = ld4(szz + o);
-    in.b2 = ld4(szz + o + p.pitch); in.b3 = ld4(szz + o + 2 * p.pitch);
-    in.cxx = ld4(sxx + o); in.Lxx = ld2(sxx + o - 2); in.Rxx = ld2(sxx + o + 4);
-    in.Lxz = ld2(sxz + o - 2); in.Rxz = ld2(sxz + o + 4);
-    in.vx = ld4(fl + F_VX * fs + o); in.vz = ld4(fl + F_VZ * fs + o);
-    in.bx = ld4(p.mat + M_BX * ncell + cc); in.bz = ld4(p.mat + M_BZ * ncell + cc);
-}
-
-// the V update of el_step_v on one group; memory variables read from psi*, written (owner only) to psi*_out
-__device__ __forceinline__ void v_update(const ElParams &p, int s, int j, int g, VIn &in, bool mine,
-                                         float4 &vxn, float4 &vzn, float4 &s4o, float4 &s5o)
-{
-    {
-        // free surface, odd mirroring about row 0: sxz(-m) = -sxz(m-1), szz(-m) = -szz(m).  Component-wise
-        // selects: a select between whole float4 values sends the struct to scratch memory
-        const bool m0 = p.fsurf && j == 0, m1 = p.fsurf && j == 1;
-#define MIFWI_SEL(dst, c, v) dst.x = (c) ? -(v).x : dst.x; dst.y = (c) ? -(v).y : dst.y; \
-                             dst.z = (c) ? -(v).z : dst.z; dst.w = (c) ? -(v).w : dst.w
-        MIFWI_SEL(in.a0, m1, in.a1);
-        MIFWI_SEL(in.a0, m0, in.a3);
-        MIFWI_SEL(in.a1, m0, in.a2);
-        MIFWI_SEL(in.b0, m0, in.b2);
-#undef MIFWI_SEL
-    }
-    const float xx[8] = {in.Lxx.x, in.Lxx.y, in.cxx.x, in.cxx.y, in.cxx.z, in.cxx.w, in.Rxx.x, in.Rxx.y};
-    const float xz[8] = {in.Lxz.x, in.Lxz.y, in.a2.x, in.a2.y, in.a2.z, in.a2.w, in.Rxz.x, in.Rxz.y};
-    float d1[4], d2[4], d3[4], d4[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        d1[c] = dfw(xx[c + 1], xx[c + 2], xx[c + 3], xx[c + 4]);
-        d2[c] = dbw(comp(in.a0, c), comp(in.a1, c), comp(in.a2, c), comp(in.a3, c));
-        d3[c] = dbw(xz[c], xz[c + 1], xz[c + 2], xz[c + 3]);
-        d4[c] = dfw(comp(in.b0, c), comp(in.b1, c), comp(in.b2, c), comp(in.b3, c));
-    }
-    const int xs_off = xstrip(p, g);
-    if (xs_off >= 0) {
-        const float4 pxa = ld4(p.px + PA * p.gp + 4 * g), pxb = ld4(p.px + PB * p.gp + 4 * g);
-        const float4 pxk = ld4(p.px + PK * p.gp + 4 * g), pxah = ld4(p.px + PAH * p.gp + 4 * g);
-        const float4 pxbh = ld4(p.px + PBH * p.gp + 4 * g), pxkh = ld4(p.px + PKH * p.gp + 4 * g);
-        const long long q1 = (long long)s * p.psix_shot + ((long long)0 * p.nz + j) * p.wx + xs_off;
-        const long long q3 = (long long)s * p.psix_shot + ((long long)1 * p.nz + j) * p.wx + xs_off;
-        const float4 s1 = ld4(p.psix + q1), s3 = ld4(p.psix + q3);
-        float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t3[4] = {s3.x, s3.y, s3.z, s3.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            d1[c] = pml(t1[c], comp(pxah, c), comp(pxbh, c), comp(pxkh, c), d1[c]);
-            d3[c] = pml(t3[c], comp(pxa, c), comp(pxb, c), comp(pxk, c), d3[c]);
-        }
-        if (mine) {
-            st4(p.psix_out + q1, make_float4(t1[0], t1[1], t1[2], t1[3]));
-            st4(p.psix_out + q3, make_float4(t3[0], t3[1], t3[2], t3[3]));
-        }
-    }
-    const int zs = zstrip(p, j);
-    if (zs >= 0) {
-        const float za = p.pz[PA * p.nz + j], zb = p.pz[PB * p.nz + j], zk = p.pz[PK * p.nz + j];
-        const float zah = p.pz[PAH * p.nz + j], zbh = p.pz[PBH * p.nz + j], zkh = p.pz[PKH * p.nz + j];
-        const long long q2 = (long long)s * p.psiz_shot + ((long long)0 * 2 * p.W + zs) * p.gp + 4 * g;
-        const long long q4 = (long long)s * p.psiz_shot + ((long long)1 * 2 * p.W + zs) * p.gp + 4 * g;
-        const float4 s2 = ld4(p.psiz + q2), s4 = ld4(p.psiz + q4);
-        float t2[4] = {s2.x, s2.y, s2.z, s2.w}, t4[4] = {s4.x, s4.y, s4.z, s4.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            d2[c] = pml(t2[c], za, zb, zk, d2[c]);
-            d4[c] = pml(t4[c], zah, zbh, zkh, d4[c]);
-        }
-        if (mine) {
-            st4(p.psiz_out + q2, make_float4(t2[0], t2[1], t2[2], t2[3]));
-            st4(p.psiz_out + q4, make_float4(t4[0], t4[1], t4[2], t4[3]));
-        }
-    }
-    float s4v[4], s5v[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { s4v[c] = d1[c] + d2[c]; s5v[c] = d3[c] + d4[c]; }
-    vxn = make_float4(fmaf(in.bx.x, s4v[0], in.vx.x), fmaf(in.bx.y, s4v[1], in.vx.y),
-                      fmaf(in.bx.z, s4v[2], in.vx.z), fmaf(in.bx.w, s4v[3], in.vx.w));
-    vzn = make_float4(fmaf(in.bz.x, s5v[0], in.vz.x), fmaf(in.bz.y, s5v[1], in.vz.y),
-                      fmaf(in.bz.z, s5v[2], in.vz.z), fmaf(in.bz.w, s5v[3], in.vz.w));
-    s4o = make_float4(s4v[0], s4v[1], s4v[2], s4v[3]);
-    s5o = make_float4(s5v[0], s5v[1], s5v[2], s5v[3]);
-}
-
-template <bool SAVE>
-__global__ __launch_bounds__(kThreads) void el_step_fused(const ElParams p)
-{
-    int bx, by;
-    xcd_tile(p, bx, by);
-    if (by >= p.tiles_z) {
-        sample_points<0>(p, bx, by);
-        return;
-    }
-    __shared__ float V[2][ASZ][ASX];
-    __shared__ float inj[ATZ * 4 * AGO];
-    const int tile_j = by * ATZ;
-    const int tile_g = bx * AGO;
-    const int s = (int)blockIdx.z;
-    const unsigned fs = p.field_stride;
-    const unsigned ncell = (unsigned)p.nz * p.gp;
-    const int t = (int)threadIdx.x;
-    const float *fin = p.fields + (long long)s * p.shot_stride;
-    float *fout = p.fields_out + (long long)s * p.shot_stride;
-    const int orow = t / AGO, ogrp = t % AGO;
-    const int oj = tile_j + orow, og = tile_g + ogrp;
-    const bool own_ok = oj < p.nz && og < p.ng;
-    const unsigned occ = (unsigned)oj * p.gp + 4 * og;
-    const unsigned oo = (unsigned)(oj + 2) * p.pitch + 4 + 4 * og;
-    int hr = 0, hg = 0;
-    if (t < kHalo) halo_item(t, hr, hg);
-    const int hj = tile_j - 2 + hr, hgg = tile_g - 1 + hg;
-    const bool halo_ok = t < kHalo && hj >= 0 && hj < p.nz && hgg >= 0 && hgg < p.ng;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    VIn own, halo;
-    float4 Ls = zero4, Ms = zero4, mus = zero4;
-    if (own_ok) v_load(p, fin, oj, og, own);
-    if (halo_ok) v_load(p, fin, hj, hgg, halo);
-    if (own_ok) {
-        Ls = ld4(p.mat + M_L * ncell + occ); Ms = ld4(p.mat + M_M * ncell + occ);
-        mus = ld4(p.mat + M_MU * ncell + occ);
-    }
-    const bool has_inj = stage_injection<ATZ, 4 * AGO, 1>(p, s, tile_j, 4 * tile_g, inj);
-    // ---- V: new velocities of the tile + halo into LDS ---------------------------------------------
-    float4 oxx = zero4, ozz = zero4, oxz = zero4;
-    {
-        float4 vxn = zero4, vzn = zero4, s4 = zero4, s5 = zero4;
-        if (own_ok) {
-            oxx = own.cxx; ozz = own.b1; oxz = own.a2;           // old stresses of the own group (S needs them)
-            v_update(p, s, oj, og, own, true, vxn, vzn, s4, s5);
-            st4(fout + F_VX * fs + oo, vxn);
-            st4(fout + F_VZ * fs + oo, vzn);
-            if (SAVE) {
-                float *Sp = p.S + (long long)s * p.snap_shot + occ;
-                mifwi::stnt4(Sp + 3 * (long long)ncell, s4);
-                mifwi::stnt4(Sp + 4 * (long long)ncell, s5);
-            }
-        }
-        const int x = 4 * (ogrp + 1);
-        st4(&V[0][orow + 2][x], vxn); st4(&V[1][orow + 2][x], vzn);
-    }
-    if (t < kHalo) {
-        float4 vxn = zero4, vzn = zero4, s4, s5;
-        if (halo_ok) v_update(p, s, hj, hgg, halo, false, vxn, vzn, s4, s5);
-        st4(&V[0][hr][4 * hg], vxn); st4(&V[1][hr][4 * hg], vzn);
-    }
-    __syncthreads();
-    // ---- S: new stresses of the tile from LDS ------------------------------------------------------
-    if (own_ok) {
-        const int r = orow + 2, cb = 4 * (ogrp + 1);
-        const Row8 xv = row8(&V[0][r][0], cb), zv = row8(&V[1][r][0], cb);
-        const float4 a0 = ld4(&V[1][r - 2][cb]), a1 = ld4(&V[1][r - 1][cb]);
-        const float4 a2 = ld4(&V[1][r][cb]), a3 = ld4(&V[1][r + 1][cb]);
-        const float4 b0 = ld4(&V[0][r - 1][cb]), b1 = ld4(&V[0][r][cb]);
-        const float4 b2 = ld4(&V[0][r + 1][cb]), b3 = ld4(&V[0][r + 2][cb]);
-        float e1[4], e2[4], e3[4], e4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            e1[c] = dbw(xv.v[c], xv.v[c + 1], xv.v[c + 2], xv.v[c + 3]);
-            e2[c] = dbw(comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
-            e3[c] = dfw(comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
-            e4[c] = dfw(zv.v[c + 1], zv.v[c + 2], zv.v[c + 3], zv.v[c + 4]);
-        }
-        const int xs_off = xstrip(p, og);
-        if (xs_off >= 0) {
-            const float4 pxa = ld4(p.px + PA * p.gp + 4 * og), pxb = ld4(p.px + PB * p.gp + 4 * og);
-            const float4 pxk = ld4(p.px + PK * p.gp + 4 * og), pxah = ld4(p.px + PAH * p.gp + 4 * og);
-            const float4 pxbh = ld4(p.px + PBH * p.gp + 4 * og), pxkh = ld4(p.px + PKH * p.gp + 4 * og);
-            const long long q5 = (long long)s * p.psix_shot + ((long long)2 * p.nz + oj) * p.wx + xs_off;
-            const long long q8 = (long long)s * p.psix_shot + ((long long)3 * p.nz + oj) * p.wx + xs_off;
-            const float4 s5 = ld4(p.psix + q5), s8 = ld4(p.psix + q8);
-            float t5[4] = {s5.x, s5.y, s5.z, s5.w}, t8[4] = {s8.x, s8.y, s8.z, s8.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                e1[c] = pml(t5[c], comp(pxa, c), comp(pxb, c), comp(pxk, c), e1[c]);
-                e4[c] = pml(t8[c], comp(pxah, c), comp(pxbh, c), comp(pxkh, c), e4[c]);
-            }
-            st4(p.psix_out + q5, make_float4(t5[0], t5[1], t5[2], t5[3]));
-            st4(p.psix_out + q8, make_float4(t8[0], t8[1], t8[2], t8[3]));
-        }
-        const int zs = zstrip(p, oj);
-        if (zs >= 0) {
-            const float za = p.pz[PA * p.nz + oj], zb = p.pz[PB * p.nz + oj], zk = p.pz[PK * p.nz + oj];
-            const float zah = p.pz[PAH * p.nz + oj], zbh = p.pz[PBH * p.nz + oj], zkh = p.pz[PKH * p.nz + oj];
-            const long long q6 = (long long)s * p.psiz_shot + ((long long)2 * 2 * p.W + zs) * p.gp + 4 * og;
-            const long long q7 = (long long)s * p.psiz_shot + ((long long)3 * 2 * p.W + zs) * p.gp + 4 * og;
-            const float4 s6 = ld4(p.psiz + q6), s7 = ld4(p.psiz + q7);
-            float t6[4] = {s6.x, s6.y, s6.z, s6.w}, t7[4] = {s7.x, s7.y, s7.z, s7.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                e2[c] = pml(t6[c], za, zb, zk, e2[c]);
-                e3[c] = pml(t7[c], zah, zbh, zkh, e3[c]);
-            }
-            st4(p.psiz_out + q6, make_float4(t6[0], t6[1], t6[2], t6[3]));
-            st4(p.psiz_out + q7, make_float4(t7[0], t7[1], t7[2], t7[3]));
-        }
-        float nxx[4], nzz[4], nxz[4], s3v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            s3v[c] = e3[c] + e4[c];
-            nxx[c] = fmaf(comp(Ms, c), e1[c], fmaf(comp(Ls, c), e2[c], comp(oxx, c)));
-            nzz[c] = fmaf(comp(Ls, c), e1[c], fmaf(comp(Ms, c), e2[c], comp(ozz, c)));
-            nxz[c] = fmaf(comp(mus, c), s3v[c], comp(oxz, c));
-            if (has_inj) {
-                const float a = inj[orow * 4 * AGO + 4 * ogrp + c];
-                nxx[c] += a;
-                nzz[c] += a;
-            }
-            if (p.fsurf && oj == 0) nzz[c] = 0.f;
-        }
-        st4(fout + F_SXX * fs + oo, make_float4(nxx[0], nxx[1], nxx[2], nxx[3]));
-        st4(fout + F_SZZ * fs + oo, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
-        st4(fout + F_SXZ * fs + oo, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
-        if (SAVE) {
-            float *Sp = p.S + (long long)s * p.snap_shot + occ;
-            mifwi::stnt4(Sp, make_float4(e1[0], e1[1], e1[2], e1[3]));
-            mifwi::stnt4(Sp + (long long)ncell, make_float4(e2[0], e2[1], e2[2], e2[3]));
-            mifwi::stnt4(Sp + 2 * (long long)ncell, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
-        }
-    }
-}
+#include "mifwi_elastic_fused.h"
 
 // receivers of the state in p.fields (the last step of a fused range)
 __global__ __launch_bounds__(kThreads) void el_sample_v(const ElParams p)
@@ -1199,6 +965,28 @@ __global__ void el_inject_pressure(const ElParams p)
     atomicAdd(fl + F_SZZ * (long long)p.field_stride + off, a);
 }
 
+// adjoint of the velocity receivers: vx_bar, vz_bar [cell] += w g[n] at the head of adjoint step n, before S^T
+// (oracle/elastic.c, "a. receivers^T").  Receivers normally sit on distinct cells; taps that share a cell add
+// in hardware order.
+__global__ void el_inject_adjsrc(const ElParams p)
+{
+    const int per = p.ninj * p.ntap_inj;
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (idx >= p.gs * per) return;
+    const int s = p.s0 + idx / per, r = idx % per;
+    if (s >= p.nshot) return;
+    const long long ee = (long long)s * per + r;
+    const int cell = p.inj_cell[ee];
+    if (cell < 0) return;
+    const int j = cell / p.nx, i = cell - j * p.nx;
+    const unsigned off = (unsigned)(j + 2) * p.pitch + 4 + i;
+    float *fl = p.fields + (long long)s * p.shot_stride;
+    const float w = p.inj_w[ee];
+    const long long ai = (long long)s * p.ninj + r / p.ntap_inj;
+    atomicAdd(fl + F_VX * (long long)p.field_stride + off, w * p.inj_amp0[ai]);
+    atomicAdd(fl + F_VZ * (long long)p.field_stride + off, w * p.inj_amp1[ai]);
+}
+
 __global__ void el_points_bbox(const int *cell, int npts_per_shot, int n1, int *bbox)
 {
     __shared__ int red[4][kThreads];
@@ -1261,6 +1049,8 @@ struct mifwi_elastic_plan {
     int pass_shots;        // forward per-step family: shots per pass over the time range
     int pass_groups;       // adjoint per-step family: shot groups per pass
     int fused;             // forward V+S in one launch (second copy of the state in the work buffer)
+    int fused_pass_shots;  // shots per pass of the fused forward (both copies of the state in the Infinity Cache)
+    int fused_adj;         // adjoint S^T+V^T in one launch (second copy of the adjoint fields in the work buffer)
     long long field_stride, shot_stride, fields_elems, psix_elems, psiz_elems, coef_elems;
     long long psi_elems;  // psix+psiz rounded up to 64
     // cluster path (LDS-resident time loop); 0 when a shot does not fit
@@ -1403,7 +1193,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
 template <bool SAVE>
 int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStream_t st)
 {
-    if (mifwi::fake_timeout()) return mifwi::kClusterTimedOut;
+    if (mifwi::fake_timeout() == 1) return mifwi::kClusterTimedOut;
     MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
     c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
     c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
@@ -1420,19 +1210,23 @@ int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStr
     int err = 0;
     MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
     MIFWI_HIP_TRY(hipStreamSynchronize(st));
-    return err != 0 ? mifwi::kClusterTimedOut : MIFWI_OK;
+    return (err != 0 || mifwi::fake_timeout() == 2) ? mifwi::kClusterTimedOut : MIFWI_OK;
 }
 
-// outcome of a single-launch attempt: done (return *out), or fall back to one launch per half step
-bool el_cluster_done(int rc, int32_t flags, int *out)
+// A timed-out single-launch attempt has advanced the state by an unknown number of steps: a call that started from
+// the zero state is zeroed again, a resumed call (time checkpointing) gets back the copy of its input state taken
+// before the attempt; then the per-step kernels run the range.
+int el_cluster_backup(float *work, long long state_elems, float *backup, int32_t flags, hipStream_t st)
 {
-    if (rc != mifwi::kClusterTimedOut) { *out = rc; return true; }
-    if (!(flags & MIFWI_ZERO_STATE)) {
-        *out = mifwi::fail(MIFWI_EHIP, "single-launch time loop: a halo hand-off timed out (not every workgroup was "
-                           "resident in time) on a resumed call; set MIFWI_EL_CLUSTER=0 / MIFWI_EL_CLUSTER_ADJ=0");
-        return true;
-    }
-    return false;
+    if (flags & MIFWI_ZERO_STATE) return MIFWI_OK;
+    MIFWI_HIP_TRY(hipMemcpyAsync(backup, work, sizeof(float) * state_elems, hipMemcpyDeviceToDevice, st));
+    return MIFWI_OK;
+}
+int el_cluster_restore(float *work, long long state_elems, const float *backup, int32_t flags, hipStream_t st)
+{
+    if (flags & MIFWI_ZERO_STATE) MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * state_elems, st));
+    else MIFWI_HIP_TRY(hipMemcpyAsync(work, backup, sizeof(float) * state_elems, hipMemcpyDeviceToDevice, st));
+    return MIFWI_OK;
 }
 
 }  // namespace
@@ -1508,6 +1302,7 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     // snapshot stream, and their grids' snapshots fit in memory many times over)
     pl->snap_bf16 = d->snapshot_format == MIFWI_SNAPSHOT_BF16 && !pl->cluster && !pl->cl_adj;
     pl->snap_shot = pl->snap_bf16 ? mifwi::round_up64(5 * pl->coef_elems / 2, 4) : 5 * pl->coef_elems;
+    pl->fused_adj = !pl->cl_adj && d->source_type == 0 && !d->record_pressure && env_int("MIFWI_EL_FUSED_ADJ", 0) != 0;
     {
         // Infinity Cache residency (per-step family, large grids): a pass over the time range takes only as
         // many shots as keep state + materials (+ gradient accumulators) under kResident bytes; measured on
@@ -1526,7 +1321,7 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
         // adjoint: groups of gs shots share one accumulator set; when the groups do not all fit, smaller groups
         // (more accumulator traffic, 40/gs B per cell-step) can still pay: 1000x3000, gs 2, one group per pass
         // 0.87 ms against 0.98 ms for gs 4 over all shots
-        const double astate = 4.0 * (double)pl->shot_stride + 2.0 * psi1, accg = 4.0 * 5.0 * cells;
+        const double astate = (pl->fused_adj ? 8.0 : 4.0) * (double)pl->shot_stride + 2.0 * psi1, accg = 4.0 * 5.0 * cells;
         if (!pl->cl_adj && d->shots_per_group <= 0 && env_int("MIFWI_EL_GS", 0) <= 0 &&
             pl->ngroups * (pl->gs * astate + accg) + mats > kResident) {
             int g = pl->gs;
@@ -1545,7 +1340,18 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
         k = env_int("MIFWI_EL_PASS_GROUPS", k);
         pl->pass_groups = std::min(pl->ngroups, std::max(1, k));
     }
-    pl->fused = !pl->cluster && !pl->snap_bf16 && d->source_type == 0 && !d->record_pressure && env_int("MIFWI_EL_FUSED", 0) != 0;   // measured: no faster than two launches yet
+    // V+S in one launch pays where the time loop has to be cut into Infinity-Cache-sized passes anyway (measured,
+    // 1000x3000 x 16 shots: 622 -> 558 us per step, 516 with bf16 planes; 350x1700 x 32: 232 -> 232, 214 -> 209)
+    pl->fused = !pl->cluster && d->source_type == 0 && !d->record_pressure &&
+                env_int("MIFWI_EL_FUSED", pl->pass_shots < d->nshot ? 1 : 0) != 0;
+    {
+        const double cells = (double)pl->coef_elems, mats = 4.0 * 5.0 * cells;
+        const double fstate = 4.0 * (double)pl->shot_stride + 4.0 * (double)(pl->psix_elems + pl->psiz_elems) / d->nshot;
+        int ps = d->nshot;
+        if (d->nshot * 2.0 * fstate + mats > 250e6) ps = (int)std::max(1.0, std::floor((230e6 - mats) / (2.0 * fstate)));
+        ps = env_int("MIFWI_EL_FUSED_PASS_SHOTS", ps);
+        pl->fused_pass_shots = std::min(d->nshot, std::max(1, ps));
+    }
     if (pl->cl_adj) {                    // the adjoint cluster kernel keeps one accumulator set per shot
         pl->gs = 1;
         pl->ngroups = d->nshot;
@@ -1595,10 +1401,12 @@ int mifwi_elastic_plan_layout(const mifwi_elastic_plan *pl, mifwi_elastic_layout
     const long long psi = pl->psi_elems;
     const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
     out->state_elems = pl->fields_elems + psi;
-    out->work_forward_elems = out->state_elems + bbox + (pl->cluster ? pl->xbuf_elems : 0) +
+    // single-launch plans: room for a copy of a resumed call's input state (el_cluster_backup)
+    out->work_forward_elems = out->state_elems + bbox + (pl->cluster ? pl->xbuf_elems + out->state_elems : 0) +
                               (pl->fused ? out->state_elems : 0);
-    out->work_backward_elems = pl->fields_elems + 2 * psi + 5LL * pl->ngroups * pl->coef_elems + bbox +
-                               (pl->cl_adj ? pl->xbuf_elems + pl->list_elems : 0);
+    const long long adj_state = pl->fields_elems + 2 * psi + 5LL * pl->ngroups * pl->coef_elems;
+    out->work_backward_elems = adj_state + bbox + (pl->cl_adj ? pl->xbuf_elems + pl->list_elems + adj_state : 0) +
+                               (pl->fused_adj ? pl->fields_elems : 0);
     return MIFWI_OK;
 }
 
@@ -1651,49 +1459,67 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
         c.rec_vx = want_rec ? rec_vx : nullptr; c.rec_vz = want_rec ? rec_vz : nullptr;
         c.dbg = env_int("MIFWI_EL_CL_DBG", 0);
         c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(d.nz, c.NW) >= 8 ? 48 : 1);   // mifwi::poll_nap
-        int out = 0;
-        if (el_cluster_done(snap ? el_cluster_run<true>(pl, c, xbuf, st) : el_cluster_run<false>(pl, c, xbuf, st),
-                            flags, &out))
-            return out;
-        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (pl->fields_elems + psi), st));
+        float *backup = xbuf + pl->xbuf_elems;
+        rc = el_cluster_backup(work, pl->fields_elems + psi, backup, flags, st);
+        if (rc) return rc;
+        rc = snap ? el_cluster_run<true>(pl, c, xbuf, st) : el_cluster_run<false>(pl, c, xbuf, st);
+        if (rc != mifwi::kClusterTimedOut) return rc;
+        rc = el_cluster_restore(work, pl->fields_elems + psi, backup, flags, st);
+        if (rc) return rc;
     }
     if (pl->fused && n_end > n_begin) {
-        // V+S in one launch: the state ping-pongs between the copy at the head of the work buffer and a
-        // second one behind the bounding boxes; an odd number of steps ends with a copy back
+        // V+S in one launch: the state ping-pongs between the copy at the head of the work buffer and a second
+        // one behind the bounding boxes.  Shots are taken a few at a time (both copies of their state stay in the
+        // Infinity Cache); a pass with an odd number of steps ends with a copy back of its shots.
         const long long state = pl->fields_elems + psi;
         float *B = work + state + mifwi::round_up64(4LL * d.nshot, 64);
         MIFWI_HIP_TRY(hipMemsetAsync(B, 0, sizeof(float) * state, st));     // its pad rows / columns stay zero
         ElParams q = p;
         q.ninj = d.nsrc; q.ntap_inj = d.ntap; q.inj_cell = src_cell; q.inj_w = src_w; q.inj_bbox = bbox;
         q.nsmp = want_rec ? d.nrec : 0; q.ntap_smp = d.ntap; q.smp_cell = rec_cell; q.smp_w = rec_w;
-        const int tx = mifwi::ceil_div(pl->ng, AGO), tz = mifwi::ceil_div(d.nz, ATZ);
+        const int tx = mifwi::ceil_div(pl->ng, FTG), tz = mifwi::ceil_div(d.nz, FTZ);
         const int ex = want_rec ? mifwi::ceil_div(mifwi::ceil_div(d.nrec, kThreads), tx) : 0;
-        q.tiles_z = tz;
-        for (int n = n_begin; n < n_end; ++n) {
-            const bool even = ((n - n_begin) & 1) == 0;
-            float *in = even ? work : B, *out = even ? B : work;
-            q.fields = in; q.psix = in + pl->fields_elems; q.psiz = q.psix + pl->psix_elems;
-            q.fields_out = out; q.psix_out = out + pl->fields_elems; q.psiz_out = q.psix_out + pl->psix_elems;
-            q.S = snap ? snap + (long long)(n - n_begin) * snap_step : nullptr;
-            q.inj_amp0 = f ? f + (long long)n * d.nshot * d.nsrc : nullptr;
-            // the receivers see the input state: the velocities of step n-1
-            const bool smp = want_rec && n > n_begin;
-            q.smp_out0 = smp ? rec_vx + (long long)(n - 1) * d.nshot * d.nrec : nullptr;
-            q.smp_out1 = smp ? rec_vz + (long long)(n - 1) * d.nshot * d.nrec : nullptr;
-            const dim3 grid(tx, tz + (smp ? ex : 0), d.nshot);
-            if (snap) hipLaunchKernelGGL(el_step_fused<true>, grid, dim3(kThreads), 0, st, q);
-            else hipLaunchKernelGGL(el_step_fused<false>, grid, dim3(kThreads), 0, st, q);
+        for (int s0 = 0; s0 < d.nshot; s0 += pl->fused_pass_shots) {
+            const int cs = std::min(pl->fused_pass_shots, d.nshot - s0);
+            q.s0 = s0;
+            q.tiles_z = tz;
+            for (int n = n_begin; n < n_end; ++n) {
+                const bool even = ((n - n_begin) & 1) == 0;
+                float *in = even ? work : B, *out = even ? B : work;
+                q.fields = in; q.psix = in + pl->fields_elems; q.psiz = q.psix + pl->psix_elems;
+                q.fields_out = out; q.psix_out = out + pl->fields_elems; q.psiz_out = q.psix_out + pl->psix_elems;
+                q.S = snap ? snap + (long long)(n - n_begin) * snap_step : nullptr;
+                q.inj_amp0 = f ? f + (long long)n * d.nshot * d.nsrc : nullptr;
+                // the receivers see the input state: the velocities of step n-1
+                const bool smp = want_rec && n > n_begin;
+                q.smp_out0 = smp ? rec_vx + (long long)(n - 1) * d.nshot * d.nrec : nullptr;
+                q.smp_out1 = smp ? rec_vz + (long long)(n - 1) * d.nshot * d.nrec : nullptr;
+                const dim3 grid(tx, tz + (smp ? ex : 0), cs);
+                if (save == 2) hipLaunchKernelGGL(el_fwd_fused<2>, grid, dim3(kThreads), 0, st, q);
+                else if (save == 1) hipLaunchKernelGGL(el_fwd_fused<1>, grid, dim3(kThreads), 0, st, q);
+                else hipLaunchKernelGGL(el_fwd_fused<0>, grid, dim3(kThreads), 0, st, q);
+            }
+            float *last = ((n_end - n_begin) & 1) ? B : work;
+            if (want_rec) {
+                q.fields = last; q.tiles_z = 0;
+                q.smp_out0 = rec_vx + (long long)(n_end - 1) * d.nshot * d.nrec;
+                q.smp_out1 = rec_vz + (long long)(n_end - 1) * d.nshot * d.nrec;
+                hipLaunchKernelGGL(el_sample_v, dim3(mifwi::ceil_div(d.nrec, kThreads), 1, cs), dim3(kThreads), 0,
+                                   st, q);
+            }
+            if (last != work) {
+                const long long psix1 = 4LL * d.nz * pl->wx, psiz1 = 4LL * 2 * pl->W * pl->gp;
+                MIFWI_HIP_TRY(hipMemcpyAsync(work + s0 * pl->shot_stride, B + s0 * pl->shot_stride,
+                                             sizeof(float) * cs * pl->shot_stride, hipMemcpyDeviceToDevice, st));
+                if (psix1 > 0)
+                    MIFWI_HIP_TRY(hipMemcpyAsync(work + pl->fields_elems + s0 * psix1, B + pl->fields_elems + s0 * psix1,
+                                                 sizeof(float) * cs * psix1, hipMemcpyDeviceToDevice, st));
+                if (psiz1 > 0)
+                    MIFWI_HIP_TRY(hipMemcpyAsync(work + pl->fields_elems + pl->psix_elems + s0 * psiz1,
+                                                 B + pl->fields_elems + pl->psix_elems + s0 * psiz1,
+                                                 sizeof(float) * cs * psiz1, hipMemcpyDeviceToDevice, st));
+            }
         }
-        float *last = ((n_end - n_begin) & 1) ? B : work;
-        if (want_rec) {
-            q.fields = last; q.tiles_z = 0;
-            q.smp_out0 = rec_vx + (long long)(n_end - 1) * d.nshot * d.nrec;
-            q.smp_out1 = rec_vz + (long long)(n_end - 1) * d.nshot * d.nrec;
-            hipLaunchKernelGGL(el_sample_v, dim3(mifwi::ceil_div(d.nrec, kThreads), 1, d.nshot), dim3(kThreads), 0,
-                               st, q);
-        }
-        if (last != work)
-            MIFWI_HIP_TRY(hipMemcpyAsync(work, B, sizeof(float) * state, hipMemcpyDeviceToDevice, st));
     } else {
         p.fields = fields; p.psix = psi_state; p.psiz = psi_state + pl->psix_elems;
         ElParams ps = p;
@@ -1766,17 +1592,17 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
     float *acc = psiB + psi;
     const long long nacc = 5LL * pl->ngroups * pl->coef_elems;
     int *bbox = reinterpret_cast<int *>(acc + nacc);
-    if (flags & MIFWI_ZERO_STATE)
+    float *fieldsB = reinterpret_cast<float *>(bbox) + mifwi::round_up64(4LL * d.nshot, 64);   // fused adjoint only
+    if (flags & MIFWI_ZERO_STATE) {
         MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (pl->fields_elems + 2 * psi + nacc), st));
-    hipLaunchKernelGGL(el_points_bbox, dim3(d.nshot), dim3(kThreads), 0, st, rec_cell,
-                       d.nrec * d.ntap, d.nx, bbox);
+        if (pl->fused_adj) MIFWI_HIP_TRY(hipMemsetAsync(fieldsB, 0, sizeof(float) * pl->fields_elems, st));
+    }
     ElParams p = el_base(pl, mat, pz, px);
     p.fields = fields;
     p.acc = acc;
     ElParams ps = p;
     ps.gs = pl->gs;
-    ps.ninj = d.nrec; ps.ntap_inj = d.ntap; ps.inj_cell = rec_cell; ps.inj_w = rec_w;
-    ps.inj_bbox = bbox;
+    ps.ninj = d.nrec; ps.ntap_inj = d.ntap; ps.inj_cell = rec_cell; ps.inj_w = rec_w;    // el_inject_adjsrc
     const bool want_f = grad_f != nullptr && d.nsrc > 0;
     ps.nsmp = want_f ? d.nsrc : 0; ps.ntap_smp = d.ntap; ps.smp_cell = src_cell; ps.smp_w = src_w;
     const long long snap_step = pl->snap_shot * d.nshot;
@@ -1808,7 +1634,11 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
         c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
         c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
-        for (int s0 = 0; s0 < d.nshot && !mifwi::fake_timeout(); s0 += pl->adj_shots) {
+        const long long adj_state = pl->fields_elems + 2 * psi + nacc;
+        float *backup = reinterpret_cast<float *>(lists) + pl->list_elems;
+        rc = el_cluster_backup(work, adj_state, backup, flags, st);
+        if (rc) return rc;
+        for (int s0 = 0; s0 < d.nshot && mifwi::fake_timeout() != 1; s0 += pl->adj_shots) {
             c.shot0 = s0;
             c.shot1 = std::min(d.nshot, s0 + pl->adj_shots);
             const int nsl8 = mifwi::ceil_div(c.shot1 - s0, 8);
@@ -1821,12 +1651,11 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         int err = 0;
         MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
         MIFWI_HIP_TRY(hipStreamSynchronize(st));
-        int out = 0;
-        if (el_cluster_done((err != 0 || mifwi::fake_timeout()) ? mifwi::kClusterTimedOut : MIFWI_OK, flags, &out)) {
-            if (out) return out;
-            per_step = false;
+        if (err != 0 || mifwi::fake_timeout()) {
+            rc = el_cluster_restore(work, adj_state, backup, flags, st);
+            if (rc) return rc;
         } else {
-            MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (pl->fields_elems + 2 * psi + nacc), st));
+            per_step = false;
         }
     }
     // shot groups are independent: a few at a time keep fields, accumulators and materials in the Infinity Cache
@@ -1846,6 +1675,24 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         const bool force = d.source_type != 0;        // grad_f of a point force: v_bar sampled between S^T and V^T
         ps.smp_out0 = (want_f && !force) ? grad_f + (long long)n * d.nshot * d.nsrc : nullptr;
         p.psix = ps.psix; p.psiz = ps.psiz; p.psix_out = ps.psix_out; p.psiz_out = ps.psiz_out;
+        if (pl->fused_adj) {
+            // S^T + V^T in one launch: the adjoint fields ping-pong like the memory variables (absolute in n)
+            ps.fields = par ? fieldsB : fields;
+            ps.fields_out = par ? fields : fieldsB;
+        }
+        if (d.nrec > 0) {
+            ElParams pq = ps;
+            pq.gs = cs;
+            hipLaunchKernelGGL(el_inject_adjsrc, dim3(mifwi::ceil_div(cs * d.nrec * d.ntap, 64)), dim3(64), 0, st, pq);
+        }
+        if (pl->fused_adj) {
+            const int tx = mifwi::ceil_div(pl->ng, FTG), tz = mifwi::ceil_div(d.nz, FTZ);
+            ps.tiles_z = tz;
+            const int ex = want_f ? mifwi::ceil_div(mifwi::ceil_div(ps.gs * ps.nsmp, kThreads), tx) : 0;
+            if (pl->snap_bf16) hipLaunchKernelGGL(el_adj_fused<true>, dim3(tx, tz + ex, cg), dim3(kThreads), 0, st, ps);
+            else hipLaunchKernelGGL(el_adj_fused<false>, dim3(tx, tz + ex, cg), dim3(kThreads), 0, st, ps);
+            continue;
+        }
         {
             const int tx = mifwi::ceil_div(pl->ng, AGO), tz = mifwi::ceil_div(d.nz, ATZ);
             ps.tiles_z = tz;

@@ -140,9 +140,12 @@ struct EcHandoff {
 #pragma unroll
             for (int k = 0; k < kEcGr; ++k)
                 if (rcv_lo[k] >= 0) ok = ok && (unsigned)(v[k] >> 32) == epoch;
-            if (ok || no_wait) break;
+            if (ok || no_wait || failed) break;   // once failed: one pass per hand-off, garbage forward until the check
             if (spins > kEcMaxSpin ||
                 ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                // publish at once: every other workgroup of the launch bails within 256 spins instead of running
+                // into its own time-out, one hand-off after the other
+                if (spins > kEcMaxSpin) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 failed = true;
                 break;
             }
@@ -337,6 +340,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     const int xcd = L & 7, kq = L >> 3;
     const int w = kq % p.NW, s = p.shot0 + xcd + 8 * (kq / p.NW);
     if (s >= p.shot1) return;
+    // ablation builds only: slab 1 of the first shot never shows up (a workgroup that was not resident in time)
+    if ((kDbg(p) & 64) && w == 1 && s == p.shot0) return;
     const int t = (int)threadIdx.x;
     int r0, R;
     ec_slab_rows(p.nz, p.NW, w, r0, R);
@@ -666,6 +671,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     const int xcd = L & 7, kq = L >> 3;
     const int w = kq % p.NW, s = p.shot0 + xcd + 8 * (kq / p.NW);
     if (s >= p.shot1) return;
+    // ablation builds only: slab 1 of the first shot never shows up (a workgroup that was not resident in time)
+    if ((kDbg(p) & 64) && w == 1 && s == p.shot0) return;
     const int t = (int)threadIdx.x;
     int r0, R;
     ec_slab_rows(p.nz, p.NW, w, r0, R);

@@ -41,9 +41,8 @@ class _MisfitFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        adj = ctx.adj
-        ctx.adj = None
-        return (None if adj is None else adj * g), None, None, None
+        # the adjoint source stays with the graph (a second backward through a retained graph gets it again)
+        return (None if ctx.adj is None else ctx.adj * g), None, None, None
 
 
 def l1_trace_normalized(pred, obs_norm, direct=None):

@@ -1,7 +1,15 @@
 """The single-launch time loops hand halo rows between workgroups and give up (bounded spins) when
-a neighbour never shows up.  A call that starts from the zero state then re-runs with one launch
-per (half) step instead of failing; a resumed (checkpointed) call cannot and reports the error.
-MIFWI_TEST_FAKE_TIMEOUT=1 makes the host treat every single-launch attempt as timed out."""
+a neighbour never shows up.  The call then re-runs with one launch per (half) step instead of failing:
+from the zero state when it started there, from a copy of its input state when it was a resumed
+(time-checkpointed) call.  MIFWI_TEST_FAKE_TIMEOUT=1 makes the host treat every single-launch attempt as
+timed out before it runs, =2 after it has run (the state really has to be restored); the device side of
+the time-out (a workgroup that never shows up) is driven in an ablation build, in a child process."""
+import os
+import subprocess
+import sys
+
+
+import numpy as np
 import pytest
 import torch
 
@@ -80,17 +88,69 @@ def test_elastic_falls_back_to_one_launch_per_half_step(monkeypatch):
     _same(ref[2:], got[2:])
 
 
-def test_resumed_calls_report_the_timeout(monkeypatch):
-    """A checkpointed run resumes from saved state: no clean restart exists, so the error surfaces."""
-    from physicsbasedfwi2_amd._lib import MifwiError
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_resumed_calls_fall_back_too(monkeypatch, mode):
+    """A checkpointed run resumes from saved state.  The library keeps a copy of a resumed call's input state, so
+    a timed-out attempt - even one that has already advanced (mode 2: every attempt runs, then counts as timed
+    out) - is rolled back and the range runs on the per-step kernels: same results, no error."""
     ca = acoustic_case(seed=83, n0=100, n1=160, nb=10, nt=120, ns=3, nrec=30)
     ce = elastic_case(seed=89, nz=100, nx=300, fw=10, ns=3, nrec=50, nt=120)
     ref_a = _acoustic(ca, snapshot_budget=1 << 20)            # forces several time segments
     ref_e = _elastic(ce, snapshot_budget=1 << 21)
     _same(ref_a, _acoustic(ca))
     _same(ref_e, _elastic(ce))
-    monkeypatch.setenv("MIFWI_TEST_FAKE_TIMEOUT", "1")
-    with pytest.raises(MifwiError, match="timed out"):
-        _acoustic(ca, snapshot_budget=1 << 20)
-    with pytest.raises(MifwiError, match="timed out"):
-        _elastic(ce, snapshot_budget=1 << 21)
+    monkeypatch.setenv("MIFWI_TEST_FAKE_TIMEOUT", mode)
+    got_a = _acoustic(ca, snapshot_budget=1 << 20)
+    got_e = _elastic(ce, snapshot_budget=1 << 21)
+    assert float(ref_a[0].abs().max()) > 0 and torch.equal(ref_a[0], got_a[0])
+    assert torch.equal(ref_e[0], got_e[0]) and torch.equal(ref_e[1], got_e[1])
+    _same(ref_a[1:], got_a[1:])
+    _same(ref_e[2:], got_e[2:])
+
+
+_CHILD = r"""
+import sys, json
+import numpy as np, torch
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+from cases import acoustic_case, elastic_case
+from physicsbasedfwi2_amd import acoustic, elastic
+dev = "cuda:0"
+t = lambda c, *n: [torch.tensor(c[k]) for k in n]
+ca = acoustic_case(seed=71, n0=120, n1=200, nb=10, nt=100, ns=6, nrec=40)
+r = torch.tensor(ca["r"], dtype=torch.float32, device=dev, requires_grad=True)
+f = torch.tensor(ca["f"], dtype=torch.float32, device=dev)
+rec = acoustic.propagate(r, f, *t(ca, "q0", "q1", "sc", "sw", "rc", "rw"), ca["c0"], ca["c1"])
+rec.backward(torch.sign(rec.detach()))
+ce = elastic_case(seed=79, nz=100, nx=300, fw=10, ns=6, nrec=100, nt=100)
+mat = torch.tensor(ce["mat"], dtype=torch.float32, device=dev, requires_grad=True)
+ef = torch.tensor(ce["f"], dtype=torch.float32, device=dev)
+vx, vz = elastic.propagate(mat, ef, *t(ce, "pz", "px", "sc", "sw", "rc", "rw"), ce["fw"])
+torch.autograd.backward([vx, vz], [torch.sign(vx.detach()), torch.sign(vz.detach())])
+np.savez(sys.argv[1], rec=rec.detach().cpu().numpy(), gr=r.grad.cpu().numpy(), vx=vx.detach().cpu().numpy(),
+         vz=vz.detach().cpu().numpy(), gm=mat.grad.cpu().numpy())
+"""
+
+
+def test_a_workgroup_that_never_shows_up_times_out_on_the_device_and_the_call_falls_back(tmp_path):
+    """The device side of the time-out, once: in the ablation build (libmifwi_ablations.so, built by
+    __graft_entry__.build() with -DMIFWI_ABLATIONS) debug bit 64 makes slab 1 of the first shot of every
+    single-launch kernel exit at once.  Its neighbours spin out, the first to give up publishes the error word, the
+    rest of the launch bails within 256 polls, the host zeroes the state and runs the per-step kernels: same
+    traces bit for bit, gradients to summation order."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "physicsbasedfwi2_amd", "libmifwi_ablations.so")
+    if not os.path.exists(lib):
+        pytest.skip("ablation build not present (python __graft_entry__.py builds it)")
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD % {"tests": os.path.join(root, "tests"), "root": root})
+    outs = []
+    for tag, env in (("ref", {}), ("abl", {"MIFWI_LIB": lib, "MIFWI_AC_CL_DBG": "64", "MIFWI_EL_CL_DBG": "64"})):
+        out = tmp_path / (tag + ".npz")
+        res = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, **env), capture_output=True,
+                             text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(dict(np.load(out)))
+    ref, abl = outs
+    assert np.abs(ref["rec"]).max() > 0 and np.array_equal(ref["rec"], abl["rec"])
+    assert np.array_equal(ref["vx"], abl["vx"]) and np.array_equal(ref["vz"], abl["vz"])
+    assert rel_l2(abl["gr"], ref["gr"]) <= 2e-5 and rel_l2(abl["gm"], ref["gm"]) <= 2e-5

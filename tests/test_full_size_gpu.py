@@ -308,33 +308,48 @@ def test_full_length_runs_agree_between_families(monkeypatch):
     assert rel_l2(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()) <= 5e-5
 
 
-def test_fused_forward_step_matches_the_two_launch_form(monkeypatch):
-    """MIFWI_EL_FUSED=1: V and S in one launch with a recomputed halo and a ping-pong state (opt-in, large
-    grids).  Same arithmetic term by term: traces and gradients equal the two-launch kernels bit for bit,
-    with the free surface, an odd number of steps, checkpointed segments and a grid wider than one tile."""
+def test_fused_steps_match_the_two_launch_form(monkeypatch):
+    """MIFWI_EL_FUSED=1: V and S in one launch; MIFWI_EL_FUSED_ADJ=1: S^T and V^T in one launch (stencil operands
+    staged in LDS, recomputed halo, ping-pong state; large grids).  Same arithmetic term by term: traces and
+    gradients equal the two-launch kernels bit for bit, with the free surface, an odd number of steps, passes over
+    shot subsets (copy back of a pass that ends in the second copy), shot groups sharing one accumulator set,
+    checkpointed segments, bf16 snapshot planes and a grid wider and taller than one tile."""
     monkeypatch.setenv("MIFWI_EL_CLUSTER", "0")
     monkeypatch.setenv("MIFWI_EL_CLUSTER_ADJ", "0")
     from physicsbasedfwi2_amd import elastic
     from physicsbasedfwi2_amd.elastic import ElasticPlan
     case = elastic_case(seed=61, nz=70, nx=150, fw=8, ns=3, nrec=40, nt=75)
+    big = 1 << 40
     outs = []
-    for fused, fsurf, budget in (("0", 0, 1 << 40), ("1", 0, 1 << 40), ("0", 1, 1 << 40), ("1", 1, 1 << 40),
-                                 ("1", 1, 3 << 20)):
+    for fused, adj, fsurf, budget, pass_shots, fmt, gs in (
+            ("0", "0", 0, big, None, "f32", 0), ("1", "0", 0, big, None, "f32", 0), ("1", "1", 0, big, 2, "f32", 0),
+            ("0", "0", 1, big, None, "f32", 2), ("0", "1", 1, big, None, "f32", 2), ("1", "1", 1, 3 << 20, 2, "f32", 2),
+            ("0", "0", 1, big, None, "bf16", 0), ("1", "1", 1, big, 2, "bf16", 0), ("1", "1", 1, 3 << 20, None, "bf16", 0)):
         monkeypatch.setenv("MIFWI_EL_FUSED", fused)
+        monkeypatch.setenv("MIFWI_EL_FUSED_ADJ", adj)
+        if pass_shots:
+            monkeypatch.setenv("MIFWI_EL_FUSED_PASS_SHOTS", str(pass_shots))
+            monkeypatch.setenv("MIFWI_EL_PASS_GROUPS", "1")
+        else:
+            monkeypatch.delenv("MIFWI_EL_FUSED_PASS_SHOTS", raising=False)
+            monkeypatch.delenv("MIFWI_EL_PASS_GROUPS", raising=False)
         lay0 = ElasticPlan(70, 150, 75, 3, 1, 40, 1, 8, 0).layout
         mat = torch.tensor(case["mat"], dtype=torch.float32, device=DEV, requires_grad=True)
         f = torch.tensor(case["f"], dtype=torch.float32, device=DEV, requires_grad=True)
         rvx, rvz = elastic.propagate(mat, f, torch.tensor(case["pz"]), torch.tensor(case["px"]),
                                      torch.tensor(case["sc"]), torch.tensor(case["sw"]),
                                      torch.tensor(case["rc"]), torch.tensor(case["rw"]), case["fw"],
-                                     free_surface=fsurf, snapshot_budget=budget)
+                                     free_surface=fsurf, snapshot_budget=budget, snapshot_format=fmt,
+                                     shots_per_group=gs)
         torch.autograd.backward([rvx, rvz], [torch.sign(rvx.detach()), torch.sign(rvz.detach())])
-        outs.append((lay0.work_forward_elems, rvx.detach(), rvz.detach(), mat.grad.clone(), f.grad.clone()))
-    assert outs[1][0] > outs[0][0]                      # the fused plan carries a second copy of the state
-    assert float(outs[0][1].abs().max()) > 0
-    for a, b in ((0, 1), (2, 3), (2, 4)):
-        for x, y in zip(outs[a][1:], outs[b][1:]):
-            assert torch.equal(x, y)
+        outs.append((lay0.work_forward_elems, lay0.work_backward_elems, rvx.detach(), rvz.detach(), mat.grad.clone(),
+                     f.grad.clone()))
+    assert outs[1][0] > outs[0][0] and outs[2][1] > outs[0][1]     # the fused plans carry a second copy of the state
+    assert float(outs[0][2].abs().max()) > 0 and float(outs[0][4].abs().max()) > 0
+    for a, b in ((0, 1), (0, 2), (3, 4), (3, 5), (6, 7), (6, 8)):
+        for x, y in zip(outs[a][2:], outs[b][2:]):
+            assert torch.equal(x, y), (a, b)
+    assert not torch.equal(outs[3][4], outs[6][4])      # the bf16 planes were in use
 
 
 def test_passes_over_shot_subsets_change_nothing(monkeypatch):

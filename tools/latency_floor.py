@@ -18,10 +18,9 @@ from physicsbasedfwi2_amd import build  # noqa: E402
 
 
 def main():
-    out_dir = os.path.join(ROOT, "gpurun_out")
-    os.makedirs(out_dir, exist_ok=True)
-    lib = os.path.join(out_dir, "libmifwi_ablations.so")
-    build.build(out=lib, extra_flags=["-DMIFWI_ABLATIONS"])
+    lib = build.LIB.replace("libmifwi.so", "libmifwi_ablations.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(build.LIB):
+        build.build(out=lib, extra_flags=["-DMIFWI_ABLATIONS"])
     doc = {"csrc_sha16": bench.csrc_sha16(),
            "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True,
                                     text=True).stdout.strip() or os.environ.get("GRAFT_COMMIT", ""),

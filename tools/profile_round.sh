@@ -1,0 +1,39 @@
+#!/bin/bash
+# Round profile set, run on the GPU box (gpurun -- bash tools/profile_round.sh [r02]); results under gpurun_out/,
+# to be copied into profiles/:
+#   <R>_bench_default_output.json        python bench.py
+#   <R>_bench_default_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command (no CPU baseline)
+#   <R>_pmc_traffic.json                 FETCH_SIZE / WRITE_SIZE passes of the four bench workloads (tools/pmc_traffic.py)
+#   <R>_latency_floor.json               tools/latency_floor.py (ablation build)
+#   <R>_seam_kernel_stats.csv            rocprofv3 stats of the SEAM-sized sample
+R=${1:-r02}
+O=gpurun_out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -x
+python tools/latency_floor.py $O/${R}_latency_floor.json > $O/latency_floor.log 2>&1 || { tail -5 $O/latency_floor.log; exit 1; }
+cp $O/${R}_latency_floor.json profiles/${R}_latency_floor.json        # bench.py reads profiles/
+pmc() {  # name, bench args..., -- pmc_traffic args
+    local name=$1; shift
+    local bargs=() ; while [ "$1" != "--" ]; do bargs+=("$1"); shift; done; shift
+    for C in FETCH_SIZE WRITE_SIZE; do
+        rm -rf $O/pmc_${name}_$C
+        timeout -k 10 600 rocprofv3 --pmc $C --output-format csv -d $O/pmc_${name}_$C -- python bench.py "${bargs[@]}" --steps 1 --warmup 0 --no-cpu-baseline --no-also --no-verify > $O/pmc.log 2>&1 || { tail -5 $O/pmc.log; return 1; }
+    done
+    python tools/pmc_traffic.py $O/pmc_${name}_FETCH_SIZE $O/pmc_${name}_WRITE_SIZE $O/${R}_pmc_traffic.json "$@" > /dev/null || return 1
+    find $O/pmc_${name}_FETCH_SIZE $O/pmc_${name}_WRITE_SIZE -name "*.csv" -size +200k -delete
+}
+pmc el100 --workload elastic_marmousi -- --workload elastic_marmousi &&
+pmc ac174 --workload acoustic_marmousi -- --workload acoustic_marmousi &&
+pmc el350 --workload elastic_marmousi --grid 350x1700 --nt 60 -- --workload elastic_marmousi --grid 350x1700 --nt 60 &&
+pmc seam --workload elastic_seam --nt 12 -- --workload elastic_seam --nt 12 || exit 1
+cp $O/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json
+python bench.py > $O/${R}_bench_default_output.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
+rm -rf $O/prof_default
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python bench.py --no-cpu-baseline > $O/prof.log 2>&1 || { tail -5 $O/prof.log; exit 1; }
+find $O/prof_default -name "*kernel_stats.csv" -exec cp {} $O/${R}_bench_default_kernel_stats.csv \;
+find $O/prof_default -name "*kernel_trace.csv" -delete
+rm -rf $O/prof_seam
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_seam -- python bench.py --workload elastic_seam --nt 90 --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-verify > $O/${R}_seam_bench_output.json 2> $O/prof.log || { tail -5 $O/prof.log; exit 1; }
+find $O/prof_seam -name "*kernel_stats.csv" -exec cp {} $O/${R}_seam_kernel_stats.csv \;
+find $O/prof_seam -name "*kernel_trace.csv" -delete
+echo PROFILE_ROUND_DONE
