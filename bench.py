@@ -578,7 +578,7 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
         el = float(t.item())
     if rank != 0:
         return None
-    if not (np.isfinite(losses[0]) and losses[0] > 1e-12 and gsums[0] > 1e-12):
+    if not args.timing_only and not (np.isfinite(losses[0]) and losses[0] > 1e-25 and gsums[0] > 1e-25):
         raise SystemExit("bench: the timed pass produced loss %.3g, |grad| sum %.3g - nothing reached the receivers, "
                          "the kernels were timed on zeros" % (losses[0], gsums[0]))
     value = wl.units_per_step * world * args.steps / el / 1e6
@@ -606,7 +606,7 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
     }
     dom = "adjoint+imaging" if t_b >= t_f else "forward+save"
     check = {"loss": losses[0], "grad_abs_sum": gsums[0], "bitwise_repeatable": deterministic}
-    if not args.no_verify:
+    if not (args.no_verify or args.timing_only):
         check.update(cross_check(wl, name, dev, kw))
     out = {
         "metric": "grid-cells*timesteps/sec (forward+adjoint gradient pass)",
@@ -685,7 +685,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--nt", type=int, default=0, help="override time steps (debug only)")
     ap.add_argument("--shots", type=int, default=0, help="override shots per GPU (debug only)")
@@ -697,6 +697,8 @@ def main():
                     help="HIP device of this rank (default LOCAL_RANK; rehearsals put every rank on 0)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the untimed cross-check of the two kernel families (counter / ablation runs)")
+    ap.add_argument("--timing-only", action="store_true",
+                    help="ablation builds (wrong results by construction): no cross-check, no refusal of a zero loss")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the secondary workloads of the default invocation")
     args = ap.parse_args()

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define MIFWI_VERSION_MAJOR 0
-#define MIFWI_VERSION_MINOR 3   /* 3: elastic desc gained snapshot_format; layout snap_step_elems, snapshot_format */
+#define MIFWI_VERSION_MINOR 3   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format */
 
 enum {
     MIFWI_OK = 0,
@@ -178,6 +178,9 @@ typedef struct {
                                 counterpart of the wavefield compression / decimation DENISE and deepwave apply to
                                 their stored fields.  Honoured by plans that run the per-step
                                 kernels; single-launch plans keep f32 (layout.snapshot_format says which).     */
+    int32_t fd_order;        /* spatial order of the staggered-grid first derivatives (DENISE FD_ORDER, left commented at
+                                models/networks.py:10447): 4 (Taylor weights 9/8, -1/24; 0 means 4) or 2 (1, 0).
+                                Higher orders need a wider halo than the state layout carries: EINVAL.             */
 } mifwi_elastic_desc;
 
 enum { MIFWI_SNAPSHOT_F32 = 0, MIFWI_SNAPSHOT_BF16 = 1 };
@@ -249,16 +252,37 @@ int mifwi_elastic_plan_cluster_slabs(const mifwi_elastic_plan *plan, int32_t adj
  *                  d = pred - direct;  dn = d / (max_t |d| + 1e-10);  loss = mean |dn - obs|
  *   L2             seisgan/fwi/layers.py:176-178; DENISE lnorm = 2 (models/networks.py:7758):
  *                  loss = 1/2 sum (pred - obs)^2
+ *   GLOBAL_CORRELATION  DENISE's global-correlation norm, selectable through add_fwi_stage(lnorm=...)
+ *                  (models/networks.py:9863, 10503 pass lnorm): loss = - sum_traces <pred, obs> / (|pred| |obs|)
  * pred, obs, direct (NULL = none; L1 only), adj_out (NULL = loss only): [nt][ntrace] with
  * trace = shot*nrec + receiver, the propagators' own output layout.  adj_out = dloss/dpred
  * (including the path through each trace's maximum).  loss_out: one device float.
  * work: mifwi_misfit_work_elems(kind, nt, ntrace) floats, 8-byte aligned.
  * ==================================================================================== */
-enum { MIFWI_MISFIT_L1_TRACE_NORM = 0, MIFWI_MISFIT_L2 = 1 };
+enum { MIFWI_MISFIT_L1_TRACE_NORM = 0, MIFWI_MISFIT_L2 = 1, MIFWI_MISFIT_GLOBAL_CORRELATION = 2 };
 
 int64_t mifwi_misfit_work_elems(int32_t kind, int64_t nt, int64_t ntrace);
 int mifwi_misfit(int device, int32_t kind, const float *pred, const float *obs, const float *direct,
                  int64_t nt, int64_t ntrace, float *loss_out, float *adj_out, float *work, void *stream);
+
+/* ======================================================================================
+ * GRADIENT CONDITIONING on the device (what sits between d.get_fwi_gradients(...) and fake_Vp.backward(grad))
+ *
+ * Replaces the numpy / scipy post-processing of the model gradients in the elastic prop() methods:
+ *   models/networks.py:7808-7862, 9884-9919  flipud, zero rows 0:25, scale by max(model)/max(gradient), rho x 0.1
+ *   models/networks.py:10522-10540           flipud, scipy.ndimage.gaussian_filter(sigma=3), zero rows 0:5, same scaling
+ *   models/networks.py:7731, 9832-9833       SWS_TAPER_GRAD_HOR / EXP_TAPER_GRAD_HOR (a weight per depth row)
+ * grad, out [nplane][nz][nx] device (nplane <= 4, out != grad); models NULL or [nplane][nz][nx] device;
+ * row_weight NULL or [nz] device (indexed by the row of `grad` as stored);  flip: output row j reads stored row
+ * nz-1-j;  sigma: 0 = no smoothing, else scipy's Gaussian (radius int(4 sigma + 0.5) <= 32, 'reflect' boundary);
+ * mute_rows: output rows [0, mute_rows) are zeroed after the smoothing;  factors NULL or HOST array [nplane].
+ *   out_k = factor_k * (models ? max(models_k) / max(t_k) : 1) * t_k,   t_k = mute(smooth(w * flip(grad_k)))
+ * work: mifwi_gradient_condition_work_elems(nplane) floats.
+ * ==================================================================================== */
+int64_t mifwi_gradient_condition_work_elems(int32_t nplane);
+int mifwi_gradient_condition(int device, const float *grad, const float *models, float *out, int32_t nplane,
+                             int32_t nz, int32_t nx, const float *row_weight, float sigma, int32_t flip,
+                             int32_t mute_rows, const float *factors, float *work, void *stream);
 
 #ifdef __cplusplus
 }

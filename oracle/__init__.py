@@ -179,12 +179,12 @@ def _el_cfg():
         _fields_ = [("nz", ctypes.c_int), ("nx", ctypes.c_int), ("nt", ctypes.c_int),
                     ("nshot", ctypes.c_int), ("nsrc", ctypes.c_int), ("nrec", ctypes.c_int),
                     ("ntap", ctypes.c_int), ("free_surface", ctypes.c_int),
-                    ("source_type", ctypes.c_int)]
+                    ("source_type", ctypes.c_int), ("fd_order", ctypes.c_int)]
     return ElCfg
 
 
 def _elastic_forward(self, mat, pz, px, f, src_cell, src_w, rec_cell, rec_w, save=False,
-                     free_surface=0, source_type=0, pressure=False):
+                     free_surface=0, source_type=0, pressure=False, fd_order=4):
     """mat [5,nz,nx]; pz [6,nz]; px [6,nx]; f [nt,ns,nsrc] -> rec_vx, rec_vz [nt,ns,nrec]
     (and S [nt,ns,5,nz,nx] when save).  source_type 0: f added to sxx and szz; 1 / 2: to vx / vz."""
     mat = self._r(mat); pz = self._r(pz); px = self._r(px); f = self._r(f)
@@ -193,7 +193,7 @@ def _elastic_forward(self, mat, pz, px, f, src_cell, src_w, rec_cell, rec_w, sav
     _, nz, nx = mat.shape
     nt, ns, nsrc = f.shape
     nrec, ntap = rec_cell.shape[1], rec_cell.shape[2]
-    cfg = _el_cfg()(nz, nx, nt, ns, nsrc, nrec, ntap, free_surface, source_type)
+    cfg = _el_cfg()(nz, nx, nt, ns, nsrc, nrec, ntap, free_surface, source_type, fd_order)
     rvx = np.zeros((nt, ns, nrec), dtype=self.dtype)
     rvz = np.zeros((nt, ns, nrec), dtype=self.dtype)
     S = np.zeros((nt, ns, 5, nz, nx), dtype=self.dtype) if save else None
@@ -209,7 +209,7 @@ def _elastic_forward(self, mat, pz, px, f, src_cell, src_w, rec_cell, rec_w, sav
 
 
 def _elastic_backward(self, mat, pz, px, src_cell, src_w, rec_cell, rec_w, g_vx, g_vz, S,
-                      want_grad_f=True, free_surface=0, source_type=0, g_p=None):
+                      want_grad_f=True, free_surface=0, source_type=0, g_p=None, fd_order=4):
     mat = self._r(mat); pz = self._r(pz); px = self._r(px)
     g_vx = self._r(g_vx); g_vz = self._r(g_vz); S = self._r(S)
     g_p = None if g_p is None else self._r(g_p)
@@ -218,7 +218,7 @@ def _elastic_backward(self, mat, pz, px, src_cell, src_w, rec_cell, rec_w, g_vx,
     _, nz, nx = mat.shape
     nt, ns, nrec = g_vx.shape
     nsrc, ntap = src_cell.shape[1], src_cell.shape[2]
-    cfg = _el_cfg()(nz, nx, nt, ns, nsrc, nrec, ntap, free_surface, source_type)
+    cfg = _el_cfg()(nz, nx, nt, ns, nsrc, nrec, ntap, free_surface, source_type, fd_order)
     gm = np.zeros((5, nz, nx), dtype=self.dtype)
     gf = np.zeros((nt, ns, nsrc), dtype=self.dtype) if want_grad_f else None
     st = self.lib.oracle_elastic_backward(ctypes.byref(cfg), self._p(mat), self._p(pz),

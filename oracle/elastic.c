@@ -61,15 +61,25 @@ typedef float real;
 #define FMA(a, b, c) fmaf((a), (b), (c))
 #endif
 
-#define C1 ((real)(9.0 / 8.0))
-#define C2 ((real)(-1.0 / 24.0))
+/* Staggered first-derivative weights: Taylor order 4 (9/8, -1/24) or order 2 (1, 0) in the same four-point form
+ * (cfg.fd_order; DENISE FD_ORDER).  File-scope: set at the head of each entry point (tests call them one at a time). */
+static real gC1 = (real)(9.0 / 8.0), gC2 = (real)(-1.0 / 24.0);
+#define C1 gC1
+#define C2 gC2
 #define HALO 2
 
 typedef struct {
     int nz, nx, nt, nshot, nsrc, nrec, ntap;
     int free_surface;       /* 1: stress-imaging free surface on row 0 (see header) */
     int source_type;        /* 0: explosive (sxx, szz), 1: force on vx, 2: force on vz */
+    int fd_order;           /* 4 (or 0) / 2 */
 } oracle_elastic_cfg;
+
+static void set_order(const oracle_elastic_cfg *c)
+{
+    if (c->fd_order == 2) { gC1 = (real)1; gC2 = (real)0; }
+    else { gC1 = (real)(9.0 / 8.0); gC2 = (real)(-1.0 / 24.0); }
+}
 
 typedef struct {
     int nz, nx;
@@ -165,6 +175,7 @@ int oracle_elastic_forward(const oracle_elastic_cfg *c, const real *mat, const r
                            real *S, real *rec_p)
 {
     if (c->free_surface && c->nz < 3) return 2;
+    set_order(c);
     geom g = {c->nz, c->nx, (size_t)(c->nx + 2 * HALO), 0};
     g.n = (size_t)(c->nz + 2 * HALO) * g.p;
     const int ns = c->nshot, nx = c->nx;
@@ -254,6 +265,7 @@ int oracle_elastic_backward(const oracle_elastic_cfg *c, const real *mat, const 
                             const real *g_p)
 {
     if (c->free_surface && c->nz < 3) return 2;
+    set_order(c);
     geom g = {c->nz, c->nx, (size_t)(c->nx + 2 * HALO), 0};
     g.n = (size_t)(c->nz + 2 * HALO) * g.p;
     const int ns = c->nshot, nx = c->nx, nz = c->nz;

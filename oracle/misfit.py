@@ -50,3 +50,19 @@ def l1_trace_normalized(pred, obs_norm, direct=None, dtype=np.float64):
 def l2_half(pred, obs, dtype=np.float64):
     r = np.asarray(pred, dtype=dtype) - np.asarray(obs, dtype=dtype)
     return dtype(0.5 * (r * r).sum()), r
+
+
+def global_correlation(pred, obs, dtype=np.float64):
+    """DENISE's global-correlation norm (Choi & Alkhalifah 2012): per trace (time on axis 0)
+    -<s, o> / (|s| |o|), summed over traces; a dead trace on either side contributes nothing.
+    Returns (loss, dloss/dpred)."""
+    s = np.asarray(pred, dtype=dtype)
+    o = np.asarray(obs, dtype=dtype)
+    nt = s.shape[0]
+    sf, of = s.reshape(nt, -1), o.reshape(nt, -1)
+    ss, oo, so = (sf * sf).sum(0), (of * of).sum(0), (sf * of).sum(0)
+    ok = (ss > 0) & (oo > 0)
+    den = np.where(ok, np.sqrt(ss) * np.sqrt(oo), 1.0)
+    c = np.where(ok, so / den, 0.0)
+    adj = np.where(ok, -1.0 / den, 0.0) * of + np.where(ok, c / np.where(ok, ss, 1.0), 0.0) * sf
+    return dtype(-c.sum()), adj.reshape(s.shape)

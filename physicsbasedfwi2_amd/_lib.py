@@ -40,7 +40,7 @@ class ElasticDesc(ctypes.Structure):
                 ("ntap", ctypes.c_int32), ("pml_width", ctypes.c_int32),
                 ("free_surface", ctypes.c_int32), ("shots_per_group", ctypes.c_int32),
                 ("source_type", ctypes.c_int32), ("record_pressure", ctypes.c_int32),
-                ("snapshot_format", ctypes.c_int32)]
+                ("snapshot_format", ctypes.c_int32), ("fd_order", ctypes.c_int32)]
 
 
 class ElasticLayout(ctypes.Structure):
@@ -84,9 +84,13 @@ SIGNATURES = {
     "mifwi_misfit_work_elems": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64]),
     "mifwi_misfit": (ctypes.c_int, [ctypes.c_int, ctypes.c_int32] + [_P] * 3 + [ctypes.c_int64] * 2 +
                      [_P] * 4),
+    "mifwi_gradient_condition_work_elems": (ctypes.c_int64, [ctypes.c_int32]),
+    "mifwi_gradient_condition": (ctypes.c_int, [ctypes.c_int] + [_P] * 3 + [ctypes.c_int32] * 3 + [_P, ctypes.c_float] +
+                                 [ctypes.c_int32] * 2 + [_P] * 3),
 }
 MISFIT_L1_TRACE_NORM = 0
 MISFIT_L2 = 1
+MISFIT_GLOBAL_CORRELATION = 2
 
 _lib = None
 

@@ -220,6 +220,7 @@ class Denise:
         self.fwi_stages = []
         self._observed = None
         self._gradients = None
+        self._gradients_dev = None
         self._shots = None
         self._shots_p = None
         self._observed_p = None
@@ -266,7 +267,11 @@ class Denise:
             torch.device("cuda", torch.cuda.current_device())
         h = model.dx
         vmax = float(model.vp.max())
-        limit = profiles.elastic_cfl_limit(h, vmax)
+        # FD_ORDER (left commented at networks.py:10447): 2 or 4 are built (Taylor weights, MAXRELERROR = 0)
+        if int(self.FD_ORDER) not in (2, 4):
+            raise MifwiError("FD_ORDER=%s not implemented: the staggered-grid stencils are built for order 2 "
+                             "and 4" % self.FD_ORDER)
+        limit = profiles.elastic_cfl_limit(h, vmax, int(self.FD_ORDER))
         dt = float(self.DT) if self.DT else _nice_dt(limit)
         if dt > limit:
             raise MifwiError("DT=%g s violates the stability limit %g s (h=%g m, vp_max=%g m/s)"
@@ -334,7 +339,8 @@ class Denise:
         if kind != "explosive":
             f = elastic.force_amplitude(f, mat, g["sc"], g["sw"], h, kind)
         out = elastic.propagate(mat, f, pz, px, g["sc"], g["sw"], g["rc"], g["rw"], fw,
-                                free_surface=fsurf, source_type=kind, record_pressure=self.SEISMO in (2, 4))
+                                free_surface=fsurf, source_type=kind, record_pressure=self.SEISMO in (2, 4),
+                                fd_order=int(self.FD_ORDER))
         # DENISE's pressure seismogram: p = -(sxx + syy) at the receiver node
         return (out[0], out[1], -out[2]) if len(out) == 3 else (out[0], out[1], None)
 
@@ -382,16 +388,22 @@ class Denise:
         st = self.fwi_stages[-1] if self.fwi_stages else dict(fc_low=0.0, fc_high=0.0, order=6, lnorm=2)
         fl = lambda a: butterworth(a, dt, st.get("fc_low", 0.0), st.get("fc_high", 0.0),
                                    st.get("order", 6))
-        # L2 objective (lnorm = 2) and its adjoint sources in one fused pass each (csrc/mifwi_misfit.hip)
+        # objective and adjoint sources in one fused pass per component (csrc/mifwi_misfit.hip): lnorm = 2 is the
+        # L2 norm every stage of the reference asks for (networks.py:7761, 9863, 10503); 5 is DENISE's
+        # global-correlation norm (numbering as in the DENISE manual; DENISE itself is not in the reference tree)
+        lnorm = int(st.get("lnorm", 2))
+        if lnorm not in (2, 5):
+            raise MifwiError("lnorm=%s not implemented (2: L2, 5: global correlation)" % lnorm)
+        objective = misfit.l2_half if lnorm == 2 else misfit.global_correlation
         loss = 0.0
         if self.QUELLTYPB in (1, 2):
-            loss = loss + misfit.l2_half(fl(vy), fl(oy))
+            loss = loss + objective(fl(vy), fl(oy))
         if self.QUELLTYPB in (1, 3):
-            loss = loss + misfit.l2_half(fl(vx), fl(ox))
+            loss = loss + objective(fl(vx), fl(ox))
         if self.QUELLTYPB == 4:
             if self._observed_p is None:
                 raise MifwiError("QUELLTYPB=4: pass the observed pressure with set_observed(vx, vy, p=...)")
-            loss = loss + misfit.l2_half(fl(p), fl(self._observed_p.to(dev).permute(1, 0, 2)))
+            loss = loss + objective(fl(p), fl(self._observed_p.to(dev).permute(1, 0, 2)))
         loss.backward()
         self.loss = float(loss.detach())
         with open("loss_curve_grad.out", "w") as fh:
@@ -402,6 +414,7 @@ class Denise:
             w = torch.tensor(gradient_taper(model.ny, h, self.GRADT1, self.GRADT2, self.GRADT3, self.GRADT4,
                                             self.EXP_TAPER_GRAD_HOR), device=dev)[:, None]
             grads = [g * w for g in grads]
+        self._gradients_dev = torch.stack(grads)           # [vp, vs, rho] on the device, row 0 = surface
         gvp, gvs, grho = (np.flipud(g.cpu().numpy()).copy() for g in grads)
         self._gradients = {"rho": grho, "vp": gvp, "vs": gvs}
         self.DT_used = dt
@@ -417,6 +430,24 @@ class Denise:
         sel = [n for n in names if all(k in n for k in keys)]
         out = [self._gradients[n.rsplit("_", 1)[1].split(".")[0]] for n in sel]
         return (out, sel) if return_filenames else out
+
+
+def conditioned_gradients(d, vp, vs, rho, mute_rows=25, rho_factor=0.1, sigma=0.0):
+    """What models/networks.py:7799-7862 (9877-9919; 10514-10560 with ``sigma=3, mute_rows=5``) computes from
+    ``d.get_fwi_gradients`` on the host - flipud back, zero the top rows, rescale every gradient to
+    max(model)/max(gradient), rho x 0.1 - in one device call on the gradients ``d.grad`` left on the GPU
+    (csrc/mifwi_gradient.hip).  ``vp, vs, rho``: the models whose maxima set the scale (the reference's
+    ``vpst, vsst, rhost``), [nz, nx], any device.  Returns (vp_grad, vs_grad, rho_grad) CUDA float tensors in the
+    network's orientation (row 0 = surface), ready for ``fake_Vp.backward(vp_grad)``."""
+    from .. import conditioning
+    if getattr(d, "_gradients_dev", None) is None:
+        raise MifwiError("run grad() first")
+    dev = d._gradients_dev.device
+    models = torch.stack([torch.as_tensor(np.ascontiguousarray(m) if isinstance(m, np.ndarray) else m)
+                          .to(device=dev, dtype=torch.float32) for m in (vp, vs, rho)])
+    out = conditioning.condition_gradients(d._gradients_dev, models, None, sigma, False, mute_rows,
+                                           (1.0, 1.0, rho_factor))
+    return out[0], out[1], out[2]
 
 
 def gradients_allreduce(d, group=None):

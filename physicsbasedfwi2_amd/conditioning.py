@@ -1,7 +1,8 @@
 """The O(data) host expressions that surround the propagator call inside the reference's
 ``prop()`` methods: trace normalisation and L1 misfit (models/networks.py:5418-5419,
 5467-5476), shot shuffle / strided mini-batch (5434-5440, 5454-5461), gradient conditioning
-(5329-5332, 5492-5493; 7808-7862).  Plain torch / numpy; the fused HIP misfit lives in misfit.py.
+(5329-5332, 5492-5493; 7808-7862).  Plain torch / numpy; the fused HIP misfit lives in misfit.py, the fused HIP
+gradient conditioning (:func:`condition_gradients`) in csrc/mifwi_gradient.hip.
 """
 import numpy as np
 import torch
@@ -80,3 +81,39 @@ def condition_elastic_gradients_on_device(g_vp, g_vs, g_rho, vp, vs, rho, mute_r
         gg[0:mute_rows, :] = 0.0
         outs.append(gg * (torch.as_tensor(m).max().to(gg.device) / gg.max()) * fac)
     return outs
+
+
+def condition_gradients(grads, models=None, row_weight=None, sigma=0.0, flip=False, mute_rows=0, factors=None):
+    """The whole post-processing of the model gradients in ONE library call on the device the gradients live on
+    (csrc/mifwi_gradient.hip; no CPU path): depth taper -> scipy's Gaussian smoothing -> top mute -> max-ratio
+    rescale, i.e. networks.py:7808-7862 (``flip=True, mute_rows=25, factors=(1, 1, 0.1)``) and 10522-10540
+    (``flip=True, sigma=3, mute_rows=5``) without numpy round trips.
+
+    grads [k, nz, nx] (k <= 4) CUDA tensor, as stored (``flip`` makes output row j read stored row nz-1-j);
+    models [k, nz, nx] or None: ``out_k *= max(models_k) / max(out_k)``;  row_weight [nz] (indexed like the stored
+    rows) or None;  factors: k floats.  Returns a new [k, nz, nx] tensor."""
+    import ctypes
+    from . import _lib
+    if not grads.is_cuda:
+        raise _lib.MifwiError("condition_gradients needs CUDA/HIP tensors (libmifwi has no CPU fallback)")
+    lib = _lib.load()
+    g = grads.detach().to(dtype=torch.float32).contiguous()
+    if g.dim() != 3 or not 1 <= g.shape[0] <= 4:
+        raise ValueError("grads must be [k, nz, nx] with k <= 4")
+    k, nz, nx = g.shape
+    dev = g.device
+    m = None if models is None else torch.as_tensor(models).to(device=dev, dtype=torch.float32).contiguous()
+    if m is not None and tuple(m.shape) != tuple(g.shape):
+        raise ValueError("models must have the shape of grads")
+    w = None if row_weight is None else torch.as_tensor(row_weight).to(device=dev, dtype=torch.float32).contiguous()
+    if w is not None and tuple(w.shape) != (nz,):
+        raise ValueError("row_weight must be [nz]")
+    fac = None if factors is None else (ctypes.c_float * k)(*[float(v) for v in factors])
+    out = torch.empty_like(g)
+    work = torch.empty(lib.mifwi_gradient_condition_work_elems(k), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(lib.mifwi_gradient_condition(dev.index or 0, _lib.ptr(g), _lib.ptr(m), _lib.ptr(out), k, nz, nx,
+                                                _lib.ptr(w), float(sigma), int(bool(flip)), int(mute_rows),
+                                                ctypes.cast(fac, ctypes.c_void_p) if fac is not None else None,
+                                                _lib.ptr(work), torch.cuda.current_stream(dev).cuda_stream))
+    return out

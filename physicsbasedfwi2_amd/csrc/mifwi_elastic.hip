@@ -36,8 +36,13 @@ constexpr int kThreads = 256;
 #ifndef MIFWI_EL_MINWAVES
 #define MIFWI_EL_MINWAVES 1
 #endif
-constexpr float C1 = (float)(9.0 / 8.0);
-constexpr float C2 = (float)(-1.0 / 24.0);
+// staggered-grid first-derivative weights (mifwi_elastic_desc.fd_order): Taylor order 4 = (9/8, -1/24),
+// order 2 = (1, 0) - the same four-point form, so every kernel serves both
+struct FdK { float c1, c2; };
+inline FdK fd_weights(int order)
+{
+    return order == 2 ? FdK{1.0f, 0.0f} : FdK{(float)(9.0 / 8.0), (float)(-1.0 / 24.0)};
+}
 
 enum { F_VX = 0, F_VZ = 1, F_SXX = 2, F_SZZ = 3, F_SXZ = 4 };
 enum { M_L = 0, M_M = 1, M_MU = 2, M_BX = 3, M_BZ = 4 };
@@ -75,6 +80,7 @@ struct ElParams {
     float *smp_out0, *smp_out1;
     int tiles_z;
     int xcd;                     // 1: XCD-contiguous tile order (xcd_tile)
+    FdK K;                       // stencil weights
 };
 
 __device__ __forceinline__ float comp(const float4 &v, int c)
@@ -84,13 +90,13 @@ __device__ __forceinline__ float comp(const float4 &v, int c)
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
 __device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
-__device__ __forceinline__ float dfw(float fm1, float f0, float f1, float f2)   // Dp at "0"
+__device__ __forceinline__ float dfw(const FdK &K, float fm1, float f0, float f1, float f2)   // Dp at "0"
 {
-    return fmaf(C1, f1 - f0, C2 * (f2 - fm1));
+    return fmaf(K.c1, f1 - f0, K.c2 * (f2 - fm1));
 }
-__device__ __forceinline__ float dbw(float fm2, float fm1, float f0, float f1)  // Dm at "0"
+__device__ __forceinline__ float dbw(const FdK &K, float fm2, float fm1, float f0, float f1)  // Dm at "0"
 {
-    return fmaf(C1, f0 - fm1, C2 * (f1 - fm2));
+    return fmaf(K.c1, f0 - fm1, K.c2 * (f1 - fm2));
 }
 // forward C-PML: psi <- b psi + a d ; returns d*ik + psi
 __device__ __forceinline__ float pml(float &psi, float a, float b, float ik, float d)
@@ -178,23 +184,36 @@ __device__ __forceinline__ int zstrip(const ElParams &p, int j)
 
 // Workgroups are dealt to the 8 XCDs round-robin in launch order, each XCD with an L2 of its own: with
 // the plain blockIdx -> tile map, neighbouring tiles never share an L2 and every halo row/column is
-// fetched from memory again.  Remap so that each XCD walks one contiguous, row-major run of the
-// (x, y) tiles of its z slice (a bijection on [0, gridDim.x * gridDim.y)).
-__device__ __forceinline__ void xcd_tile(const ElParams &p, int &bx, int &by)
+// fetched from memory again.  Remap (a bijection on the launch grid):
+//  * z slices (shots / shot groups) in full sets of eight: XCD c takes the slices c, c+8, ... WHOLE, walking
+//    each in row-major tile order - every halo a tile reads was fetched by the same L2 one tile row earlier
+//    (measured on 350x1700, 8 shots per launch: the halo rows of a 2.7-tile-row run per XCD came from the
+//    other XCDs' runs, i.e. from beyond L2);
+//  * the remaining slices: each XCD walks one contiguous, row-major run of the (x, y) tiles of the slice.
+__device__ __forceinline__ void xcd_tile(const ElParams &p, int &bx, int &by, int &bz)
 {
-    bx = (int)blockIdx.x; by = (int)blockIdx.y;
+    bx = (int)blockIdx.x; by = (int)blockIdx.y; bz = (int)blockIdx.z;
     if (!p.xcd) return;
     const unsigned gx = gridDim.x, n2 = gx * gridDim.y;
-    const unsigned L = blockIdx.x + gx * blockIdx.y;
-    const unsigned c = L & 7u, idx = L >> 3, q = n2 >> 3, r = n2 & 7u;
-    const unsigned T = c * q + (c < r ? c : r) + idx;
+    const unsigned z8 = gridDim.z & ~7u;
+    unsigned T;
+    if (blockIdx.z < z8) {
+        const unsigned L = blockIdx.x + gx * blockIdx.y + n2 * blockIdx.z;
+        const unsigned c = L & 7u, idx = L >> 3, zl = idx / n2;
+        T = idx - zl * n2;
+        bz = (int)(c + 8u * zl);
+    } else {
+        const unsigned L = blockIdx.x + gx * blockIdx.y;
+        const unsigned c = L & 7u, idx = L >> 3, q = n2 >> 3, r = n2 & 7u;
+        T = c * q + (c < r ? c : r) + idx;
+    }
     by = (int)(T / gx); bx = (int)(T - (unsigned)by * gx);
 }
 
 // ------------------------------------------------------------------------------------------------
 // sampling workgroups.  mode 0: out0 = sum w vx, out1 = sum w vz ; mode 1: out0 = sum w (sxx+szz)
 template <int MODE>
-__device__ void sample_points(const ElParams &p, int bx, int by)
+__device__ void sample_points(const ElParams &p, int bx, int by, int bz)
 {
     if (p.smp_out0 == nullptr) return;
     const int nrb = (int)(gridDim.y - p.tiles_z) * (int)gridDim.x;
@@ -202,7 +221,7 @@ __device__ void sample_points(const ElParams &p, int bx, int by)
     const int total = p.gs * p.nsmp;
     for (int e = rb * (int)blockDim.x + (int)threadIdx.x; e < total; e += nrb * (int)blockDim.x) {
         const int si = e / p.nsmp, ip = e - si * p.nsmp;
-        const int s = p.s0 + (int)blockIdx.z * p.gs + si;
+        const int s = p.s0 + bz * p.gs + si;
         if (s >= p.nshot) continue;
         const float *fl = p.fields + (long long)s * p.shot_stride;
         float a0 = 0.f, a1 = 0.f;
@@ -261,14 +280,15 @@ __device__ bool stage_injection(const ElParams &p, int s, int tile_j, int tile_i
 template <int LX, int RZ, int SAVE>       // SAVE 0: no snapshots, 1: f32 planes, 2: bf16 planes
 __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const ElParams p)
 {
+    const FdK K = p.K;
     constexpr int LZ = kThreads / LX;
     const int lx = (int)threadIdx.x % LX, lz = (int)threadIdx.x / LX;
-    int bx, by;
-    xcd_tile(p, bx, by);
+    int bx, by, bz;
+    xcd_tile(p, bx, by, bz);
     const int g = bx * LX + lx;
     const int j0 = (by * LZ + lz) * RZ;
     if (g >= p.ng || j0 >= p.nz) return;
-    const int s = p.s0 + (int)blockIdx.z;
+    const int s = p.s0 + bz;
     const unsigned fs = p.field_stride;
     float *fl = p.fields + (long long)s * p.shot_stride;
     const float *sxx = fl + F_SXX * fs, *szz = fl + F_SZZ * fs, *sxz = fl + F_SXZ * fs;
@@ -336,10 +356,10 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
             float d1[4], d2[4], d3[4], d4[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                d1[c] = dfw(xx[c + 1], xx[c + 2], xx[c + 3], xx[c + 4]);
-                d2[c] = dbw(comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
-                d3[c] = dbw(xz[c], xz[c + 1], xz[c + 2], xz[c + 3]);
-                d4[c] = dfw(comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
+                d1[c] = dfw(K, xx[c + 1], xx[c + 2], xx[c + 3], xx[c + 4]);
+                d2[c] = dbw(K, comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
+                d3[c] = dbw(K, xz[c], xz[c + 1], xz[c + 2], xz[c + 3]);
+                d4[c] = dfw(K, comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
             }
             if (xs_off >= 0) {
                 float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t3[4] = {s3.x, s3.y, s3.z, s3.w};
@@ -389,12 +409,13 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
 template <int LX, int RZ, int SAVE>
 __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const ElParams p)
 {
+    const FdK K = p.K;
     constexpr int LZ = kThreads / LX;
     constexpr int TZ = LZ * RZ, TX = LX * 4;
-    int bx, by;
-    xcd_tile(p, bx, by);
+    int bx, by, bz;
+    xcd_tile(p, bx, by, bz);
     if (by >= p.tiles_z) {
-        sample_points<0>(p, bx, by);
+        sample_points<0>(p, bx, by, bz);
         return;
     }
     __shared__ float inj[TZ * TX];
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const E
         pxbh = ld4(p.px + PBH * p.gp + 4 * g); pxkh = ld4(p.px + PKH * p.gp + 4 * g);
     }
     for (int si = 0; si < p.gs; ++si) {
-        const int s = p.s0 + (int)blockIdx.z * p.gs + si;
+        const int s = p.s0 + bz * p.gs + si;
         if (s >= p.nshot) break;
         const bool has_inj = stage_injection<TZ, TX, 1>(p, s, tile_j, tile_i, inj);
         if (active) {
@@ -446,10 +467,10 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const E
                     float e1[4], e2[4], e3[4], e4[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        e1[c] = dbw(xv[c], xv[c + 1], xv[c + 2], xv[c + 3]);
-                        e2[c] = dbw(comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
-                        e3[c] = dfw(comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
-                        e4[c] = dfw(zv[c + 1], zv[c + 2], zv[c + 3], zv[c + 4]);
+                        e1[c] = dbw(K, xv[c], xv[c + 1], xv[c + 2], xv[c + 3]);
+                        e2[c] = dbw(K, comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
+                        e3[c] = dfw(K, comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
+                        e4[c] = dfw(K, zv[c + 1], zv[c + 2], zv[c + 3], zv[c + 4]);
                     }
                     if (xs_off >= 0) {
                         float *q5 = p.psix + (long long)s * p.psix_shot + ((long long)2 * p.nz + j) * p.wx + xs_off;
@@ -613,10 +634,11 @@ __device__ __forceinline__ void stage_E(const ElParams &p, int s, int j, int g, 
 template <bool BF16>
 __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
 {
-    int bx, by;
-    xcd_tile(p, bx, by);
+    const FdK K = p.K;
+    int bx, by, bz;
+    xcd_tile(p, bx, by, bz);
     if (by >= p.tiles_z) {
-        sample_points<1>(p, bx, by);
+        sample_points<1>(p, bx, by, bz);
         return;
     }
     __shared__ float E[4][ASZ][ASX];
@@ -643,7 +665,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
     if (own_ok) {
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            acc[k] = ld4(p.acc + ((long long)(p.s0 / p.gs + (int)blockIdx.z) * 5 + k) * ncell + occ);
+            acc[k] = ld4(p.acc + ((long long)(p.s0 / p.gs + bz) * 5 + k) * ncell + occ);
         own.m0 = ld4(p.mat + M_L * ncell + occ); own.m1 = ld4(p.mat + M_M * ncell + occ);
         own.m2 = ld4(p.mat + M_MU * ncell + occ);
     }
@@ -652,7 +674,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
         halo.m2 = ld4(p.mat + M_MU * ncell + hcc);
     }
     for (int si = 0; si < p.gs; ++si) {
-        const int s = p.s0 + (int)blockIdx.z * p.gs + si;
+        const int s = p.s0 + bz * p.gs + si;
         if (s >= p.nshot) break;
         float *fl = p.fields + (long long)s * p.shot_stride;
         float4 vxb = zero4, vzb = zero4, S1 = zero4, S2 = zero4, S3 = zero4, S4 = zero4, S5 = zero4;
@@ -704,10 +726,10 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
             const float4 z2c = ld4(&E[1][r + 1][cb]), z2d = ld4(&E[1][r + 2][cb]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float dx1 = dfw(x1.v[c + 1], x1.v[c + 2], x1.v[c + 3], x1.v[c + 4]);
-                const float dz3 = dbw(comp(z3a, c), comp(z3b, c), comp(z3c, c), comp(z3d, c));
-                const float dz2 = dfw(comp(z2a, c), comp(z2b, c), comp(z2c, c), comp(z2d, c));
-                const float dx4 = dbw(x4.v[c], x4.v[c + 1], x4.v[c + 2], x4.v[c + 3]);
+                const float dx1 = dfw(K, x1.v[c + 1], x1.v[c + 2], x1.v[c + 3], x1.v[c + 4]);
+                const float dz3 = dbw(K, comp(z3a, c), comp(z3b, c), comp(z3c, c), comp(z3d, c));
+                const float dz2 = dfw(K, comp(z2a, c), comp(z2b, c), comp(z2c, c), comp(z2d, c));
+                const float dx4 = dbw(K, x4.v[c], x4.v[c + 1], x4.v[c + 2], x4.v[c + 3]);
                 float ax = comp(vxb, c) - (dx1 + dz3);
                 float az = comp(vzb, c) - (dz2 + dx4);
                 if (4 * og + c >= p.nx) { ax = 0.f; az = 0.f; }
@@ -738,7 +760,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
     if (own_ok) {
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            st4(p.acc + ((long long)(p.s0 / p.gs + (int)blockIdx.z) * 5 + k) * ncell + occ, acc[k]);
+            st4(p.acc + ((long long)(p.s0 / p.gs + bz) * 5 + k) * ncell + occ, acc[k]);
     }
 }
 
@@ -797,12 +819,13 @@ __device__ __forceinline__ void stage_D(const ElParams &p, int s, int j, int g, 
 // V^T:  D = B^T v_bar through the transposed C-PML;  sigma_bar -= stencils(D)
 __global__ __launch_bounds__(kThreads) void el_adj_v(const ElParams p)
 {
+    const FdK K = p.K;
     __shared__ float D[4][ASZ][ASX];
-    int bx, by;
-    xcd_tile(p, bx, by);
+    int bx, by, bz;
+    xcd_tile(p, bx, by, bz);
     const int tile_j = by * ATZ;
     const int tile_g = bx * AGO;
-    const int s = p.s0 + (int)blockIdx.z;
+    const int s = p.s0 + bz;
     const unsigned fs = p.field_stride;
     const unsigned ncell = (unsigned)p.nz * p.gp;
     const int t = (int)threadIdx.x;
@@ -858,17 +881,17 @@ __global__ __launch_bounds__(kThreads) void el_adj_v(const ElParams p)
         if (p.fsurf && oj < 2) { m12 = ld4(&D[1][2][cb]); m13 = ld4(&D[1][3][cb]); m32 = ld4(&D[3][2][cb]); }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float dx1 = dbw(x1.v[c], x1.v[c + 1], x1.v[c + 2], x1.v[c + 3]);
-            const float dz2 = dfw(comp(z2a, c), comp(z2b, c), comp(z2c, c), comp(z2d, c));
-            const float dx3 = dfw(x3.v[c + 1], x3.v[c + 2], x3.v[c + 3], x3.v[c + 4]);
-            const float dz4 = dbw(comp(z4a, c), comp(z4b, c), comp(z4c, c), comp(z4d, c));
+            const float dx1 = dbw(K, x1.v[c], x1.v[c + 1], x1.v[c + 2], x1.v[c + 3]);
+            const float dz2 = dfw(K, comp(z2a, c), comp(z2b, c), comp(z2c, c), comp(z2d, c));
+            const float dx3 = dfw(K, x3.v[c + 1], x3.v[c + 2], x3.v[c + 3], x3.v[c + 4]);
+            const float dz4 = dbw(K, comp(z4a, c), comp(z4b, c), comp(z4c, c), comp(z4d, c));
             nxx[c] = comp(bxx, c) - dx1;
             nxz[c] = comp(bxz, c) - (dz2 + dx3);
             nzz[c] = comp(bzz, c) - dz4;
             if (p.fsurf && oj < 2) {
                 // transposed odd mirroring (tile_j == 0 here: staged row 2 is grid row 0)
-                if (oj == 0) nxz[c] = nxz[c] + fmaf(C1, comp(m12, c), C2 * comp(m13, c));
-                else { nxz[c] = nxz[c] + C2 * comp(m12, c); nzz[c] = nzz[c] + C2 * comp(m32, c); }
+                if (oj == 0) nxz[c] = nxz[c] + fmaf(K.c1, comp(m12, c), K.c2 * comp(m13, c));
+                else { nxz[c] = nxz[c] + K.c2 * comp(m12, c); nzz[c] = nzz[c] + K.c2 * comp(m32, c); }
             }
             if (4 * og + c >= p.nx) { nxx[c] = 0.f; nxz[c] = 0.f; nzz[c] = 0.f; }
         }
@@ -883,7 +906,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_v(const ElParams p)
 // receivers of the state in p.fields (the last step of a fused range)
 __global__ __launch_bounds__(kThreads) void el_sample_v(const ElParams p)
 {
-    sample_points<0>(p, (int)blockIdx.x, (int)blockIdx.y);
+    sample_points<0>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 // ---- point forces (source_type 1 / 2): a handful of cells per shot, launches of their own ---------------------
@@ -1075,6 +1098,7 @@ ElParams el_base(const mifwi_elastic_plan *pl, const float *mat, const float *pz
     p.mat = mat; p.pz = pz; p.px = px;
     p.xcd = pl->xcd;
     p.snap_shot = pl->snap_shot;
+    p.K = fd_weights(pl->d.fd_order);
     return p;
 }
 
@@ -1248,6 +1272,8 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
         return mifwi::fail(MIFWI_EINVAL, "record_pressure must be 0 or 1");
     if (d->source_type < 0 || d->source_type > 2)
         return mifwi::fail(MIFWI_EINVAL, "source_type must be 0 (explosive), 1 (force x) or 2 (force z)");
+    if (d->fd_order != 0 && d->fd_order != 2 && d->fd_order != 4)
+        return mifwi::fail(MIFWI_EINVAL, "fd_order %d: the staggered-grid stencils are built for order 2 and 4", d->fd_order);
     if (d->snapshot_format != MIFWI_SNAPSHOT_F32 && d->snapshot_format != MIFWI_SNAPSHOT_BF16)
         return mifwi::fail(MIFWI_EINVAL, "snapshot_format must be MIFWI_SNAPSHOT_F32 or MIFWI_SNAPSHOT_BF16");
     int rc = mifwi::check_device(device);
@@ -1257,6 +1283,7 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     MIFWI_HIP_TRY(hipSetDevice(device));
     mifwi_elastic_plan *pl = new mifwi_elastic_plan;
     pl->d = *d;
+    if (pl->d.fd_order == 0) pl->d.fd_order = 4;
     pl->device = device;
     pl->rec_p = nullptr; pl->g_p = nullptr;
     pl->ng = mifwi::ceil_div(d->nx, 4);
@@ -1459,6 +1486,7 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
         c.rec_vx = want_rec ? rec_vx : nullptr; c.rec_vz = want_rec ? rec_vz : nullptr;
         c.dbg = env_int("MIFWI_EL_CL_DBG", 0);
         c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(d.nz, c.NW) >= 8 ? 48 : 1);   // mifwi::poll_nap
+        c.K = fd_weights(d.fd_order);
         float *backup = xbuf + pl->xbuf_elems;
         rc = el_cluster_backup(work, pl->fields_elems + psi, backup, flags, st);
         if (rc) return rc;
@@ -1631,6 +1659,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         c.slab_cnt = lists; c.slab_list = lists + (long long)d.nshot * pl->adj_NW;
         c.dbg = env_int("MIFWI_EL_CL_DBG", 0);
         c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(d.nz, c.NW) >= 8 ? 48 : 1);   // mifwi::poll_nap
+        c.K = fd_weights(d.fd_order);
         MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
         c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
         c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);

@@ -40,6 +40,7 @@ struct EcParams {
     unsigned long long *xbuf;            // [nshot][NW][2 kinds][2 parities][8*gp] granules
     int *err;
     int dbg, nap;
+    FdK K;                               // stencil weights (fd_order)
 };
 
 __device__ __forceinline__ void ec_slab_rows(int nz, int NW, int w, int &r0, int &rows)
@@ -193,6 +194,7 @@ struct EcCtx {
     float *Lf[5];
     const float *lpx, *lpz;
     int PL, R, gp, fsurf;
+    FdK K;
 };
 
 // V update (reads stresses from LDS, writes the group's velocities in place)
@@ -201,6 +203,7 @@ __device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const in
                                             float4 &o1)
 {
     const int PL = c.PL;
+    const FdK K = c.K;
     const float *sxx = c.Lf[F_SXX] + lo, *szz = c.Lf[F_SZZ] + lo, *sxz = c.Lf[F_SXZ] + lo;
     const float4 cxx = ld4(sxx);
     const float2 Lxx = ld2(sxx - 2), Rxx = ld2(sxx + 4);
@@ -224,10 +227,10 @@ __device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const in
     float d1[4], d2[4], d3[4], d4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        d1[k] = dfw(xx[k + 1], xx[k + 2], xx[k + 3], xx[k + 4]);
-        d2[k] = dbw(comp(a0, k), comp(a1, k), comp(a2, k), comp(a3, k));
-        d3[k] = dbw(xz[k], xz[k + 1], xz[k + 2], xz[k + 3]);
-        d4[k] = dfw(comp(b0, k), comp(b1, k), comp(b2, k), comp(b3, k));
+        d1[k] = dfw(K, xx[k + 1], xx[k + 2], xx[k + 3], xx[k + 4]);
+        d2[k] = dbw(K, comp(a0, k), comp(a1, k), comp(a2, k), comp(a3, k));
+        d3[k] = dbw(K, xz[k], xz[k + 1], xz[k + 2], xz[k + 3]);
+        d4[k] = dfw(K, comp(b0, k), comp(b1, k), comp(b2, k), comp(b3, k));
     }
     if (G.xs_off >= 0) {
         const float *q = c.lpx + 4 * gq;
@@ -271,6 +274,7 @@ __device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const in
                                             float4 &S3, float4 &o0, float4 &o1)
 {
     const int PL = c.PL;
+    const FdK K = c.K;
     const float *vx = c.Lf[F_VX] + lo, *vz = c.Lf[F_VZ] + lo;
     const float4 b1 = ld4(vx);
     const float2 Lvx = ld2(vx - 2), Rvx = ld2(vx + 4);
@@ -283,10 +287,10 @@ __device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const in
     float e1[4], e2[4], e3[4], e4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        e1[k] = dbw(xv[k], xv[k + 1], xv[k + 2], xv[k + 3]);
-        e2[k] = dbw(comp(a0, k), comp(a1, k), comp(a2, k), comp(a3, k));
-        e3[k] = dfw(comp(b0, k), comp(b1, k), comp(b2, k), comp(b3, k));
-        e4[k] = dfw(zv[k + 1], zv[k + 2], zv[k + 3], zv[k + 4]);
+        e1[k] = dbw(K, xv[k], xv[k + 1], xv[k + 2], xv[k + 3]);
+        e2[k] = dbw(K, comp(a0, k), comp(a1, k), comp(a2, k), comp(a3, k));
+        e3[k] = dfw(K, comp(b0, k), comp(b1, k), comp(b2, k), comp(b3, k));
+        e4[k] = dfw(K, zv[k + 1], zv[k + 2], zv[k + 3], zv[k + 4]);
     }
     if (G.xs_off >= 0) {
         const float *q = c.lpx + 4 * gq;
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     EcCtx c;
     for (int k = 0; k < 5; ++k) c.Lf[k] = lds + k * fsz;
     float *lpx = lds + 5 * fsz, *lpz = lpx + 6 * p.gp;        // C-PML tables: px [6][gp], pz [6][R]
-    c.lpx = lpx; c.lpz = lpz; c.PL = PL; c.R = R; c.gp = p.gp; c.fsurf = p.fsurf;
+    c.lpx = lpx; c.lpz = lpz; c.PL = PL; c.R = R; c.gp = p.gp; c.fsurf = p.fsurf; c.K = p.K;
     const unsigned ncell = (unsigned)p.nz * p.gp;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long xplane = (long long)p.nz * p.wx, zplane = 2LL * p.W * p.gp;
@@ -629,6 +633,7 @@ struct EaParams {
     unsigned long long *xbuf;
     int *err;
     int dbg, nap;
+    FdK K;                               // stencil weights (fd_order)
 };
 
 // receivers of each slab (adjoint sources), one block per shot
@@ -667,6 +672,7 @@ template <int NG>
 __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const FdK K = p.K;
     const int L = (int)blockIdx.x;
     const int xcd = L & 7, kq = L >> 3;
     const int w = kq % p.NW, s = p.shot0 + xcd + 8 * (kq / p.NW);
@@ -902,10 +908,10 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         float nvx[4], nvz[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float dx1 = dfw(x1[c + 1], x1[c + 2], x1[c + 3], x1[c + 4]);
-            const float dz3 = dbw(comp(t0, c), comp(t1, c), comp(t2, c), comp(t3, c));
-            const float dz2 = dfw(comp(u0, c), comp(u1, c), comp(u2, c), comp(u3, c));
-            const float dx4 = dbw(x4[c], x4[c + 1], x4[c + 2], x4[c + 3]);
+            const float dx1 = dfw(K, x1[c + 1], x1[c + 2], x1[c + 3], x1[c + 4]);
+            const float dz3 = dbw(K, comp(t0, c), comp(t1, c), comp(t2, c), comp(t3, c));
+            const float dz2 = dfw(K, comp(u0, c), comp(u1, c), comp(u2, c), comp(u3, c));
+            const float dx4 = dbw(K, x4[c], x4[c + 1], x4[c + 2], x4[c + 3]);
             nvx[c] = comp(g.vx, c) - (dx1 + dz3);
             nvz[c] = comp(g.vz, c) - (dz2 + dx4);
             if (4 * gq + c >= p.nx) { nvx[c] = 0.f; nvz[c] = 0.f; }
@@ -992,10 +998,10 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         float nxx[4], nzz[4], nxz[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float dx1 = dbw(x1[c], x1[c + 1], x1[c + 2], x1[c + 3]);
-            const float dz2 = dfw(comp(u0, c), comp(u1, c), comp(u2, c), comp(u3, c));
-            const float dx3 = dfw(x3[c + 1], x3[c + 2], x3[c + 3], x3[c + 4]);
-            const float dz4 = dbw(comp(t0, c), comp(t1, c), comp(t2, c), comp(t3, c));
+            const float dx1 = dbw(K, x1[c], x1[c + 1], x1[c + 2], x1[c + 3]);
+            const float dz2 = dfw(K, comp(u0, c), comp(u1, c), comp(u2, c), comp(u3, c));
+            const float dx3 = dfw(K, x3[c + 1], x3[c + 2], x3[c + 3], x3[c + 4]);
+            const float dz4 = dbw(K, comp(t0, c), comp(t1, c), comp(t2, c), comp(t3, c));
             nxx[c] = comp(g.bxx, c) - dx1;
             nxz[c] = comp(g.bxz, c) - (dz2 + dx3);
             nzz[c] = comp(g.bzz, c) - dz4;
@@ -1006,8 +1012,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             const float4 r0d4 = ld4(pln + 3 * fsz + 2 * PL + 4 + 4 * gq);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (jq == 0) nxz[c] = nxz[c] + fmaf(C1, comp(r0d2, c), C2 * comp(r1d2, c));
-                else { nxz[c] = nxz[c] + C2 * comp(r0d2, c); nzz[c] = nzz[c] + C2 * comp(r0d4, c); }
+                if (jq == 0) nxz[c] = nxz[c] + fmaf(K.c1, comp(r0d2, c), K.c2 * comp(r1d2, c));
+                else { nxz[c] = nxz[c] + K.c2 * comp(r0d2, c); nzz[c] = nzz[c] + K.c2 * comp(r0d4, c); }
             }
         }
 #pragma unroll

@@ -50,6 +50,7 @@ __device__ __forceinline__ void fwd_v_update(const ElParams &p, int s, int j, in
                                              const float *Lxz, int lr, int lc, const FwdV &in, bool mine,
                                              float4 &vxn, float4 &vzn, float *s4v, float *s5v)
 {
+    const FdK K = p.K;
     // windows: sxz rows j-2..j+1 (a0..a3), szz rows j-1..j+2 (b0..b3); the FRS-row planes start two rows earlier
     float4 a0 = lds4(Lxz + (lr + 0) * FSW + lc), a1 = lds4(Lxz + (lr + 1) * FSW + lc);
     const float4 a2 = lds4(Lxz + (lr + 2) * FSW + lc), a3 = lds4(Lxz + (lr + 3) * FSW + lc);
@@ -71,10 +72,10 @@ __device__ __forceinline__ void fwd_v_update(const ElParams &p, int s, int j, in
     float d1[4], d2[4], d3[4], d4[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        d1[c] = dfw(xx.v[c + 1], xx.v[c + 2], xx.v[c + 3], xx.v[c + 4]);
-        d2[c] = dbw(comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
-        d3[c] = dbw(xz.v[c], xz.v[c + 1], xz.v[c + 2], xz.v[c + 3]);
-        d4[c] = dfw(comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
+        d1[c] = dfw(K, xx.v[c + 1], xx.v[c + 2], xx.v[c + 3], xx.v[c + 4]);
+        d2[c] = dbw(K, comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
+        d3[c] = dbw(K, xz.v[c], xz.v[c + 1], xz.v[c + 2], xz.v[c + 3]);
+        d4[c] = dfw(K, comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
     }
     const int xs_off = xstrip(p, g);
     if (xs_off >= 0) {
@@ -126,10 +127,11 @@ __device__ __forceinline__ void fwd_v_update(const ElParams &p, int s, int j, in
 template <int SNAP>      // 0: no snapshots, 1: f32 planes, 2: bf16 planes
 __global__ __launch_bounds__(kThreads, 4) void el_fwd_fused(const ElParams p)
 {
-    int bx, by;
-    xcd_tile(p, bx, by);
+    const FdK K = p.K;
+    int bx, by, bz;
+    xcd_tile(p, bx, by, bz);
     if (by >= p.tiles_z) {
-        sample_points<0>(p, bx, by);
+        sample_points<0>(p, bx, by, bz);
         return;
     }
     __shared__ __attribute__((aligned(16))) float Lxz[FRS * FSW];
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(kThreads, 4) void el_fwd_fused(const ElParams p)
     __shared__ __attribute__((aligned(16))) float Vz[FRV * FSW];
     __shared__ float inj[FTZ * 4 * FTG];
     const int tile_j = by * FTZ, tile_g = bx * FTG;
-    const int s = p.s0 + (int)blockIdx.z;
+    const int s = p.s0 + bz;
     const unsigned fs = p.field_stride;
     const unsigned ncell = (unsigned)p.nz * p.gp;
     const int t = (int)threadIdx.x;
@@ -239,10 +241,10 @@ __global__ __launch_bounds__(kThreads, 4) void el_fwd_fused(const ElParams p)
         float e1[4], e2[4], e3[4], e4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            e1[c] = dbw(xv.v[c], xv.v[c + 1], xv.v[c + 2], xv.v[c + 3]);
-            e2[c] = dbw(comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
-            e3[c] = dfw(comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
-            e4[c] = dfw(zv.v[c + 1], zv.v[c + 2], zv.v[c + 3], zv.v[c + 4]);
+            e1[c] = dbw(K, xv.v[c], xv.v[c + 1], xv.v[c + 2], xv.v[c + 3]);
+            e2[c] = dbw(K, comp(a0, c), comp(a1, c), comp(a2, c), comp(a3, c));
+            e3[c] = dfw(K, comp(b0, c), comp(b1, c), comp(b2, c), comp(b3, c));
+            e4[c] = dfw(K, zv.v[c + 1], zv.v[c + 2], zv.v[c + 3], zv.v[c + 4]);
         }
         const int xs_off = xstrip(p, og);
         if (xs_off >= 0) {
@@ -324,6 +326,7 @@ __device__ __forceinline__ void adj_v_update(const ElParams &p, int g, const flo
                                              const float *E4, int lr, int lc, const float4 &vxb, const float4 &vzb,
                                              float *nvx, float *nvz)
 {
+    const FdK K = p.K;
     const Row8 x1 = row8(E1 + lr * FSW, lc), x4 = row8(E4 + lr * FSW, lc);
     const float4 z3a = lds4(E3 + (lr + 0) * FSW + lc), z3b = lds4(E3 + (lr + 1) * FSW + lc);
     const float4 z3c = lds4(E3 + (lr + 2) * FSW + lc), z3d = lds4(E3 + (lr + 3) * FSW + lc);
@@ -331,10 +334,10 @@ __device__ __forceinline__ void adj_v_update(const ElParams &p, int g, const flo
     const float4 z2c = lds4(E2 + (lr + 3) * FSW + lc), z2d = lds4(E2 + (lr + 4) * FSW + lc);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float dx1 = dfw(x1.v[c + 1], x1.v[c + 2], x1.v[c + 3], x1.v[c + 4]);
-        const float dz3 = dbw(comp(z3a, c), comp(z3b, c), comp(z3c, c), comp(z3d, c));
-        const float dz2 = dfw(comp(z2a, c), comp(z2b, c), comp(z2c, c), comp(z2d, c));
-        const float dx4 = dbw(x4.v[c], x4.v[c + 1], x4.v[c + 2], x4.v[c + 3]);
+        const float dx1 = dfw(K, x1.v[c + 1], x1.v[c + 2], x1.v[c + 3], x1.v[c + 4]);
+        const float dz3 = dbw(K, comp(z3a, c), comp(z3b, c), comp(z3c, c), comp(z3d, c));
+        const float dz2 = dfw(K, comp(z2a, c), comp(z2b, c), comp(z2c, c), comp(z2d, c));
+        const float dx4 = dbw(K, x4.v[c], x4.v[c + 1], x4.v[c + 2], x4.v[c + 3]);
         float ax = comp(vxb, c) - (dx1 + dz3);
         float az = comp(vzb, c) - (dz2 + dx4);
         if (4 * g + c >= p.nx) { ax = 0.f; az = 0.f; }
@@ -379,10 +382,11 @@ __device__ __forceinline__ FHalo f_halo(const ElParams &p, int t, int tile_j, in
 template <bool BF16>
 __global__ __launch_bounds__(kThreads, 3) void el_adj_fused(const ElParams p)
 {
-    int bx, by;
-    xcd_tile(p, bx, by);
+    const FdK K = p.K;
+    int bx, by, bz;
+    xcd_tile(p, bx, by, bz);
     if (by >= p.tiles_z) {
-        sample_points<1>(p, bx, by);
+        sample_points<1>(p, bx, by, bz);
         return;
     }
     __shared__ __attribute__((aligned(16))) float buf[kAFElems];      // 53,760 B: three workgroups per CU
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(kThreads, 3) void el_adj_fused(const ElParams p)
     float4 acc[5];
     {
         const FOwn o = f_own(p, t, tile_j, tile_g);
-        const long long acc_base = (long long)(p.s0 / p.gs + (int)blockIdx.z) * 5 * ncell + o.occ;
+        const long long acc_base = (long long)(p.s0 / p.gs + bz) * 5 * ncell + o.occ;
         if (o.ok) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) acc[k] = ld4(p.acc + acc_base + (long long)k * ncell);
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(kThreads, 3) void el_adj_fused(const ElParams p)
         sts4(buf + e * FSW + FSW - 4, zero4);
     }
     for (int si = 0; si < p.gs; ++si) {
-        const int s = p.s0 + (int)blockIdx.z * p.gs + si;
+        const int s = p.s0 + bz * p.gs + si;
         if (s >= p.nshot) break;
         const float *fin = p.fields + (long long)s * p.shot_stride;
         float *fout = p.fields_out + (long long)s * p.shot_stride;
@@ -545,17 +549,17 @@ __global__ __launch_bounds__(kThreads, 3) void el_adj_fused(const ElParams p)
                 if (p.fsurf && o.oj < 2) { m12 = lds4(D2 + 2 * FSW + cb); m13 = lds4(D2 + 3 * FSW + cb); m32 = lds4(D4 + 2 * FSW + cb); }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float dx1 = dbw(x1.v[c], x1.v[c + 1], x1.v[c + 2], x1.v[c + 3]);
-                    const float dz2 = dfw(comp(z2a, c), comp(z2b, c), comp(z2c, c), comp(z2d, c));
-                    const float dx3 = dfw(x3.v[c + 1], x3.v[c + 2], x3.v[c + 3], x3.v[c + 4]);
-                    const float dz4 = dbw(comp(z4a, c), comp(z4b, c), comp(z4c, c), comp(z4d, c));
+                    const float dx1 = dbw(K, x1.v[c], x1.v[c + 1], x1.v[c + 2], x1.v[c + 3]);
+                    const float dz2 = dfw(K, comp(z2a, c), comp(z2b, c), comp(z2c, c), comp(z2d, c));
+                    const float dx3 = dfw(K, x3.v[c + 1], x3.v[c + 2], x3.v[c + 3], x3.v[c + 4]);
+                    const float dz4 = dbw(K, comp(z4a, c), comp(z4b, c), comp(z4c, c), comp(z4d, c));
                     nxx[c] = comp(sxx0, c) - dx1;
                     nxz[c] = comp(sxz0, c) - (dz2 + dx3);
                     nzz[c] = comp(szz0, c) - dz4;
                     if (p.fsurf && o.oj < 2) {
                         // transposed odd mirroring (tile_j == 0 here: row 2 of the planes is grid row 0)
-                        if (o.oj == 0) nxz[c] = nxz[c] + fmaf(C1, comp(m12, c), C2 * comp(m13, c));
-                        else { nxz[c] = nxz[c] + C2 * comp(m12, c); nzz[c] = nzz[c] + C2 * comp(m32, c); }
+                        if (o.oj == 0) nxz[c] = nxz[c] + fmaf(K.c1, comp(m12, c), K.c2 * comp(m13, c));
+                        else { nxz[c] = nxz[c] + K.c2 * comp(m12, c); nzz[c] = nzz[c] + K.c2 * comp(m32, c); }
                     }
                     if (4 * o.og + c >= p.nx) { nxx[c] = 0.f; nxz[c] = 0.f; nzz[c] = 0.f; }
                 }
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(kThreads, 3) void el_adj_fused(const ElParams p)
     }
     {
         const FOwn o = f_own(p, f_opaque(t), tile_j, tile_g);
-        const long long acc_base = (long long)(p.s0 / p.gs + (int)blockIdx.z) * 5 * ncell + o.occ;
+        const long long acc_base = (long long)(p.s0 / p.gs + bz) * 5 * ncell + o.occ;
         if (o.ok) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) st4(p.acc + acc_base + (long long)k * ncell, acc[k]);

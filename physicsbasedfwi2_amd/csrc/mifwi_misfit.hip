@@ -7,6 +7,10 @@
 //       adj = dloss/dpred (what autograd's backward of those lines delivers to the propagator)
 //   kind L2             seisgan/fwi/layers.py:176-178 and DENISE lnorm=2 (networks.py:7758):
 //       loss = 1/2 sum (pred - obs)^2;  adj = pred - obs
+//   kind GLOBAL_CORRELATION  (DENISE's global-correlation norm, the `lnorm` argument of add_fwi_stage at
+//       models/networks.py:9863, 10503; Choi & Alkhalifah 2012): per trace s = pred, o = obs
+//       loss = - sum_traces <s, o> / (|s| |o|);  adj = -(o/|o| - <s,o>/(|s||o|) s/|s|) / |s|
+//       (a trace with |s| = 0 or |o| = 0 contributes nothing)
 // Layout [nt][ntrace] (trace = shot*nrec + receiver fastest), i.e. the propagators' own output.
 //
 // One workgroup = 64 neighbouring traces x 16 interleaved time slices: every wave reads whole
@@ -87,6 +91,45 @@ __global__ __launch_bounds__(kTr *kSl) void misfit_l1_trace_norm(const float *pr
     }
 }
 
+// global correlation: pass 1 the three inner products of a trace (fp64, fixed order), pass 2 the adjoint source
+__global__ __launch_bounds__(kTr *kSl) void misfit_global_correlation(const float *pred, const float *obs, int nt,
+                                                                      long long ntrace, float *adj, double *partial)
+{
+    __shared__ double s_ss[kSl][kTr], s_oo[kSl][kTr], s_so[kSl][kTr];
+    __shared__ double s_loss[kSl];
+    const int lane = (int)threadIdx.x % kTr, sl = (int)threadIdx.x / kTr;
+    const long long tr = (long long)blockIdx.x * kTr + lane;
+    const bool live = tr < ntrace;
+    double ss = 0.0, oo = 0.0, so = 0.0;
+    if (live)
+        for (int t = sl; t < nt; t += kSl) {
+            const long long o = (long long)t * ntrace + tr;
+            const double a = (double)pred[o], b = (double)obs[o];
+            ss += a * a; oo += b * b; so += a * b;
+        }
+    s_ss[sl][lane] = ss; s_oo[sl][lane] = oo; s_so[sl][lane] = so;
+    __syncthreads();
+    ss = oo = so = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSl; ++k) { ss += s_ss[k][lane]; oo += s_oo[k][lane]; so += s_so[k][lane]; }
+    const bool ok = live && ss > 0.0 && oo > 0.0;
+    const double ns = sqrt(ss), no = sqrt(oo);
+    const double c = ok ? so / (ns * no) : 0.0;
+    if (adj && live) {
+        const float ka = ok ? (float)(-1.0 / (ns * no)) : 0.f;        // coefficient of o
+        const float kb = ok ? (float)(c / ss) : 0.f;                  // coefficient of s
+        for (int t = sl; t < nt; t += kSl) {
+            const long long o = (long long)t * ntrace + tr;
+            adj[o] = fmaf(ka, obs[o], kb * pred[o]);
+        }
+    }
+    double loss = sl == 0 ? -c : 0.0;                                   // one slice speaks for the trace
+    for (int off = 32; off > 0; off >>= 1) loss += __shfl_down(loss, off, 64);
+    if (lane == 0) s_loss[sl] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_loss[0];
+}
+
 __global__ __launch_bounds__(256) void misfit_l2(const float *pred, const float *obs, long long n, float *adj,
                                                  double *partial)
 {
@@ -148,9 +191,10 @@ int mifwi_misfit(int device, int32_t kind, const float *pred, const float *obs, 
     if (!pred || !obs || !loss_out || !work) return mifwi::fail(MIFWI_EINVAL, "null argument");
     if (nt < 1 || ntrace < 1 || nt > 0x7fffffff)
         return mifwi::fail(MIFWI_EINVAL, "bad sizes nt=%lld ntrace=%lld", (long long)nt, (long long)ntrace);
-    if (kind != MIFWI_MISFIT_L1_TRACE_NORM && kind != MIFWI_MISFIT_L2)
+    if (kind != MIFWI_MISFIT_L1_TRACE_NORM && kind != MIFWI_MISFIT_L2 && kind != MIFWI_MISFIT_GLOBAL_CORRELATION)
         return mifwi::fail(MIFWI_EINVAL, "unknown misfit kind %d", kind);
-    if (kind == MIFWI_MISFIT_L2 && direct) return mifwi::fail(MIFWI_EINVAL, "L2 misfit takes no direct wave");
+    if (kind != MIFWI_MISFIT_L1_TRACE_NORM && direct)
+        return mifwi::fail(MIFWI_EINVAL, "only the trace-normalised L1 misfit takes a direct wave");
     if ((reinterpret_cast<uintptr_t>(work) & 7) != 0) return mifwi::fail(MIFWI_EINVAL, "work must be 8-byte aligned");
     int rc = mifwi::check_device(device);
     if (rc) return rc;
@@ -169,6 +213,12 @@ int mifwi_misfit(int device, int32_t kind, const float *pred, const float *obs, 
             hipLaunchKernelGGL(misfit_l1_trace_norm<false>, dim3((unsigned)blocks), dim3(kTr * kSl), 0, st, pred, obs,
                                direct, (int)nt, (long long)ntrace, inv_n, adj_out, partial);
         hipLaunchKernelGGL(misfit_finish, dim3(1), dim3(256), 0, st, partial, (int)blocks, 1.0 / (double)n, loss_out);
+    } else if (kind == MIFWI_MISFIT_GLOBAL_CORRELATION) {
+        const long long blocks = (ntrace + kTr - 1) / kTr;
+        if (blocks > 0x7fffffff) return mifwi::fail(MIFWI_EINVAL, "too many traces");
+        hipLaunchKernelGGL(misfit_global_correlation, dim3((unsigned)blocks), dim3(kTr * kSl), 0, st, pred, obs, (int)nt,
+                           (long long)ntrace, adj_out, partial);
+        hipLaunchKernelGGL(misfit_finish, dim3(1), dim3(256), 0, st, partial, (int)blocks, 1.0, loss_out);
     } else {
         const int blocks = l2_blocks(n);
         hipLaunchKernelGGL(misfit_l2, dim3(blocks), dim3(256), 0, st, pred, obs, n, adj_out, partial);

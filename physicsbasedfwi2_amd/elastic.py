@@ -85,11 +85,12 @@ def staggered_materials(vp, vs, rho, dt, h, free_surface=False):
 
 class ElasticPlan:
     def __init__(self, nz, nx, nt, nshot, nsrc, nrec, ntap, pml_width, device_index,
-                 shots_per_group=0, free_surface=0, source_type=0, record_pressure=0, snapshot_format=None):
+                 shots_per_group=0, free_surface=0, source_type=0, record_pressure=0, snapshot_format=None,
+                 fd_order=4):
         self._lib = _lib.load()
         fmt = SNAPSHOT_FORMATS[snapshot_format or snapshot_mode()]
         self.desc = _lib.ElasticDesc(nz, nx, nt, nshot, nsrc, nrec, ntap, pml_width,
-                                     free_surface, shots_per_group, source_type, record_pressure, fmt)
+                                     free_surface, shots_per_group, source_type, record_pressure, fmt, fd_order)
         self._h = ctypes.c_void_p()
         _lib.check(self._lib.mifwi_elastic_plan_create(ctypes.byref(self._h), device_index,
                                                        ctypes.byref(self.desc)))
@@ -126,7 +127,7 @@ class ElasticPlan:
 class _ElasticFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mat, f, pz, px, geom, pml_width, shots_per_group, snapshot_budget, free_surface,
-                source_type=0, record_pressure=0, snapshot_format=None):
+                source_type=0, record_pressure=0, snapshot_format=None, fd_order=4):
         _require_cuda(mat, "mat")
         dev = mat.device
         lib = _lib.load()
@@ -142,7 +143,8 @@ class _ElasticFn(torch.autograd.Function):
             raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (nz, nx))
         with torch.cuda.device(dev):
             plan = ElasticPlan(nz, nx, nt, ns, nsrc, nrec, ntap, pml_width, dev.index,
-                               shots_per_group, free_surface, source_type, record_pressure, snapshot_format)
+                               shots_per_group, free_surface, source_type, record_pressure, snapshot_format,
+                               fd_order)
             lay = plan.layout
             gp = lay.gp
             mat_p = torch.zeros((5, nz, gp), device=dev, dtype=torch.float32)
@@ -255,12 +257,12 @@ class _ElasticFn(torch.autograd.Function):
             ctx.plan = None
             ctx.snap = None
             ctx.ckpt = None
-        return (grad_mat[:, :, :nx].contiguous(), grad_f) + (None,) * 10
+        return (grad_mat[:, :, :nx].contiguous(), grad_f) + (None,) * 11
 
 
 def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
               shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET, free_surface=False,
-              source_type="explosive", record_pressure=False, snapshot_format=None):
+              source_type="explosive", record_pressure=False, snapshot_format=None, fd_order=4):
     """Elastic forward modelling, differentiable w.r.t. ``mat`` and ``f``.
 
     mat [5,nz,nx] from :func:`staggered_materials`;  f [nt,nshot,nsrc] (added to sxx and szz);
@@ -270,6 +272,8 @@ def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
     pz [6,nz], px [6,nx] from :func:`profiles.cpml_tables`;  cells are iz*nx+ix.
     free_surface: row 0 is a stress-free surface (build ``mat`` with ``free_surface=True`` and
     ``pz`` with ``low=False``).
+    fd_order: 4 (default) or 2 - spatial order of the staggered first derivatives (DENISE ``FD_ORDER``); the time
+    step must respect the order's own stability limit (:func:`profiles.elastic_cfl_limit`).
     snapshot_format: "f32" (default; the gradient is the exact discrete adjoint) or "bf16": the forward snapshot
     planes are kept as bf16 (half the snapshot stream and memory; material gradients within 4e-3 rel-L2 of the
     f32 form in the worst case, seismograms unchanged) on grids that run the per-step kernels; None = MIFWI_EL_SNAP or "f32".
@@ -287,7 +291,7 @@ def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
         raise MifwiError("snapshot_format must be one of %s" % sorted(SNAPSHOT_FORMATS))
     rvx, rvz, rp = _ElasticFn.apply(mat, f, pz, px, geom, int(pml_width), int(shots_per_group),
                                     int(snapshot_budget), 1 if free_surface else 0, st,
-                                    1 if record_pressure else 0, snapshot_format)
+                                    1 if record_pressure else 0, snapshot_format, int(fd_order))
     return (rvx, rvz, rp) if record_pressure else (rvx, rvz)
 
 

@@ -8,7 +8,10 @@ Drop-in for the torch expressions the reference evaluates between the propagator
 * ``l2_half(pred, obs)`` -- ``0.5 * sum((pred - obs)**2)``, seisgan/fwi/layers.py:176-178 and
   DENISE's lnorm = 2 objective (networks.py:7758)
 
-Both return a 0-d tensor that back-propagates into ``pred`` (one kernel pass produces the loss and
+* ``global_correlation(pred, obs)`` -- ``-sum_traces <pred, obs> / (|pred| |obs|)``, DENISE's global-correlation
+  norm (the ``lnorm`` argument of ``add_fwi_stage``, models/networks.py:9863, 10503)
+
+All return a 0-d tensor that back-propagates into ``pred`` (one kernel pass produces the loss and
 dloss/dpred).  No CPU fallback: CPU tensors raise.
 """
 import torch
@@ -53,3 +56,8 @@ def l1_trace_normalized(pred, obs_norm, direct=None):
 def l2_half(pred, obs):
     """0.5 * sum((pred - obs)**2)."""
     return _MisfitFn.apply(pred, obs, None, _lib.MISFIT_L2)
+
+
+def global_correlation(pred, obs):
+    """-sum over traces of <pred, obs> / (|pred| |obs|), time on axis 0 (insensitive to trace amplitudes)."""
+    return _MisfitFn.apply(pred, obs, None, _lib.MISFIT_GLOBAL_CORRELATION)

@@ -50,9 +50,10 @@ def scalar_cfl_limit(spacing, vp_max):
     return 2.0 / (vp_max * math.sqrt(s))
 
 
-def elastic_cfl_limit(h, vp_max):
-    """4th-order staggered grid (9/8, -1/24) in 2-D: dt <= h / (vp sqrt(2) (9/8 + 1/24))."""
-    return h / (vp_max * math.sqrt(2.0) * (9.0 / 8.0 + 1.0 / 24.0))
+def elastic_cfl_limit(h, vp_max, fd_order=4):
+    """Staggered grid in 2-D: dt <= h / (vp sqrt(2) sum|c_k|) - (9/8 + 1/24) for order 4, 1 for order 2."""
+    w = 1.0 if int(fd_order) == 2 else 9.0 / 8.0 + 1.0 / 24.0
+    return h / (vp_max * math.sqrt(2.0) * w)
 
 
 # ------------------------------------------------------------------------------ time axis --

@@ -57,7 +57,7 @@ def test_struct_layouts_match_header(tmp_path):
         assert int(got[cname]) == ctypes.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
-    assert ctypes.sizeof(_lib.ElasticDesc) == 13 * 4
+    assert ctypes.sizeof(_lib.ElasticDesc) == 14 * 4
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device error path")

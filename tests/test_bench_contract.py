@@ -98,7 +98,7 @@ def test_committed_bench_line_has_the_contract_fields():
         assert 0 < r["frac"] <= 1.0 and r["cells"] == "interior"
         assert r["traffic"] is None or (r["traffic"] > 0 and r["traffic_profiled_at"])
         assert e["check"]["bitwise_repeatable"] is True and e["check"]["verified"] is True
-        assert e["check"]["loss"] > 1e-12 and e["check"]["grad_abs_sum"] > 1e-12
+        assert e["check"]["loss"] > 1e-8 and e["check"]["grad_abs_sum"] > 1e-8
         c = e["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "C oracle" in c["sample"]
         for k in e["kernels"].values():
@@ -112,27 +112,27 @@ def test_committed_bench_line_has_the_contract_fields():
 
 def test_pmc_tool_knows_the_kernels_the_bench_runs():
     """tools/pmc_traffic.py maps kernel names to bench labels by regular expression: every time-loop kernel of
-    the committed kernel-trace summaries must fall under exactly one label of its physics, set-up kernels
-    under none."""
+    this round's committed kernel-trace summaries must fall under exactly one label of its physics, set-up
+    kernels under none."""
     import csv
     import re
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_traffic
     seen = {}
     for fname in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-        if not fname.endswith("kernel_stats.csv"):
-            continue
-        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fname))):
-            seen[pmc_traffic.clean(r["Name"])] = fname
+        if fname.startswith(bench.PROFILE_ROUND) and fname.endswith("kernel_stats.csv"):
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fname))):
+                seen[pmc_traffic.clean(r["Name"])] = fname
     assert any(n.startswith("el_cluster_adj<") for n in seen) and any(n.startswith("ac_cluster<2,") for n in seen)
+    assert any(n.startswith(("el_fwd_fused<", "el_step_v<")) for n in seen) and any(n.startswith("el_adj_s<") for n in seen)
+    loop_re = (r"(ac_cluster<[12],|ac_step<\d+, \d+, (true, false|false, true)>|el_cluster_fwd<true|el_cluster_adj<|"
+               r"el_step_[vs]<\d+, \d+, [12]>|el_adj_s<|el_adj_v$|el_fwd_fused<[12]>|el_adj_fused<|el_inject_adjsrc$)")
     for n in seen:
         phys = "acoustic" if n.startswith("ac_") else "elastic" if n.startswith("el_") else None
         if phys is None:
             continue
         hits = [lab for lab, pats in pmc_traffic.LABELS[phys].items() if any(re.search(p, n) for p in pats)]
-        loop = re.match(r"(ac_cluster<[12],|ac_step<\d+, \d+, (true, false|false, true)>|el_cluster_fwd<true|el_cluster_adj<|"
-                        r"el_step_[vs]<\d+, \d+, true>|el_adj_[sv]$|el_fwd_fused<true|el_adj_fused)", n)
-        assert len(hits) == (1 if loop else 0), (n, hits)
+        assert len(hits) == (1 if re.match(loop_re, n) else 0), (n, hits)
 
 
 def test_gpus_without_a_launcher_starts_the_ranks_and_fails_loudly_when_one_fails():
@@ -156,20 +156,33 @@ def test_gpus_without_a_launcher_starts_the_ranks_and_fails_loudly_when_one_fail
 
 
 def test_xcd_tile_order_is_a_bijection_with_contiguous_runs():
-    """The per-step kernels remap blockIdx so that each XCD (launch order modulo 8) walks one contiguous
-    run of tiles (csrc: xcd_tile).  Same arithmetic here: a permutation for every grid shape, and the
-    tiles of one XCD are consecutive."""
-    for gx in (1, 3, 12, 47):
-        for gy in (1, 2, 7, 63, 250):
-            n2 = gx * gy
-            q, r = n2 >> 3, n2 & 7
-            seen, runs = set(), {}
-            for L in range(n2):
-                c, idx = L & 7, L >> 3
-                T = c * q + min(c, r) + idx
-                assert 0 <= T < n2
-                seen.add(T)
-                runs.setdefault(c, []).append(T)
-            assert len(seen) == n2
-            for c, ts in runs.items():
-                assert ts == list(range(ts[0], ts[0] + len(ts)))
+    """The per-step kernels remap blockIdx so that neighbouring tiles share an XCD's L2 (csrc: xcd_tile; launch
+    order modulo 8 = XCD).  Same arithmetic here: a permutation of the launch grid for every shape; z slices in
+    full sets of eight go WHOLE to one XCD each, in row-major tile order; in the remaining slices each XCD walks
+    one contiguous run of tiles."""
+    def remap(gx, gy, gz, x, y, z):
+        n2, z8 = gx * gy, gz & ~7
+        if z < z8:
+            L = x + gx * y + n2 * z
+            c, idx = L & 7, L >> 3
+            zl = idx // n2
+            T, bz = idx - zl * n2, c + 8 * zl
+        else:
+            L = x + gx * y
+            c, idx, q, r = L & 7, L >> 3, n2 >> 3, n2 & 7
+            T, bz = c * q + min(c, r) + idx, z
+        return T % gx, T // gx, bz, c
+    for gx, gy, gz in ((1, 1, 1), (3, 7, 1), (12, 2, 3), (47, 63, 1), (27, 22, 8), (27, 23, 17), (5, 3, 16)):
+        seen, per_xcd = set(), {}
+        for z in range(gz):
+            for y in range(gy):
+                for x in range(gx):
+                    bx, by, bz, c = remap(gx, gy, gz, x, y, z)
+                    assert 0 <= bx < gx and 0 <= by < gy and 0 <= bz < gz
+                    seen.add((bx, by, bz))
+                    per_xcd.setdefault((c, z >= (gz & ~7), bz), []).append(by * gx + bx)
+        assert len(seen) == gx * gy * gz
+        for (c, tail, bz), ts in per_xcd.items():
+            assert ts == list(range(ts[0], ts[0] + len(ts)))          # row-major, contiguous
+            if not tail:
+                assert len(ts) == gx * gy and bz % 8 == c              # the whole slice on one XCD

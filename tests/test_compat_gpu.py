@@ -88,6 +88,23 @@ def test_denise_grad_protocol_and_directional_derivative(tmp_path, monkeypatch):
                             src, rec))
     fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - lin) <= 0.03 * abs(fd), (fd, lin)
+    # the post-processing of networks.py:7808-7862 on the device (api.conditioned_gradients) = the host expressions
+    from physicsbasedfwi2_amd import conditioning as C
+    host = C.condition_elastic_gradients(grads[1], grads[2], grads[0], vp, vs, rho)      # vp, vs, rho order
+    devg = api.conditioned_gradients(d, vp, vs, rho)
+    for a, b in zip(host, devg):
+        assert b.is_cuda and torch.allclose(a, b.cpu(), rtol=2e-6, atol=0)
+    # lnorm = 5: the global-correlation norm drives the same protocol (loss in [-2 nrec nshot, 0])
+    d5 = api.Denise(None, 0)
+    for k in ("TIME", "DT", "FREE_SURF", "FW", "FPML", "DAMPING"):
+        setattr(d5, k, getattr(d, k))
+    d5.set_observed(np.transpose(ox, (0, 2, 1)), np.transpose(oy, (0, 2, 1)))
+    d5.add_fwi_stage(fc_high=10, inv_rho_iter=10000, lnorm=5)
+    l5 = d5.grad(model, src, rec)
+    assert -2.0 * len(rec) * len(src) <= l5 < 0 and np.abs(d5.get_fwi_gradients(["vp"])[0]).max() > 0
+    d5.fwi_stages[-1]["lnorm"] = 7
+    with pytest.raises(api.MifwiError if hasattr(api, "MifwiError") else Exception):
+        d5.grad(model, src, rec)
 
 
 def test_denise_free_surface_default_runs(oracle32, tmp_path):

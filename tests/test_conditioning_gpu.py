@@ -72,3 +72,47 @@ def test_misfit_expressions_and_gaussian_smoothing_on_device(golden_dir):
     a = rng.standard_normal((37, 53))
     sm = C.gaussian_smooth(torch.tensor(a, device=DEV), 3.0)
     assert np.abs(sm.cpu().numpy() - gaussian_filter(a, sigma=3.0)).max() < 1e-12
+
+
+@pytest.mark.parametrize("sigma,mute,flip", [(0.0, 25, True), (3.0, 5, True), (1.3, 0, False), (7.5, 3, True)])
+def test_fused_gradient_conditioning_kernel(golden_dir, sigma, mute, flip):
+    """csrc/mifwi_gradient.hip against the reference's host expressions evaluated with numpy / scipy:
+    networks.py:7808-7862 (flipud, mute, max-ratio, rho x 0.1), 10522-10540 (+ gaussian_filter) and a depth taper,
+    on ragged sizes (tiles of 32 x 64, Gaussian radius up to 30 cells)."""
+    from scipy.ndimage import gaussian_filter
+    from physicsbasedfwi2_amd import conditioning as C
+    rng = np.random.default_rng(21)
+    nz, nx = 77, 203
+    g = rng.standard_normal((3, nz, nx)).astype(np.float32)
+    m = (np.abs(rng.standard_normal((3, nz, nx))) * 1000 + 500).astype(np.float32)
+    w = (np.linspace(0.0, 2.0, nz) ** 2).astype(np.float32)
+    fac = (1.0, 1.0, 0.1)
+    ref = []
+    for k in range(3):
+        t = (g[k] * w[:, None]).astype(np.float32)
+        t = np.flipud(t) if flip else t
+        if sigma > 0:
+            t = gaussian_filter(t, sigma=sigma)
+        t = t.copy()
+        t[0:mute] = 0.0
+        ref.append(t * (np.max(m[k]) / np.max(t)) * fac[k])
+    out = C.condition_gradients(torch.tensor(g, device=DEV), torch.tensor(m, device=DEV), torch.tensor(w), sigma, flip,
+                                mute, fac)
+    assert out.device.type == "cuda"
+    o = out.cpu().numpy()
+    for k in range(3):
+        assert np.abs(o[k] - ref[k]).max() <= 2e-5 * np.abs(ref[k]).max(), k
+        assert float(np.abs(o[k][:mute]).max() if mute else 0.0) == 0.0
+    # the golden elastic pair (flipud, mute 25, ratio, rho x 0.1) through the same call
+    gd = _g(golden_dir)
+    out = C.condition_gradients(torch.tensor(gd["el_g"], device=DEV), torch.tensor(gd["el_m"], device=DEV), None, 0.0,
+                                True, 25, fac)
+    assert np.allclose(out.cpu().numpy(), gd["el_g_cond"], rtol=1e-6, atol=1e-6 * np.abs(gd["el_g_cond"]).max())
+    # no models: plain factors; bad arguments fail loudly
+    out = C.condition_gradients(torch.tensor(g, device=DEV), None, None, 0.0, False, 0, (2.0, 1.0, 1.0))
+    assert torch.equal(out[0].cpu(), torch.tensor(g[0]) * 2.0) and torch.equal(out[1].cpu(), torch.tensor(g[1]))
+    from physicsbasedfwi2_amd._lib import MifwiError
+    with pytest.raises(MifwiError):
+        C.condition_gradients(torch.tensor(g, device=DEV), sigma=9.0)
+    with pytest.raises(MifwiError):
+        C.condition_gradients(torch.tensor(g))

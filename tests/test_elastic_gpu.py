@@ -15,7 +15,7 @@ TOL_TRACE = 1e-6
 TOL_GRAD = 2e-5
 
 
-def _run_hip(case, gs=0, budget=None, need_f=True, source_type="explosive"):
+def _run_hip(case, gs=0, budget=None, need_f=True, source_type="explosive", fd_order=4):
     from physicsbasedfwi2_amd import elastic
     dev = torch.device("cuda:0")
     mat = torch.tensor(case["mat"], dtype=torch.float32, device=dev, requires_grad=True)
@@ -25,7 +25,7 @@ def _run_hip(case, gs=0, budget=None, need_f=True, source_type="explosive"):
                                  torch.tensor(case["sc"]), torch.tensor(case["sw"]),
                                  torch.tensor(case["rc"]), torch.tensor(case["rw"]),
                                  case["fw"], shots_per_group=gs, free_surface=bool(case["fs"]),
-                                 source_type=source_type, **kw)
+                                 source_type=source_type, fd_order=fd_order, **kw)
     return mat, f, rvx, rvz
 
 
@@ -41,11 +41,11 @@ def test_forward_backward_parity(oracle32, kw):
     _check_parity(oracle32, elastic_case(seed=4, **kw))
 
 
-def _check_parity(o, case, bitwise=False, source_type=0):
+def _check_parity(o, case, bitwise=False, source_type=0, fd_order=4):
     ovx, ovz, S = o.elastic_forward(case["mat"], case["pz"], case["px"], case["f"], case["sc"],
                                     case["sw"], case["rc"], case["rw"], save=True,
-                                    free_surface=case["fs"], source_type=source_type)
-    mat, f, rvx, rvz = _run_hip(case, source_type=source_type)
+                                    free_surface=case["fs"], source_type=source_type, fd_order=fd_order)
+    mat, f, rvx, rvz = _run_hip(case, source_type=source_type, fd_order=fd_order)
     hx, hz = rvx.detach().cpu().numpy(), rvz.detach().cpu().numpy()
     assert np.isfinite(hx).all() and np.abs(ovx).max() > 0 and np.abs(ovz).max() > 0
     print("max |hip-oracle| vx %.3e vz %.3e" % (np.abs(hx - ovx).max(), np.abs(hz - ovz).max()))
@@ -59,7 +59,7 @@ def _check_parity(o, case, bitwise=False, source_type=0):
                                          torch.tensor(gz, device=rvx.device)])
     gm_o, gf_o = o.elastic_backward(case["mat"], case["pz"], case["px"], case["sc"], case["sw"],
                                     case["rc"], case["rw"], gx, gz, S, free_surface=case["fs"],
-                                    source_type=source_type)
+                                    source_type=source_type, fd_order=fd_order)
     gm_h = mat.grad.cpu().numpy()
     for k, name in enumerate(["lambda", "lambda+2mu", "mu_xz", "1/rho_x", "1/rho_z"]):
         assert rel_l2(gm_h[k], gm_o[k]) <= TOL_GRAD, name
@@ -335,3 +335,23 @@ def test_bf16_request_on_a_single_launch_plan_keeps_f32():
     assert pl.cluster_slabs(False) >= 1 and pl.layout.snapshot_format == _lib.SNAPSHOT_F32
     assert pl.layout.snap_step_elems == 5 * 6 * pl.layout.coef_elems
     pl.close()
+
+
+@pytest.mark.parametrize("env", [
+    {},                                                                                   # single-launch kernels
+    {"MIFWI_EL_NW": "3"},                                                                 # ... with halo hand-off
+    {"MIFWI_EL_CLUSTER": "0", "MIFWI_EL_CLUSTER_ADJ": "0"},                               # one launch per half step
+    {"MIFWI_EL_CLUSTER": "0", "MIFWI_EL_CLUSTER_ADJ": "0", "MIFWI_EL_FUSED": "1", "MIFWI_EL_FUSED_ADJ": "1"},
+])
+def test_second_order_stencils(oracle32, monkeypatch, env):
+    """fd_order = 2 (DENISE FD_ORDER; weights (1, 0) in the four-point form) through every kernel family, with the
+    free surface: seismograms bit for bit, gradients <= 2e-5 against the oracle run at the same order - and not
+    the fourth-order answer."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case = elastic_case(seed=31, nz=61, nx=83, fw=8, ns=3, nrec=15, nt=110, free_surface=True)
+    _check_parity(oracle32, case, bitwise=True, fd_order=2)
+    ovx4, _ = oracle32.elastic_forward(case["mat"], case["pz"], case["px"], case["f"], case["sc"], case["sw"],
+                                       case["rc"], case["rw"], free_surface=1)
+    _, _, rvx, _ = _run_hip(case, fd_order=2)
+    assert rel_l2(rvx.detach().cpu().numpy(), ovx4) > 1e-3

@@ -90,3 +90,24 @@ def test_second_backward_through_a_retained_graph():
     rec.backward(torch.ones_like(rec), retain_graph=True)
     with pytest.raises(MifwiError, match="called twice"):
         rec.backward(torch.ones_like(rec))
+
+
+def test_global_correlation_matches_oracle():
+    from physicsbasedfwi2_amd import misfit
+    rng = np.random.default_rng(5)
+    nt, ns, nr = 301, 3, 70                             # ragged against the 64-trace / 16-slice tiling
+    pred = (rng.standard_normal((nt, ns, nr)) * rng.random((1, ns, nr)) * 10).astype(np.float32)
+    obs = (0.7 * pred + 0.5 * rng.standard_normal((nt, ns, nr))).astype(np.float32)
+    obs[:, 0, 3] = 0.0
+    pred[:, 2, 5] = 0.0
+    dev = torch.device("cuda:0")
+    p = torch.tensor(pred, device=dev, requires_grad=True)
+    loss = misfit.global_correlation(p, torch.tensor(obs, device=dev))
+    loss.backward()
+    l, g = M.global_correlation(pred, obs)
+    assert abs(float(loss.detach()) - l) <= 1e-5 * abs(l)
+    assert rel_l2(p.grad.cpu().numpy(), g) <= 1e-5
+    assert float(p.grad[:, 0, 3].abs().max()) == 0.0 and float(p.grad[:, 2, 5].abs().max()) == 0.0
+    # scaling a trace does not change the misfit
+    p2 = torch.tensor(pred * 3.0, device=dev)
+    assert abs(float(misfit.global_correlation(p2, torch.tensor(obs, device=dev))) - l) <= 1e-5 * abs(l)

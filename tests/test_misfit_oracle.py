@@ -49,3 +49,21 @@ def test_l2_half_matches_torch():
     lo, adj = M.l2_half(pred.detach().numpy(), obs.numpy())
     assert abs(lo - loss.item()) <= 1e-13 * loss.item()
     assert np.abs(adj - pred.grad.numpy()).max() <= 1e-14
+
+
+def test_global_correlation_oracle_matches_torch_autograd():
+    """-sum_traces <s,o>/(|s||o|) written with torch ops and differentiated by autograd."""
+    import torch
+    from oracle import misfit as M
+    rng = np.random.default_rng(3)
+    pred, obs = rng.standard_normal((40, 3, 5)), rng.standard_normal((40, 3, 5))
+    obs[:, 1, 2] = 0.0                                   # a dead observed trace
+    p = torch.tensor(pred, requires_grad=True)
+    o = torch.tensor(obs)
+    num = (p * o).sum(0)
+    den = p.pow(2).sum(0).sqrt() * o.pow(2).sum(0).sqrt()
+    loss = -(torch.where(den > 0, num / torch.where(den > 0, den, torch.ones_like(den)), torch.zeros_like(den))).sum()
+    loss.backward()
+    l, g = M.global_correlation(pred, obs)
+    assert abs(l - float(loss)) <= 1e-13 * abs(float(loss))
+    assert np.abs(g - p.grad.numpy()).max() <= 1e-14 and np.abs(g[:, 1, 2]).max() == 0.0

@@ -337,3 +337,61 @@ def test_elastic_pressure_receivers_adjoint_is_exact(oracle64):
     _, gq = o.elastic_backward(c["mat"], c["pz"], c["px"], *geo, dx, dz, S2, free_surface=1, g_p=dp)
     lhs, rhs = np.sum(a * dx) + np.sum(b * dz) + np.sum(pp * dp), np.sum(q * gq)
     assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
+
+
+def test_elastic_second_order_stencils_adjoint_is_exact(oracle64):
+    """fd_order = 2 (DENISE FD_ORDER, left commented at networks.py:10447): weights (1, 0) in the same four-point
+    form.  The transposed scheme passes the dot-product identity and leaves a second-order Taylor remainder; the
+    seismograms differ from the fourth-order ones (more numerical dispersion), both stay bounded."""
+    o = oracle64
+    c = elastic_case(seed=19, nsrc=2, free_surface=True)
+    geo = (c["sc"], c["sw"], c["rc"], c["rw"])
+    kw = dict(free_surface=1, fd_order=2)
+    rng = np.random.default_rng(8)
+    vx, vz, S = o.elastic_forward(c["mat"], c["pz"], c["px"], c["f"], *geo, save=True, **kw)
+    vx4, vz4 = o.elastic_forward(c["mat"], c["pz"], c["px"], c["f"], *geo, free_surface=1)
+    assert np.isfinite(vx).all() and np.abs(vx).max() > 0
+    assert 1e-3 < rel_l2(vx, vx4) < 1.0
+    ox = vx + rng.standard_normal(vx.shape) * 0.3 * np.abs(vx).max()
+    oz = vz + rng.standard_normal(vz.shape) * 0.3 * np.abs(vz).max()
+    gm, gf = o.elastic_backward(c["mat"], c["pz"], c["px"], *geo, vx - ox, vz - oz, S, **kw)
+    dm = rng.standard_normal(c["mat"].shape) * c["mat"] * 0.02
+    df = rng.standard_normal(c["f"].shape) * np.abs(c["f"]).max() * 0.05
+
+    def J(h):
+        a, b = o.elastic_forward(c["mat"] + h * dm, c["pz"], c["px"], c["f"] + h * df, *geo, **kw)
+        return 0.5 * np.sum((a - ox) ** 2) + 0.5 * np.sum((b - oz) ** 2)
+    _, p2 = _taylor(J, np.sum(gm * dm) + np.sum(gf * df), [1e-2, 1e-3, 1e-4])
+    assert abs(p2 - 2.0) < 0.02
+    q = rng.standard_normal(c["f"].shape)
+    a, b, S2 = o.elastic_forward(c["mat"], c["pz"], c["px"], q, *geo, save=True, **kw)
+    dx, dz = rng.standard_normal(a.shape), rng.standard_normal(b.shape)
+    _, gq = o.elastic_backward(c["mat"], c["pz"], c["px"], *geo, dx, dz, S2, **kw)
+    lhs, rhs = np.sum(a * dx) + np.sum(b * dz), np.sum(q * gq)
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
+    # back to the default weights for whoever runs next in this process
+    o.elastic_forward(c["mat"], c["pz"], c["px"], c["f"][:2], *geo, free_surface=1)
+
+
+def test_elastic_stencil_orders_converge_as_advertised(oracle64):
+    """Explosive source in a homogeneous solid, pressure receiver on a grid node, the same physical set-up on
+    h = 20, 10 and 5 m with one small time step (time error out of the picture): against the fine fourth-order
+    run the second-order stencil loses a factor ~4 of error per halving of h, the fourth-order one ~16."""
+    o = oracle64
+    vp0, rho0, f0, dt = 3000.0, 2000.0, 12.0, 2.5e-4
+    nt = 960
+
+    def run(n, order):
+        h = 1200.0 / n
+        mat = H.elastic_materials(np.full((n, n), vp0), np.full((n, n), vp0 / np.sqrt(3)), np.full((n, n), rho0), dt, h)
+        nop = H.cpml_profiles(n, 0, h, dt, vp0, 10.0)
+        t = np.arange(nt) * dt
+        a = (np.pi * f0 * (t - 0.1)) ** 2
+        f = ((1 - 2 * a) * np.exp(-a) * dt / h ** 2 * 1e6)[:, None, None]       # moment rate density
+        sc, sw = H.cell_taps([[n // 2]], [[n // 3]], n)
+        rc, rw = H.cell_taps([[n // 2]], [[n // 3 + n // 4]], n)
+        return o.elastic_forward(mat, nop, nop, f, sc, sw, rc, rw, fd_order=order, pressure=True)[2][:, 0, 0]
+    ref = run(240, 4)
+    err = {(order, n): np.linalg.norm(run(n, order) - ref) / np.linalg.norm(ref) for order in (2, 4) for n in (60, 120)}
+    r2, r4 = err[(2, 60)] / err[(2, 120)], err[(4, 60)] / err[(4, 120)]
+    assert 3.0 < r2 < 5.5 and r4 > 10.0 and err[(4, 120)] < 0.1 * err[(2, 120)], err

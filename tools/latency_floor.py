@@ -24,12 +24,12 @@ def main():
     doc = {"csrc_sha16": bench.csrc_sha16(),
            "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True,
                                     text=True).stdout.strip() or os.environ.get("GRAFT_COMMIT", ""),
-           "how": "bench.py --steps 3 --warmup 1 --no-verify with -DMIFWI_ABLATIONS, MIFWI_EL_CL_DBG=3 / MIFWI_AC_CL_DBG=3 "
+           "how": "bench.py --steps 3 --warmup 3 --timing-only with -DMIFWI_ABLATIONS, MIFWI_EL_CL_DBG=3 / MIFWI_AC_CL_DBG=3 "
                   "(no halo hand-off, no snapshot stores)"}
     for wl in ("elastic_marmousi", "acoustic_marmousi"):
         env = dict(os.environ, MIFWI_LIB=lib, MIFWI_EL_CL_DBG="3", MIFWI_AC_CL_DBG="3")
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", "3", "--warmup", "1",
-               "--no-cpu-baseline", "--no-also", "--no-verify"]
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", "3", "--warmup", "3",
+               "--no-cpu-baseline", "--no-also", "--timing-only"]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         if res.returncode != 0:
             raise SystemExit("ablation run of %s failed:\n%s" % (wl, res.stderr[-2000:]))

@@ -31,9 +31,9 @@ LABELS = {
         "adjoint+imaging": [r"^ac_cluster<2,", r"^ac_step<\d+, \d+, false, true>"],
     },
     "elastic": {
-        "forward+save": [r"^el_cluster_fwd<true", r"^el_step_v<\d+, \d+, true>", r"^el_step_s<\d+, \d+, true>",
-                         r"^el_fwd_fused<true"],
-        "adjoint+imaging": [r"^el_cluster_adj<", r"^el_adj_s\b", r"^el_adj_v\b", r"^el_adj_fused\b"],
+        "forward+save": [r"^el_cluster_fwd<true", r"^el_step_v<\d+, \d+, [12]>", r"^el_step_s<\d+, \d+, [12]>",
+                         r"^el_fwd_fused<[12]>"],
+        "adjoint+imaging": [r"^el_cluster_adj<", r"^el_adj_s<", r"^el_adj_v$", r"^el_adj_fused<", r"^el_inject_adjsrc$"],
     },
 }
 

@@ -9,7 +9,6 @@
 R=${1:-r02}
 O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-set -x
 python tools/latency_floor.py $O/${R}_latency_floor.json > $O/latency_floor.log 2>&1 || { tail -5 $O/latency_floor.log; exit 1; }
 cp $O/${R}_latency_floor.json profiles/${R}_latency_floor.json        # bench.py reads profiles/
 pmc() {  # name, bench args..., -- pmc_traffic args
@@ -25,7 +24,7 @@ pmc() {  # name, bench args..., -- pmc_traffic args
 pmc el100 --workload elastic_marmousi -- --workload elastic_marmousi &&
 pmc ac174 --workload acoustic_marmousi -- --workload acoustic_marmousi &&
 pmc el350 --workload elastic_marmousi --grid 350x1700 --nt 60 -- --workload elastic_marmousi --grid 350x1700 --nt 60 &&
-pmc seam --workload elastic_seam --nt 12 -- --workload elastic_seam --nt 12 || exit 1
+pmc seam --workload elastic_seam --nt 24 -- --workload elastic_seam --nt 24 || exit 1
 cp $O/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json
 python bench.py > $O/${R}_bench_default_output.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
 rm -rf $O/prof_default
@@ -33,7 +32,7 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 find $O/prof_default -name "*kernel_stats.csv" -exec cp {} $O/${R}_bench_default_kernel_stats.csv \;
 find $O/prof_default -name "*kernel_trace.csv" -delete
 rm -rf $O/prof_seam
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_seam -- python bench.py --workload elastic_seam --nt 90 --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-verify > $O/${R}_seam_bench_output.json 2> $O/prof.log || { tail -5 $O/prof.log; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_seam -- python bench.py --workload elastic_seam --nt 90 --steps 3 --warmup 3 --no-cpu-baseline --no-also --no-verify > $O/${R}_seam_bench_output.json 2> $O/prof.log || { tail -5 $O/prof.log; exit 1; }
 find $O/prof_seam -name "*kernel_stats.csv" -exec cp {} $O/${R}_seam_kernel_stats.csv \;
 find $O/prof_seam -name "*kernel_trace.csv" -delete
 echo PROFILE_ROUND_DONE
