@@ -9,6 +9,9 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libmifwi.so")
+# the same kernels with the timing / fault-injection ablations compiled in (-DMIFWI_ABLATIONS): loaded only through
+# MIFWI_LIB, by tools/latency_floor.py and tests/test_fallback_gpu.py; always built together with LIB
+LIB_ABLATIONS = os.path.join(_HERE, "libmifwi_ablations.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
@@ -24,9 +27,9 @@ def sources():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(LIB_ABLATIONS):
         return True
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_ABLATIONS))
     deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     deps.append(os.path.join(_HERE, "..", "include", "mifwi.h"))
     return any(os.path.getmtime(d) > t for d in deps)
@@ -40,6 +43,8 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if out is None and "-DMIFWI_ABLATIONS" not in extra_flags:
+        build(force=True, verbose=verbose, extra_flags=list(extra_flags) + ["-DMIFWI_ABLATIONS"], out=LIB_ABLATIONS)
     return out or LIB
 
 

@@ -92,8 +92,8 @@ def ricker_denise(fc, nt, dt, td=0.0):
 
 def spike_denise(nt, dt, fc1, fc2, order=5, td=0.0):
     """QUELLART = 6: a unit spike at t = td, band-limited with the Butterworth response between
-    FC_SPIKE_1 (high-pass corner, <= 0: none) and FC_SPIKE_2 (low-pass corner), order ORDER_SPIKE.
-    DENISE's own filter is causal; the magnitude response is the same (conventions: DESIGN.md 2)."""
+    FC_SPIKE_1 (high-pass corner, <= 0: none) and FC_SPIKE_2 (low-pass corner), order ORDER_SPIKE, causal as
+    DENISE's time-domain filter (:func:`butterworth`)."""
     w = np.zeros(nt, dtype=np.float64)
     w[min(nt - 1, max(0, int(round(td / dt))))] = 1.0 / dt
     return butterworth(torch.tensor(w), dt, max(0.0, float(fc1)), float(fc2), int(order)).numpy()
@@ -117,20 +117,45 @@ def gradient_taper(ny, dh, gradt1=21, gradt2=25, gradt3=490, gradt4=500, exponen
     return w.astype(np.float32)
 
 
-def butterworth(x, dt, fc_low=0.0, fc_high=0.0, order=6):
-    """Zero-phase Butterworth magnitude response applied along time (dim 0) in the frequency
-    domain; differentiable (torch.fft).  fc_high > 0: low-pass corner, fc_low > 0: high-pass corner
-    (both > 0: band-pass), as the FWI-stage filter of ``add_fwi_stage``."""
-    if (not fc_low or fc_low <= 0) and (not fc_high or fc_high <= 0):
+def butterworth(x, dt, fc_low=0.0, fc_high=0.0, order=6, zero_phase=False):
+    """Butterworth filter along time (dim 0), applied in the frequency domain; differentiable (torch.fft), so the
+    adjoint sources are filtered with the transposed (time-reversed) filter by autograd.
+    fc_high > 0: low-pass corner, fc_low > 0: high-pass corner (both > 0: band-pass), as the FWI-stage filter of
+    ``add_fwi_stage`` and the band-limited spike of QUELLART = 6.
+
+    Default: the CAUSAL recursive filter DENISE applies in the time domain (forward only): the digital design of
+    ``scipy.signal.butter`` (bilinear transform, second-order sections), evaluated as its exact complex response
+    on the FFT bins of the trace padded to four times its length - equal to ``scipy.signal.sosfilt`` on the same
+    samples to the decay of the impulse response.  ``zero_phase=True`` applies the analog magnitude response
+    only.  DENISE's own coefficients cannot be checked here (not in the reference tree)."""
+    lo = float(fc_low) if fc_low and fc_low > 0 else 0.0
+    hi = float(fc_high) if fc_high and fc_high > 0 else 0.0
+    if lo <= 0 and hi <= 0:
         return x
     nt = x.shape[0]
-    nfft = 2 * nt
-    f = torch.fft.rfftfreq(nfft, d=dt).to(x.device)
-    h = torch.ones_like(f)
-    if fc_high and fc_high > 0:
-        h = h / torch.sqrt(1.0 + (f / fc_high) ** (2 * order))
-    if fc_low and fc_low > 0:
-        h = h * torch.sqrt(1.0 / (1.0 + (fc_low / torch.clamp(f, min=1e-12)) ** (2 * order)))
+    if zero_phase:
+        nfft = 2 * nt
+        f = torch.fft.rfftfreq(nfft, d=dt).to(x.device)
+        h = torch.ones_like(f)
+        if hi > 0:
+            h = h / torch.sqrt(1.0 + (f / hi) ** (2 * order))
+        if lo > 0:
+            h = h * torch.sqrt(1.0 / (1.0 + (lo / torch.clamp(f, min=1e-12)) ** (2 * order)))
+    else:
+        from scipy import signal
+        fnyq = 0.5 / dt
+        if hi >= fnyq:
+            hi = 0.0                                   # nothing to cut below Nyquist
+        if lo <= 0 and hi <= 0:
+            return x
+        nfft = 4 * nt
+        w = np.fft.rfftfreq(nfft, d=dt) * (2.0 * np.pi * dt)          # rad / sample
+        hc = np.ones(w.size, dtype=np.complex128)
+        if hi > 0:
+            hc = hc * signal.sosfreqz(signal.butter(order, hi / fnyq, "lowpass", output="sos"), worN=w)[1]
+        if lo > 0:
+            hc = hc * signal.sosfreqz(signal.butter(order, lo / fnyq, "highpass", output="sos"), worN=w)[1]
+        h = torch.tensor(hc, dtype=torch.complex64 if x.dtype == torch.float32 else torch.complex128, device=x.device)
     spec = torch.fft.rfft(x, n=nfft, dim=0) * h.view(-1, *([1] * (x.dim() - 1)))
     return torch.fft.irfft(spec, n=nfft, dim=0)[:nt]
 

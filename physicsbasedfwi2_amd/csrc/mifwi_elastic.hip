@@ -195,9 +195,9 @@ __device__ __forceinline__ void xcd_tile(const ElParams &p, int &bx, int &by, in
     bx = (int)blockIdx.x; by = (int)blockIdx.y; bz = (int)blockIdx.z;
     if (!p.xcd) return;
     const unsigned gx = gridDim.x, n2 = gx * gridDim.y;
-    const unsigned z8 = gridDim.z & ~7u;
+    const unsigned z8 = gridDim.z & ~7u;          // p.xcd == 2: whole slices per XCD
     unsigned T;
-    if (blockIdx.z < z8) {
+    if (p.xcd == 2 && blockIdx.z < z8) {
         const unsigned L = blockIdx.x + gx * blockIdx.y + n2 * blockIdx.z;
         const unsigned c = L & 7u, idx = L >> 3, zl = idx / n2;
         T = idx - zl * n2;
@@ -1316,7 +1316,7 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     }
     { const int v = env_int("MIFWI_EL_LX", 0); if (v == 16 || v == 32 || v == 64) pl->lx = v; }
     pl->rz = 1;
-    pl->xcd = env_int("MIFWI_EL_XCD", 1) != 0;
+    pl->xcd = env_int("MIFWI_EL_XCD", 1);
     int gs = d->shots_per_group;
     if (gs <= 0) gs = env_int("MIFWI_EL_GS", 4);
     if (gs <= 0) gs = 1;

@@ -116,11 +116,12 @@ __global__ __launch_bounds__(kTr *kSl) void misfit_global_correlation(const floa
     const double ns = sqrt(ss), no = sqrt(oo);
     const double c = ok ? so / (ns * no) : 0.0;
     if (adj && live) {
-        const float ka = ok ? (float)(-1.0 / (ns * no)) : 0.f;        // coefficient of o
-        const float kb = ok ? (float)(c / ss) : 0.f;                  // coefficient of s
+        // in double: on a weak trace the two coefficients overflow a float long before their combination does
+        const double ka = ok ? -1.0 / (ns * no) : 0.0;               // coefficient of o
+        const double kb = ok ? c / ss : 0.0;                         // coefficient of s
         for (int t = sl; t < nt; t += kSl) {
             const long long o = (long long)t * ntrace + tr;
-            adj[o] = fmaf(ka, obs[o], kb * pred[o]);
+            adj[o] = (float)(ka * (double)obs[o] + kb * (double)pred[o]);
         }
     }
     double loss = sl == 0 ? -c : 0.0;                                   // one slice speaks for the trace

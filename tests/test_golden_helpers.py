@@ -165,3 +165,35 @@ def test_shuffle_and_pick_reproduces_the_seeded_permutation(golden_dir):
     gen = torch.Generator().manual_seed(77)
     torch.manual_seed(77)
     assert torch.equal(C.shuffle_and_pick(18, 2, generator=gen)[0], torch.randperm(18))
+
+
+def test_stage_filter_is_the_causal_butterworth_and_differentiates_to_its_transpose():
+    """add_fwi_stage(fc_low, fc_high, order) (networks.py:7761, 9863, 10503): the shim's filter equals
+    scipy.signal's causal Butterworth (sosfilt of butter(order, fc/fnyq)) sample for sample, its output does not
+    precede its input, and autograd hands back the transposed filter (<F x, y> = <x, F^T y>)."""
+    from scipy import signal
+    import physicsbasedfwi2_amd.compat.pyapi_denise as api
+    rng = np.random.default_rng(4)
+    nt, dt = 900, 0.002
+    x = rng.standard_normal((nt, 2, 3))
+    for lo, hi, order in ((0.0, 10.0, 6), (2.0, 12.0, 6), (3.0, 10.0, 4)):
+        ref = x.copy()
+        if hi > 0:
+            ref = signal.sosfilt(signal.butter(order, hi / (0.5 / dt), "lowpass", output="sos"), ref, axis=0)
+        if lo > 0:
+            ref = signal.sosfilt(signal.butter(order, lo / (0.5 / dt), "highpass", output="sos"), ref, axis=0)
+        y = api.butterworth(torch.tensor(x), dt, lo, hi, order).numpy()
+        assert np.abs(y - ref).max() <= 1e-6 * np.abs(ref).max()      # wrap-around of the decayed impulse response
+    spike = np.zeros((nt, 1))
+    spike[300] = 1.0
+    y = api.butterworth(torch.tensor(spike), dt, 0.0, 10.0, 6).numpy()
+    assert np.abs(y[:300]).max() <= 1e-6 * np.abs(y).max() and np.argmax(np.abs(y)) > 300          # causal
+    z = api.butterworth(torch.tensor(spike), dt, 0.0, 10.0, 6, zero_phase=True).numpy()
+    assert np.abs(z[:300]).max() > 1e-3 * np.abs(z).max()                                             # the other one is not
+    xt = torch.tensor(x, requires_grad=True)
+    yt = torch.tensor(rng.standard_normal(x.shape))
+    (api.butterworth(xt, dt, 2.0, 12.0, 6) * yt).sum().backward()
+    x2 = torch.tensor(rng.standard_normal(x.shape))
+    lhs = float((api.butterworth(x2, dt, 2.0, 12.0, 6) * yt).sum())
+    rhs = float((x2 * xt.grad).sum())
+    assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs))

@@ -18,9 +18,8 @@ from physicsbasedfwi2_amd import build  # noqa: E402
 
 
 def main():
-    lib = build.LIB.replace("libmifwi.so", "libmifwi_ablations.so")
-    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(build.LIB):
-        build.build(out=lib, extra_flags=["-DMIFWI_ABLATIONS"])
+    build.build()                                  # both libraries, if stale
+    lib = build.LIB_ABLATIONS
     doc = {"csrc_sha16": bench.csrc_sha16(),
            "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True,
                                     text=True).stdout.strip() or os.environ.get("GRAFT_COMMIT", ""),
