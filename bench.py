@@ -74,7 +74,8 @@ def _profile_record(fname, workload, kernel):
     if doc.get("csrc_sha16") != csrc_sha16():
         return None, "%s describes other kernels (csrc %s, now %s)" % (fname, doc.get("csrc_sha16"), csrc_sha16())
     rec = doc.get(workload, {}).get(kernel)
-    return (rec, doc.get("commit", "")) if rec else (None, "workload not in " + fname)
+    # the GPU box has no .git: a summary measured and read in the same call names its kernel sources instead
+    return (rec, doc.get("commit") or "csrc " + doc["csrc_sha16"]) if rec else (None, "workload not in " + fname)
 
 
 def measured_traffic(workload, kernel):

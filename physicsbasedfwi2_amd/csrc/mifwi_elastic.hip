@@ -26,6 +26,8 @@
 // Arithmetic = the explicit fmaf chain of oracle/elastic.c (build with -ffp-contract=off).
 #include "mifwi_common.h"
 
+#include <vector>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -1221,6 +1223,15 @@ int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStr
     MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
     c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
     c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
+#ifdef MIFWI_ABLATIONS
+    // MIFWI_EL_CL_TRACE=<file>: phase time stamps (EC_STAMP) of one workgroup, steps 64..127, appended as text
+    const char *trace_path = getenv("MIFWI_EL_CL_TRACE");
+    const size_t trace_n = 64 * 8 * 16;
+    if (trace_path && *trace_path) {
+        MIFWI_HIP_TRY(hipMalloc(&c.trace, trace_n * sizeof(long long)));
+        MIFWI_HIP_TRY(hipMemsetAsync(c.trace, 0, trace_n * sizeof(long long), st));
+    }
+#endif
     for (int s0 = 0; s0 < pl->d.nshot; s0 += pl->cl_shots) {
         c.shot0 = s0;
         c.shot1 = std::min(pl->d.nshot, s0 + pl->cl_shots);
@@ -1234,6 +1245,21 @@ int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStr
     int err = 0;
     MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
     MIFWI_HIP_TRY(hipStreamSynchronize(st));
+#ifdef MIFWI_ABLATIONS
+    if (c.trace) {
+        std::vector<long long> h(trace_n);
+        MIFWI_HIP_TRY(hipMemcpy(h.data(), c.trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost));
+        MIFWI_HIP_TRY(hipFree(c.trace));
+        if (FILE *fp = fopen(trace_path, "a")) {
+            fprintf(fp, "# el_cluster_fwd save=%d steps=%d\n", SAVE ? 1 : 0, c.n_last - c.n_first);
+            for (size_t i = 0; i < trace_n; i += 16) {
+                for (int k = 0; k < 16; ++k) fprintf(fp, "%lld ", h[i + k]);
+                fprintf(fp, "\n");
+            }
+            fclose(fp);
+        }
+    }
+#endif
     return (err != 0 || mifwi::fake_timeout() == 2) ? mifwi::kClusterTimedOut : MIFWI_OK;
 }
 

@@ -41,7 +41,22 @@ struct EcParams {
     int *err;
     int dbg, nap;
     FdK K;                               // stencil weights (fd_order)
+#ifdef MIFWI_ABLATIONS
+    long long *trace;                    // phase time stamps of one workgroup (MIFWI_EL_CL_TRACE), see EC_STAMP
+#endif
 };
+
+// Ablation builds: wave 0..7 of slab NW/2 of the first shot writes s_memtime at phase boundary k of steps 64..127
+// to trace[((it - 64) * 8 + wave) * 16 + k]; tools/cluster_trace.py turns them into a per-phase table.
+#ifdef MIFWI_ABLATIONS
+#define EC_STAMP(k)                                                                                        \
+    do {                                                                                                   \
+        if (p.trace && tr_on && it >= 64 && it < 128 && (t & 63) == 0)                                     \
+            p.trace[((it - 64) * 8 + (t >> 6)) * 16 + (k)] = (long long)__builtin_readcyclecounter();      \
+    } while (0)
+#else
+#define EC_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ void ec_slab_rows(int nz, int NW, int w, int &r0, int &rows)
 {
@@ -509,29 +524,40 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
             mifwi::stnt4(Sn, S1); mifwi::stnt4(Sn + (long long)ncell, S2); mifwi::stnt4(Sn + 2 * (long long)ncell, S3);
         }
     };
+#ifdef MIFWI_ABLATIONS
+    const bool tr_on = w == p.NW / 2 && s == p.shot0;
+#endif
     for (int it = 0; it < nsteps; ++it) {
         const int n = p.n_first + it;
+        EC_STAMP(0);
         // ---- V: interior rows first, then receive the stress halo, then the boundary rows --------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             if (G[q].inner) do_v(G[q], n, it, false);
             __builtin_amdgcn_sched_barrier(0);             // one group at a time: bounds the register peak
         }
+        EC_STAMP(1);
         if (do_x && it > 0 && !(kDbg(p) & 32)) receive(1, (unsigned)(2 * it), (it - 1) & 1);
+        EC_STAMP(2);
         __syncthreads();                                   // A: stress halo rows are in LDS
+        EC_STAMP(3);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             if (G[q].own && !G[q].inner) do_v(G[q], n, it, true);
             __builtin_amdgcn_sched_barrier(0);
         }
+        EC_STAMP(4);
         __syncthreads();                                   // B: all velocities of the slab are in LDS
+        EC_STAMP(5);
         // ---- S: interior rows, receive the velocity halo, boundary rows -----------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             if (G[q].inner) do_s(G[q], q, n, it, false);
             __builtin_amdgcn_sched_barrier(0);
         }
+        EC_STAMP(6);
         if (do_x && !(kDbg(p) & 32)) receive(0, (unsigned)(2 * it + 1), it & 1);
+        EC_STAMP(7);
         // ---- receivers sample the new velocities (stores after the poll) ----------------------------
         if (p.rec_vx != nullptr && !(kDbg(p) & 8)) {
             if (!slow) {
@@ -557,12 +583,15 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
                 }
             }
         }
+        EC_STAMP(8);
         __syncthreads();                                   // C: velocity halo rows are in LDS
+        EC_STAMP(9);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             if (G[q].own && !G[q].inner) do_s(G[q], q, n, it, true);
             __builtin_amdgcn_sched_barrier(0);
         }
+        EC_STAMP(10);
         if ((it & 31) == 31 || it == nsteps - 1) {
             if (__syncthreads_or(X.failed ? 1 : 0)) {        // D (+ collective time-out check)
                 if (t == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -571,6 +600,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         } else {
             __syncthreads();                               // D: all stresses of the slab are in LDS
         }
+        EC_STAMP(11);
     }
 
     // ---- the own rows of the five fields and the memory variables go back to the global state -----

@@ -1,0 +1,38 @@
+"""Per-phase cycle table from the time stamps an ablation build of the elastic single-launch forward kernel
+writes (MIFWI_LIB=.../libmifwi_ablations.so MIFWI_EL_CL_TRACE=<file>): one workgroup (slab NW/2 of the first
+shot), steps 64..127, 8 waves x 12 stamps.  usage: python tools/cluster_trace.py <file>"""
+import sys
+import numpy as np
+
+NAMES = ["V interior", "poll S halo", "wait barrier A", "V boundary", "wait barrier B", "S interior", "poll V halo",
+         "receivers", "wait barrier C", "S boundary", "wait barrier D"]
+
+
+def main(path):
+    blocks, cur = [], []
+    for line in open(path):
+        if line.startswith("#"):
+            if cur:
+                blocks.append((head, cur))
+            head, cur = line.strip(), []
+        else:
+            cur.append([int(x) for x in line.split()])
+    if cur:
+        blocks.append((head, cur))
+    for head, rows in blocks:
+        a = np.array(rows, dtype=np.int64).reshape(64, 8, 16)[:, :, :12]
+        if not a.any():
+            continue
+        a = a[4:60]                                        # steps with every stamp written
+        d = np.diff(a, axis=2).astype(np.float64)          # [step][wave][phase]
+        step = (a[1:, :, 0] - a[:-1, :, 0]).mean()
+        print(head, "| s_memtime ticks per step %.0f" % step)
+        print("%-16s" % "phase" + "".join("  wave%d" % w for w in range(8)) + "    max")
+        for k, nm in enumerate(NAMES):
+            m = d[:, :, k].mean(axis=0)
+            print("%-16s" % nm + "".join("%7.0f" % x for x in m) + "%7.0f" % m.max())
+        print("%-16s" % "sum" + "".join("%7.0f" % x for x in d.mean(axis=0).sum(axis=1)))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
