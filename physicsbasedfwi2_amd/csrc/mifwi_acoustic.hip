@@ -344,6 +344,12 @@ __global__ void ac_finalize(const float *acc, int ngroups, int n0, int n1, int g
 constexpr int kClThreads = 1024;
 constexpr int kClMaxNG = 4;                  // groups of 4 cells a thread may own
 constexpr unsigned kClMaxSpin = 400000;
+// publishes stay in the XCD's L2 (mifwi::same_xcd in mifwi_common.h); -DMIFWI_HANDOFF_AGENT: written through the fabric
+#ifdef MIFWI_HANDOFF_AGENT
+#define CL_PUBLISH_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#else
+#define CL_PUBLISH_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
 
 struct ClParams {
     int n0, n1, ng, gp, pitch;
@@ -378,6 +384,7 @@ struct ClParams {
     const int *slab_list;        // adjoint: [nshot][NW][nrec*ntap] tap ids (shot-local)
     unsigned long long *xbuf;    // granules [nshot][NW][2 epoch slots][2 sides][2 rows][gp]
     int *err;
+    int *xcc_tab;                        // [nshot][NW] XCC_ID + 1 of each slab's workgroup (mifwi::same_xcd)
 };
 
 // Row slabs of a shot.  rt == 0: n0 rows split evenly over NW slabs.  rt > 0 (NW >= 3): the first and
@@ -519,6 +526,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     // its neighbours must time out, publish the error word and let the host fall back
     if ((kDbg(p) & 64) && w == 1 && s == p.shot0) return;
     const int t = (int)threadIdx.x;
+    if (!mifwi::same_xcd(p.xcc_tab, s, p.NW, w, t, p.err, kClMaxSpin, kDbg(p) & 128)) return;
     constexpr bool adj = (MODE == 2);
     int r0, R;
     slab_rows(p.n0, p.NW, p.rt, w, r0, R);
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                     if (rcv_lo[kk] >= 0)
                         __hip_atomic_store(xmine + t + kk * kClThreads,
                                            ((unsigned long long)epoch << 32) | __float_as_uint(prv[pub_off(kk)]),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                           __ATOMIC_RELAXED, CL_PUBLISH_SCOPE);
             }
         }
         __syncthreads();
@@ -874,7 +882,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 if (rcv_lo[kk] >= 0)
                     __hip_atomic_store(xmine + t + kk * kClThreads,
                                        ((unsigned long long)epoch << 32) | __float_as_uint(prv[pub_off(kk)]),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                       __ATOMIC_RELAXED, CL_PUBLISH_SCOPE);
         }
         // ---- receive the neighbours' boundary rows of the NEW field into the halo rows -------------
         if (do_x) {
@@ -1056,7 +1064,9 @@ void cluster_setup(mifwi_acoustic_plan *pl)
         }
     }
     if (!pl->cluster) return;
-    pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * pl->NW * 8 * pl->gp + 64, 64);   // granules + err word
+    // granules, the XCC_ID table of mifwi::same_xcd ([nshot][NW] ints), the block of the error word
+    pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * pl->NW * 8 * pl->gp, 64) +
+                     mifwi::round_up64((long long)pl->d.nshot * pl->NW, 64) + 64;
     pl->list_elems = mifwi::round_up64((long long)pl->d.nshot * pl->NW * (1 + (long long)pl->d.nrec), 64);
     for (const void *fn : {(const void *)ac_cluster<0, false>, (const void *)ac_cluster<1, false>,
                            (const void *)ac_cluster<2, false>, (const void *)ac_cluster<3, false>,
@@ -1080,7 +1090,8 @@ ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const flo
     c.ua = ua; c.ub = ub;
     c.nsrc = pl->d.nsrc; c.ntap = 1; c.nrec = pl->d.nrec;
     c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
-    c.err = reinterpret_cast<int *>(xbuf + 2LL * pl->d.nshot * pl->NW * 8 * pl->gp);
+    c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
+    c.xcc_tab = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64 - mifwi::round_up64((long long)pl->d.nshot * pl->NW, 64));
     c.dbg = env_int("MIFWI_AC_CL_DBG", 0);
     // fat slabs nap long between poll passes, thin ones short (mifwi::poll_nap)
     c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(pl->d.n0, pl->NW) >= 16 ? 48 : 1);

@@ -78,10 +78,49 @@ constexpr int kClusterLdsLimit = 150 * 1024;      // = the eligibility bound of 
 // step is the hand-off chain itself, nap short.
 __device__ __forceinline__ void poll_nap(int units)
 {
-    if (units >= 48) __builtin_amdgcn_s_sleep(48);
+    if (units >= 127) __builtin_amdgcn_s_sleep(127);
+    else if (units >= 96) __builtin_amdgcn_s_sleep(96);
+    else if (units >= 64) __builtin_amdgcn_s_sleep(64);
+    else if (units >= 48) __builtin_amdgcn_s_sleep(48);
     else if (units >= 16) __builtin_amdgcn_s_sleep(16);
     else if (units >= 4) __builtin_amdgcn_s_sleep(4);
     else __builtin_amdgcn_s_sleep(1);
+}
+
+// Halo hand-offs between the row slabs of a shot stay inside ONE XCD's L2: the granules are published with plain
+// (workgroup-scope) stores, which stay in that L2, and polled with agent-scope loads, which bypass the reader's L1 and
+// are served by the same L2 - an L2 round trip instead of two trips over the fabric (agent-scope stores leave the
+// L2 and drop the line: measured 2000-2500 clocks per poll against 900-1200, elastic 100x300 forward 7.2 -> 6.4 us
+// per step).  That is only correct while every slab of a shot runs on the same XCD.  The block -> (shot, slab) map puts
+// them on blocks b, b + 8, b + 16, ..., which the dispatcher deals to one XCD - observed, not promised by HIP - so it
+// is checked, not assumed: before its time loop every workgroup writes its XCC_ID to xcc_tab[shot][slab] (agent
+// scope) and reads its two neighbours' entries; a mismatch or a neighbour that never shows up makes the launch bail
+// out through the same error word as a hand-off time-out, and the host re-runs the range with one launch per step.
+// (A stale granule can never be taken for a fresh one - its tag is an older epoch - so a wrong placement could only
+// ever end in that time-out, not in wrong numbers; the check just gets there in microseconds.)
+// Returns true when this workgroup may run; collective over the workgroup (__syncthreads_or inside).
+__device__ __forceinline__ bool same_xcd(int *xcc_tab, int s, int NW, int w, int t, int *err, unsigned max_spin, int fake)
+{
+    if (NW == 1) return true;
+    bool bad = false;
+    if (t == 0) {
+        // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, 4 bits)
+        const int me = fake ? w + 1 : (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) + 1;
+        __hip_atomic_store(xcc_tab + s * NW + w, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int o = w - 1; o <= w + 1; o += 2) {
+            if (o < 0 || o >= NW) continue;
+            int v = 0;
+            for (unsigned spins = 0; spins < max_spin; ++spins) {
+                v = __hip_atomic_load(xcc_tab + s * NW + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v != 0) break;
+                if ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (v != me) bad = true;                     // 0: the neighbour never showed up
+        }
+        if (bad) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return __syncthreads_or(bad ? 1 : 0) == 0;
 }
 
 // write-once / read-once streams (snapshots): non-temporal accesses keep them out of the way of the

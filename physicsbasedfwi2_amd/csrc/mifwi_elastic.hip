@@ -1082,7 +1082,7 @@ struct mifwi_elastic_plan {
     int cluster, NW, PL, cl_shots, cl_lds, cl_ng;
     // adjoint cluster kernel (its own slab count: different LDS footprint)
     int cl_adj, adj_NW, adj_shots, adj_lds, adj_ng, adj_zrows;
-    long long xbuf_elems, list_elems;
+    long long xbuf_elems, list_elems, xcc_elems;
 };
 
 namespace {
@@ -1137,7 +1137,7 @@ void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, int nshot, hipSt
 
 void el_cluster_setup(mifwi_elastic_plan *pl)
 {
-    pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0; pl->xbuf_elems = 0;
+    pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0; pl->xbuf_elems = 0; pl->xcc_elems = 0;
     pl->cl_adj = 0; pl->adj_NW = 0; pl->adj_shots = 0; pl->adj_lds = 0; pl->adj_ng = 0; pl->adj_zrows = 0; pl->list_elems = 0;
     if (pl->d.ntap != 1 || pl->d.source_type != 0 || pl->d.record_pressure) return;   // per-step kernels only
     const bool want_fwd = env_int("MIFWI_EL_CLUSTER", 1) != 0;
@@ -1152,7 +1152,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
         if (forced > 0 && nw != forced) continue;
         const int rows = mifwi::ceil_div(pl->d.nz, nw);
         if (pl->d.nz / nw < 4) break;
-        const long long lds = (5LL * (rows + 4) * pl->PL + 6LL * pl->gp + 6LL * rows + 8) * sizeof(float);
+        const long long lds = (5LL * (rows + 4) * pl->PL + 6LL * pl->gp + 8LL * rows + 8) * sizeof(float);
         if (lds > 150 * 1024) continue;
         if ((long long)rows * pl->ng > 2 * kEcThreads || kEcRowFields * pl->gp > kEcGr * kEcThreads) continue;
         const int per_launch = 8 * (ncu / (8 * nw));
@@ -1190,7 +1190,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
                 const int nbot = std::max(0, r0 + R - std::max(r0, pl->d.nz - pl->W));
                 zmax = std::max(zmax, ntop + nbot);
             }
-            const long long lds = (4LL * (rows + 4) * pl->PL + 6LL * pl->gp + 6LL * ((rows + 3) & ~3) +
+            const long long lds = (4LL * (rows + 4) * pl->PL + 6LL * pl->gp + 8LL * rows +
                                    4LL * rows * pl->wx + 4LL * zmax * pl->gp) * sizeof(float);
             if (lds > 150 * 1024) continue;
             if ((long long)rows * pl->ng > 2 * kEcThreads || kEcRowFields * pl->gp > kEcGr * kEcThreads) continue;
@@ -1211,7 +1211,10 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
                 }
     }
     const int nwmax = std::max(pl->cluster ? pl->NW : 0, pl->cl_adj ? pl->adj_NW : 0);
-    if (nwmax > 0) pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * nwmax * 4 * kEcRowFields * pl->gp + 64, 64);
+    // granules, the XCC_ID table of mifwi::same_xcd ([nshot][nwmax] ints) and the block of the error word
+    pl->xcc_elems = nwmax > 0 ? mifwi::round_up64((long long)pl->d.nshot * nwmax, 64) : 0;
+    if (nwmax > 0)
+        pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * nwmax * 4 * kEcRowFields * pl->gp, 64) + pl->xcc_elems + 64;
     if (pl->cl_adj)
         pl->list_elems = mifwi::round_up64((long long)pl->d.nshot * pl->adj_NW * (1 + pl->d.nrec), 64);
 }
@@ -1223,6 +1226,7 @@ int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStr
     MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
     c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
     c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
+    c.xcc_tab = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64 - pl->xcc_elems);
 #ifdef MIFWI_ABLATIONS
     // MIFWI_EL_CL_TRACE=<file>: phase time stamps (EC_STAMP) of one workgroup, steps 64..127, appended as text
     const char *trace_path = getenv("MIFWI_EL_CL_TRACE");
@@ -1689,6 +1693,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
         c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
         c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
+        c.xcc_tab = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64 - pl->xcc_elems);
         const long long adj_state = pl->fields_elems + 2 * psi + nacc;
         float *backup = reinterpret_cast<float *>(lists) + pl->list_elems;
         rc = el_cluster_backup(work, adj_state, backup, flags, st);

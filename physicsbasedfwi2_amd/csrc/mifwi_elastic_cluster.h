@@ -39,6 +39,7 @@ struct EcParams {
     float *rec_vx, *rec_vz;              // [nt][nshot][nrec] or null
     unsigned long long *xbuf;            // [nshot][NW][2 kinds][2 parities][8*gp] granules
     int *err;
+    int *xcc_tab;                        // [nshot][NW] XCC_ID + 1 of each slab's workgroup (mifwi::same_xcd)
     int dbg, nap;
     FdK K;                               // stencil weights (fd_order)
 #ifdef MIFWI_ABLATIONS
@@ -88,75 +89,162 @@ __device__ __forceinline__ int ec_rf_lds_row(int rf, int R)
     return rf == 0 || rf == 1 ? R + 2 : rf == 2 ? R + 3 : rf == 3 ? 0 : 1;
 }
 
-// Uniform value the compiler must treat as unknown at this point: stops it from hoisting every
-// `base + k * pitch` address of the loop body into a register of its own (they cost one add each,
-// but ~50 live registers when hoisted, which is what made this kernel spill).
+// Value the compiler must treat as unknown at this point.  Every per-lane quantity that does not change
+// over the time loop (LDS offsets, group class, strip slots ...) goes through this once per use: left
+// alone, the compiler hoists every address `base + k * pitch` and every lane predicate derived from them
+// out of the loop - ~50 live vector registers and ~60 scalar register pairs of lane masks, which it then
+// spills to vector-register lanes (v_writelane / v_readlane + hazard s_nops on every use: a quarter of
+// the loop's vector instructions in round 1).  Recomputing costs one add or compare each.
 __device__ __forceinline__ int ec_opaque(int x)
 {
     asm volatile("" : "+v"(x));
     return x;
 }
+__device__ __forceinline__ unsigned ec_opaque(unsigned x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// The same for a wave-uniform value (scalar register): every scalar derived from it (row pitches times k, plane
+// bases, table offsets) is then recomputed by two or three scalar instructions where it is used instead of being
+// kept live over the whole time loop - ~120 of those did not fit the 102 scalar registers and were spilled.
+__device__ __forceinline__ int ec_su(int x)
+{
+    x = __builtin_amdgcn_readfirstlane(x);          // folded away when x already sits in a scalar register
+    asm volatile("" : "+s"(x));
+    return x;
+}
+__device__ __forceinline__ unsigned ec_su(unsigned x) { return (unsigned)ec_su((int)x); }
+
+// base + byte offset with the offset in a 32-bit vector register: selects the `global_* v_off, data, s[base]`
+// addressing form (uniform 64-bit base in scalar registers) instead of 64-bit vector address arithmetic
+template <class T>
+__device__ __forceinline__ T *ec_at(T *base, unsigned byte_off)
+{
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ const T *ec_at(const T *base, unsigned byte_off)
+{
+    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+// All LDS reads of a group update are requested in one batch and pinned here: the values become opaque, so the
+// compiler neither re-reads misaligned pairs from LDS in the middle of the arithmetic (it did: five dependent LDS
+// round trips per update instead of one) nor moves the reads apart.
+__device__ __forceinline__ void ec_pin(float4 &a, float4 &b, float4 &c, float4 &d)
+{
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w),
+                      "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w), "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
+}
+__device__ __forceinline__ void ec_pin(float4 &a, float4 &b)
+{
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+}
+__device__ __forceinline__ void ec_pin(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y), "+v"(c.x), "+v"(c.y), "+v"(d.x), "+v"(d.y));
+}
+
+// nothing of the prologue is in flight when the time loop starts: without this the compiler carries the
+// prologue's global loads as "possibly pending" into the loop and waits on vmcnt before the first use of
+// each such register in EVERY iteration - where the wait then drains the snapshot stores and publishes.
+__device__ __forceinline__ void ec_drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // vmcnt(0)
+
+// publishes stay in the XCD's L2 (mifwi::same_xcd in mifwi_common.h); -DMIFWI_HANDOFF_AGENT: written through the fabric
+#ifdef MIFWI_HANDOFF_AGENT
+#define EC_PUBLISH_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#else
+#define EC_PUBLISH_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
 
 // The granule hand-off of one slab, shared by the forward and the adjoint kernel.  `kind` selects one
 // of the two exchanges of a step, `parity` the double buffer, `epoch` the tag a complete granule
-// carries.  receive() hands every arrived value to dest(field_is_A, lds_offset, value).
+// carries.  receive() hands every arrived value to dest(lds_offset, value); lds_offset already holds
+// the plane of the field (B-field plane + one plane for the A field, see plane_a).
 struct EcHandoff {
     unsigned long long *xw;              // this slab's slots [kind 0..1][parity 0..1][kEcRowFields*gp]
-    long long xslot;
+    unsigned xslot8;                     // bytes of one slot
     int gp, ng, NW, w, R, t;
-    int rcv_lo[kEcGr];                   // LDS offset (inside a field) of my k-th granule, <0: none
-    unsigned rcv_meta;                   // per k: bit0 field A, bit1 comes from the slab above
+    int rcv_lo[kEcGr];                   // LDS offset (B-field plane = 0, A-field plane = plane_a) of my k-th granule, <0: none
+    unsigned rcv_off[kEcGr];             // its byte offset from (xw - 4 slots): the slab above sits there, the one below 8 slots on
     int *err;
     bool failed, no_wait;                // no_wait: timing ablation only (wrong results)
     int nap;                             // s_sleep units between poll passes (mifwi::poll_nap)
 
     __device__ __forceinline__ void init(unsigned long long *xbuf, int s, int NW_, int w_, int R_, int PL, int gp_,
-                                         int ng_, int t_, int *err_, bool no_wait_, int nap_)
+                                         int ng_, int t_, int *err_, bool no_wait_, int nap_, int plane_a)
     {
         nap = nap_;
         gp = gp_; ng = ng_; NW = NW_; w = w_; R = R_; t = t_; err = err_; failed = false; no_wait = no_wait_;
-        xslot = (long long)kEcRowFields * gp;
-        xw = xbuf + ((long long)s * NW + w) * 4 * xslot;
-        rcv_meta = 0;
+        xslot8 = 8u * kEcRowFields * gp;
+        xw = xbuf + ((long long)s * NW + w) * 4 * (kEcRowFields * gp);
 #pragma unroll
         for (int k = 0; k < kEcGr; ++k) {
             const int e = t + k * kEcThreads;
             rcv_lo[k] = -1;
+            rcv_off[k] = 4u * xslot8;               // no granule: reads the head of its own slot, value unused
             if (e < kEcRowFields * gp) {
                 const int cq = e % gp, rf = e / gp;
                 const int col = 4 * (cq % ng) + cq / ng;             // granule order is [k][group]
                 const bool from_above = rf >= 3;                      // top halo <- the slab above's last rows
                 if (cq < 4 * ng && !(from_above ? w == 0 : w == NW - 1)) {
-                    rcv_lo[k] = ec_rf_lds_row(rf, R) * PL + 4 + col;
-                    rcv_meta |= (unsigned)(ec_rf_field(rf) | (from_above ? 2 : 0)) << (2 * k);
+                    rcv_lo[k] = ec_rf_lds_row(rf, R) * PL + 4 + col + (ec_rf_field(rf) ? plane_a : 0);
+                    rcv_off[k] = 8u * e + (from_above ? 0u : 8u * xslot8);          // same index on both sides
                 }
             }
         }
     }
 
-    // sweep: every pass re-reads ALL of this thread's granules back to back (one memory round trip per
-    // pass, not one per granule) until every tag carries the epoch; bounded, a time-out sets `failed`
-    template <class Dest>
-    __device__ __forceinline__ void receive(int kind, unsigned epoch, int parity, Dest dest)
-    {
-        const unsigned long long *xu = xw - 4 * xslot + (kind * 2 + parity) * xslot;
-        const unsigned long long *xd = xw + 4 * xslot + (kind * 2 + parity) * xslot;
-        const unsigned long long *src[kEcGr];
+    // Hand-off receive in two halves, so that the flight of the first pass hides behind an update:
+    //   request(): one pass of loads of ALL of this thread's granules, back to back (one memory round trip per
+    //              pass, not one per granule), nothing waits;
+    //   complete(): examine that pass; while a tag is missing, nap and sweep again (bounded: a time-out sets
+    //              `failed`); then hand every value to dest(lds_offset, value).
+    struct Pending {
+        const unsigned long long *base;
         unsigned long long v[kEcGr];
+        // Keeps the granule registers reserved for the whole time loop (call once per iteration).  Otherwise the
+        // compiler reuses them for temporaries of the updates and, not knowing across the loop's back edge that the
+        // last sweep has landed, guards each reuse with an s_waitcnt vmcnt - which then waits for the early pass.
+        __device__ __forceinline__ void keep()
+        {
 #pragma unroll
-        for (int k = 0; k < kEcGr; ++k) {
-            src[k] = (((rcv_meta >> (2 * k)) & 2u) ? xu : xd) + (t + k * kEcThreads);   // same index on both sides
-            v[k] = 0;
+            for (int k = 0; k < kEcGr; ++k) asm volatile("" : "+v"(v[k]));
         }
+        __device__ __forceinline__ void clear()
+        {
+            base = nullptr;
+#pragma unroll
+            for (int k = 0; k < kEcGr; ++k) v[k] = 0;
+        }
+    };
+    __device__ __forceinline__ void sweep(Pending &q) const
+    {
+#pragma unroll
+        for (int k = 0; k < kEcGr; ++k)       // lanes without a k-th granule read their own slot: no branches
+            q.v[k] = __hip_atomic_load(ec_at(q.base, ec_opaque(rcv_off[k])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void request(Pending &q, int kind, int parity) const
+    {
+        // (xw - 4 slots) + slot of (kind, parity): uniform base, per-lane byte offsets
+        const unsigned xs8 = ec_su(xslot8);
+        q.base = ec_at(xw, (unsigned)(kind * 2 + parity) * xs8) - 4 * (xs8 / 8);
+        sweep(q);
+    }
+    template <class Dest>
+    __device__ __forceinline__ void complete(Pending &q, unsigned epoch, bool early, Dest dest)
+    {
+        int lo[kEcGr];
+        unsigned need[kEcGr];                  // all ones where this thread has a k-th granule
+#pragma unroll
+        for (int k = 0; k < kEcGr; ++k) { lo[k] = ec_opaque(rcv_lo[k]); need[k] = ~(unsigned)(lo[k] >> 31); }
         for (unsigned spins = 0;; ++spins) {
-            bool ok = true;
+            unsigned bad = 0;
 #pragma unroll
-            for (int k = 0; k < kEcGr; ++k)
-                if (rcv_lo[k] >= 0) v[k] = __hip_atomic_load(src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int k = 0; k < kEcGr; ++k)
-                if (rcv_lo[k] >= 0) ok = ok && (unsigned)(v[k] >> 32) == epoch;
-            if (ok || no_wait || failed) break;   // once failed: one pass per hand-off, garbage forward until the check
+            for (int k = 0; k < kEcGr; ++k) bad |= ((unsigned)(q.v[k] >> 32) ^ epoch) & need[k];
+            if (bad == 0 || no_wait || failed) break;   // once failed: one pass per hand-off, garbage forward until the check
             if (spins > kEcMaxSpin ||
                 ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 // publish at once: every other workgroup of the launch bails within 256 spins instead of running
@@ -165,11 +253,20 @@ struct EcHandoff {
                 failed = true;
                 break;
             }
-            mifwi::poll_nap(nap);
+            // the early pass was requested before the update it hid behind: look again at once, nap from then on
+            if (spins > 0 || !early) mifwi::poll_nap(nap);
+            sweep(q);
         }
 #pragma unroll
         for (int k = 0; k < kEcGr; ++k)
-            if (rcv_lo[k] >= 0) dest((int)((rcv_meta >> (2 * k)) & 1u), rcv_lo[k], __uint_as_float((unsigned)v[k]));
+            if (lo[k] >= 0) dest(lo[k], __uint_as_float((unsigned)q.v[k]));
+    }
+    template <class Dest>
+    __device__ __forceinline__ void receive(int kind, unsigned epoch, int parity, Dest dest)
+    {
+        Pending q;
+        request(q, kind, parity);
+        complete(q, epoch, false, dest);
     }
 
     // publish the four cells of a boundary-row group (local row lrw, group gq): b = the field a forward
@@ -177,59 +274,108 @@ struct EcHandoff {
     __device__ __forceinline__ void publish(int lrw, int gq, int kind, unsigned epoch, int parity, const float4 &b,
                                             const float4 &a) const
     {
-        unsigned long long *x = xw + (kind * 2 + parity) * xslot;
+        unsigned long long *x = ec_at(xw, (unsigned)(kind * 2 + parity) * ec_su(xslot8));
         const unsigned long long tag = (unsigned long long)epoch << 32;
         const float bv[4] = {b.x, b.y, b.z, b.w}, av[4] = {a.x, a.y, a.z, a.w};
+        const unsigned gp8 = 8u * ec_su((unsigned)gp), ng8 = 8u * ec_su((unsigned)ng), gq8 = 8u * gq;
         auto put = [&](int rf, const float (&v)[4]) {
+            unsigned o = rf * gp8 + gq8;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                __hip_atomic_store(x + (unsigned)(rf * gp + k * ng + gq), tag | __float_as_uint(v[k]),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < 4; ++k) {
+                __hip_atomic_store(ec_at(x, o), tag | __float_as_uint(v[k]), __ATOMIC_RELAXED, EC_PUBLISH_SCOPE);
+                o = ec_opaque(o + ng8);                            // a chain of adds, not 24 hoisted constants
+            }
         };
-        if (w > 0) {
+        const int wq = ec_su(w), Rq = ec_su(R);
+        if (wq > 0) {
             if (lrw == 0) { put(0, av); put(1, bv); }
             if (lrw == 1) put(2, bv);
         }
-        if (w < NW - 1) {
-            if (lrw == R - 2) put(3, av);
-            if (lrw == R - 1) { put(4, av); put(5, bv); }
+        if (wq < ec_su(NW) - 1) {
+            if (lrw == Rq - 2) put(3, av);
+            if (lrw == Rq - 1) { put(4, av); put(5, bv); }
         }
     }
 };
 
 // per-thread state of one owned group of 4 cells (registers for the whole run)
 struct EcGroup {
-    bool own, inner;
-    int g, j, xs_off, zs;                         // group in the row, grid row, strip slots (or -1)
+    int cls;                                      // 0: none, 1: interior rows of the slab, 2: boundary rows (stencils reach the halo)
+    int g, j;                                     // group in the row, grid row
+    int lo;                                       // LDS float offset of the group inside a field plane
+    unsigned gcb;                                 // byte offset of the group inside a [nz][gp] plane (snapshots, materials)
+    int xtab, ztab;                               // LDS float offsets of its C-PML table entries (x strip / z strip), or -1
     float4 mL, mM, mMu, mBx, mBz;                 // materials
     float4 s1, s2, s3, s4, s5, s6, s7, s8;        // C-PML memory variables
 };
 
+// LDS planes of the forward kernel: [vx | vz | szz | sxz | sxx], so that for both hand-offs the field a
+// backward difference reads sits one plane after the one a forward difference reads (EcHandoff::rcv_lo)
+__device__ __forceinline__ int ec_plane(int f) { return f == F_VX ? 0 : f == F_VZ ? 1 : f == F_SZZ ? 2 : f == F_SXZ ? 3 : 4; }
+
+// C-PML tables in LDS, one entry = the six profiles of a cell side by side (immediate offsets, no pitch
+// arithmetic): x table [group][6][4 cells], z table [row][8] (6 used)
+__device__ __forceinline__ void ec_stage_tables(float *lpx, float *lpz, const float *px, const float *pz, int gp, int nz,
+                                                int r0, int R, int t)
+{
+    for (int e = t; e < 6 * gp; e += kEcThreads) {
+        const int k = e / gp, col = e - k * gp;
+        lpx[((col >> 2) * 6 + k) * 4 + (col & 3)] = px[e];
+    }
+    for (int e = t; e < 8 * R; e += kEcThreads) {
+        const int k = e & 7, r = e >> 3;
+        lpz[e] = k < 6 ? pz[k * nz + r0 + r] : 0.f;
+    }
+}
+struct EcTabX { float4 v[6]; };
+struct EcTabZ { float v[8]; };
+__device__ __forceinline__ EcTabX ec_tab_x(const float *lpx, int xtab)
+{
+    EcTabX r;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r.v[k] = ld4(lpx + xtab + 4 * k);
+    return r;
+}
+__device__ __forceinline__ EcTabZ ec_tab_z(const float *lpz, int ztab)
+{
+    const float4 a = ld4(lpz + ztab);
+    const float2 b = ld2(lpz + ztab + 4);
+    EcTabZ r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = 0.f; r.v[7] = 0.f;
+    return r;
+}
+
 struct EcCtx {
     float *Lf[5];
     const float *lpx, *lpz;
-    int PL, R, gp, fsurf;
+    int PL, fsurf;
     FdK K;
 };
 
 // V update (reads stresses from LDS, writes the group's velocities in place)
 template <bool EDGE>   // EDGE: the group may sit on grid rows 0/1 (free-surface mirroring); interior rows never do
-__device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const int lo, const int gq, const int lrw, float4 &S4, float4 &S5, float4 &o0,
-                                            float4 &o1)
+__device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const int lo, const int jq, float4 &S4, float4 &S5,
+                                            float4 &o0, float4 &o1)
 {
-    const int PL = c.PL;
+    const int PL = ec_su(c.PL);
     const FdK K = c.K;
     const float *sxx = c.Lf[F_SXX] + lo, *szz = c.Lf[F_SZZ] + lo, *sxz = c.Lf[F_SXZ] + lo;
-    const float4 cxx = ld4(sxx);
-    const float2 Lxx = ld2(sxx - 2), Rxx = ld2(sxx + 4);
-    const float4 a2 = ld4(sxz);
-    const float2 Lxz = ld2(sxz - 2), Rxz = ld2(sxz + 4);
+    float4 cxx = ld4(sxx);
+    float2 Lxx = ld2(sxx - 2), Rxx = ld2(sxx + 4);
+    float4 a2 = ld4(sxz);
+    float2 Lxz = ld2(sxz - 2), Rxz = ld2(sxz + 4);
     float4 a0 = ld4(sxz - 2 * PL), a1 = ld4(sxz - PL);
-    const float4 a3 = ld4(sxz + PL);
+    float4 a3 = ld4(sxz + PL);
     float4 b0 = ld4(szz - PL);
-    const float4 b1 = ld4(szz), b2 = ld4(szz + PL), b3 = ld4(szz + 2 * PL);
-    if (EDGE && c.fsurf && G.j < 2) {
-        if (G.j == 0) {
+    float4 b1 = ld4(szz), b2 = ld4(szz + PL), b3 = ld4(szz + 2 * PL);
+#ifdef EC_PIN
+    ec_pin(Lxx, Rxx, Lxz, Rxz);
+    ec_pin(cxx, a2, a0, a1);
+    ec_pin(a3, b0, b1, b2);
+    ec_pin(b3, b3);
+#endif
+    if (EDGE && c.fsurf && jq < 2) {
+        if (jq == 0) {
             a1 = make_float4(-a2.x, -a2.y, -a2.z, -a2.w);
             a0 = make_float4(-a3.x, -a3.y, -a3.z, -a3.w);
             b0 = make_float4(-b2.x, -b2.y, -b2.z, -b2.w);
@@ -247,27 +393,24 @@ __device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const in
         d3[k] = dbw(K, xz[k], xz[k + 1], xz[k + 2], xz[k + 3]);
         d4[k] = dfw(K, comp(b0, k), comp(b1, k), comp(b2, k), comp(b3, k));
     }
-    if (G.xs_off >= 0) {
-        const float *q = c.lpx + 4 * gq;
-        const float4 pa = ld4(q + PA * c.gp), pb = ld4(q + PB * c.gp), pk = ld4(q + PK * c.gp);
-        const float4 pah = ld4(q + PAH * c.gp), pbh = ld4(q + PBH * c.gp), pkh = ld4(q + PKH * c.gp);
+    const int xtab = ec_opaque(G.xtab), ztab = ec_opaque(G.ztab);
+    if (xtab >= 0) {
+        const EcTabX T = ec_tab_x(c.lpx, xtab);
         float t1[4] = {G.s1.x, G.s1.y, G.s1.z, G.s1.w}, t3[4] = {G.s3.x, G.s3.y, G.s3.z, G.s3.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            d1[k] = pml(t1[k], comp(pah, k), comp(pbh, k), comp(pkh, k), d1[k]);
-            d3[k] = pml(t3[k], comp(pa, k), comp(pb, k), comp(pk, k), d3[k]);
+            d1[k] = pml(t1[k], comp(T.v[PAH], k), comp(T.v[PBH], k), comp(T.v[PKH], k), d1[k]);
+            d3[k] = pml(t3[k], comp(T.v[PA], k), comp(T.v[PB], k), comp(T.v[PK], k), d3[k]);
         }
         G.s1 = make_float4(t1[0], t1[1], t1[2], t1[3]); G.s3 = make_float4(t3[0], t3[1], t3[2], t3[3]);
     }
-    if (G.zs >= 0) {
-        const float *z = c.lpz + lrw;
-        const float za = z[PA * c.R], zb = z[PB * c.R], zk = z[PK * c.R];
-        const float zah = z[PAH * c.R], zbh = z[PBH * c.R], zkh = z[PKH * c.R];
+    if (ztab >= 0) {
+        const EcTabZ Z = ec_tab_z(c.lpz, ztab);
         float t2[4] = {G.s2.x, G.s2.y, G.s2.z, G.s2.w}, t4[4] = {G.s4.x, G.s4.y, G.s4.z, G.s4.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            d2[k] = pml(t2[k], za, zb, zk, d2[k]);
-            d4[k] = pml(t4[k], zah, zbh, zkh, d4[k]);
+            d2[k] = pml(t2[k], Z.v[PA], Z.v[PB], Z.v[PK], d2[k]);
+            d4[k] = pml(t4[k], Z.v[PAH], Z.v[PBH], Z.v[PKH], d4[k]);
         }
         G.s2 = make_float4(t2[0], t2[1], t2[2], t2[3]); G.s4 = make_float4(t4[0], t4[1], t4[2], t4[3]);
     }
@@ -283,20 +426,25 @@ __device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const in
 }
 
 // S update (reads velocities from LDS, writes the group's stresses in place); `amp` = source term
-// of this step for the group's source cell (cell G.src & 3 of the group), 0 when there is none
+// of this step for the group's cells (0 where there is none)
 template <bool EDGE>
-__device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const int lo, const int gq, const int lrw, const float4 &amp, float4 &S1, float4 &S2,
-                                            float4 &S3, float4 &o0, float4 &o1)
+__device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const int lo, const int jq, const float4 &amp, float4 &S1,
+                                            float4 &S2, float4 &S3, float4 &o0, float4 &o1)
 {
-    const int PL = c.PL;
+    const int PL = ec_su(c.PL);
     const FdK K = c.K;
     const float *vx = c.Lf[F_VX] + lo, *vz = c.Lf[F_VZ] + lo;
-    const float4 b1 = ld4(vx);
-    const float2 Lvx = ld2(vx - 2), Rvx = ld2(vx + 4);
-    const float4 a2 = ld4(vz);
-    const float2 Lvz = ld2(vz - 2), Rvz = ld2(vz + 4);
-    const float4 a0 = ld4(vz - 2 * PL), a1 = ld4(vz - PL), a3 = ld4(vz + PL);
-    const float4 b0 = ld4(vx - PL), b2 = ld4(vx + PL), b3 = ld4(vx + 2 * PL);
+    float4 b1 = ld4(vx);
+    float2 Lvx = ld2(vx - 2), Rvx = ld2(vx + 4);
+    float4 a2 = ld4(vz);
+    float2 Lvz = ld2(vz - 2), Rvz = ld2(vz + 4);
+    float4 a0 = ld4(vz - 2 * PL), a1 = ld4(vz - PL), a3 = ld4(vz + PL);
+    float4 b0 = ld4(vx - PL), b2 = ld4(vx + PL), b3 = ld4(vx + 2 * PL);
+#ifdef EC_PIN
+    ec_pin(Lvx, Rvx, Lvz, Rvz);
+    ec_pin(b1, a2, a0, a1);
+    ec_pin(a3, b0, b2, b3);
+#endif
     const float xv[8] = {Lvx.x, Lvx.y, b1.x, b1.y, b1.z, b1.w, Rvx.x, Rvx.y};
     const float zv[8] = {Lvz.x, Lvz.y, a2.x, a2.y, a2.z, a2.w, Rvz.x, Rvz.y};
     float e1[4], e2[4], e3[4], e4[4];
@@ -307,27 +455,24 @@ __device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const in
         e3[k] = dfw(K, comp(b0, k), comp(b1, k), comp(b2, k), comp(b3, k));
         e4[k] = dfw(K, zv[k + 1], zv[k + 2], zv[k + 3], zv[k + 4]);
     }
-    if (G.xs_off >= 0) {
-        const float *q = c.lpx + 4 * gq;
-        const float4 pa = ld4(q + PA * c.gp), pb = ld4(q + PB * c.gp), pk = ld4(q + PK * c.gp);
-        const float4 pah = ld4(q + PAH * c.gp), pbh = ld4(q + PBH * c.gp), pkh = ld4(q + PKH * c.gp);
+    const int xtab = ec_opaque(G.xtab), ztab = ec_opaque(G.ztab);
+    if (xtab >= 0) {
+        const EcTabX T = ec_tab_x(c.lpx, xtab);
         float t5[4] = {G.s5.x, G.s5.y, G.s5.z, G.s5.w}, t8[4] = {G.s8.x, G.s8.y, G.s8.z, G.s8.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            e1[k] = pml(t5[k], comp(pa, k), comp(pb, k), comp(pk, k), e1[k]);
-            e4[k] = pml(t8[k], comp(pah, k), comp(pbh, k), comp(pkh, k), e4[k]);
+            e1[k] = pml(t5[k], comp(T.v[PA], k), comp(T.v[PB], k), comp(T.v[PK], k), e1[k]);
+            e4[k] = pml(t8[k], comp(T.v[PAH], k), comp(T.v[PBH], k), comp(T.v[PKH], k), e4[k]);
         }
         G.s5 = make_float4(t5[0], t5[1], t5[2], t5[3]); G.s8 = make_float4(t8[0], t8[1], t8[2], t8[3]);
     }
-    if (G.zs >= 0) {
-        const float *z = c.lpz + lrw;
-        const float za = z[PA * c.R], zb = z[PB * c.R], zk = z[PK * c.R];
-        const float zah = z[PAH * c.R], zbh = z[PBH * c.R], zkh = z[PKH * c.R];
+    if (ztab >= 0) {
+        const EcTabZ Z = ec_tab_z(c.lpz, ztab);
         float t6[4] = {G.s6.x, G.s6.y, G.s6.z, G.s6.w}, t7[4] = {G.s7.x, G.s7.y, G.s7.z, G.s7.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            e2[k] = pml(t6[k], za, zb, zk, e2[k]);
-            e3[k] = pml(t7[k], zah, zbh, zkh, e3[k]);
+            e2[k] = pml(t6[k], Z.v[PA], Z.v[PB], Z.v[PK], e2[k]);
+            e3[k] = pml(t7[k], Z.v[PAH], Z.v[PBH], Z.v[PKH], e3[k]);
         }
         G.s6 = make_float4(t6[0], t6[1], t6[2], t6[3]); G.s7 = make_float4(t7[0], t7[1], t7[2], t7[3]);
     }
@@ -341,7 +486,7 @@ __device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const in
         rxz[k] = fmaf(comp(G.mMu, k), s3v[k], comp(oxz, k));
         rxx[k] += comp(amp, k); rzz[k] += comp(amp, k);       // source term of the cell (0 without one)
     }
-    if (EDGE && c.fsurf && G.j == 0) { rzz[0] = rzz[1] = rzz[2] = rzz[3] = 0.f; }
+    if (EDGE && c.fsurf && jq == 0) { rzz[0] = rzz[1] = rzz[2] = rzz[3] = 0.f; }
     S1 = make_float4(e1[0], e1[1], e1[2], e1[3]); S2 = make_float4(e2[0], e2[1], e2[2], e2[3]);
     S3 = make_float4(s3v[0], s3v[1], s3v[2], s3v[3]);
     o0 = make_float4(rzz[0], rzz[1], rzz[2], rzz[3]);            // published: szz, sxz
@@ -362,62 +507,73 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     // ablation builds only: slab 1 of the first shot never shows up (a workgroup that was not resident in time)
     if ((kDbg(p) & 64) && w == 1 && s == p.shot0) return;
     const int t = (int)threadIdx.x;
+    if (!mifwi::same_xcd(p.xcc_tab, s, p.NW, w, t, p.err, kEcMaxSpin, kDbg(p) & 128)) return;
     int r0, R;
     ec_slab_rows(p.nz, p.NW, w, r0, R);
     const int PL = p.PL, LR = R + 4;
     const int fsz = LR * PL;
     EcCtx c;
-    for (int k = 0; k < 5; ++k) c.Lf[k] = lds + k * fsz;
-    float *lpx = lds + 5 * fsz, *lpz = lpx + 6 * p.gp;        // C-PML tables: px [6][gp], pz [6][R]
-    c.lpx = lpx; c.lpz = lpz; c.PL = PL; c.R = R; c.gp = p.gp; c.fsurf = p.fsurf; c.K = p.K;
+    for (int k = 0; k < 5; ++k) c.Lf[k] = lds + ec_plane(k) * fsz;
+    float *lpx = lds + 5 * fsz, *lpz = lpx + 6 * p.gp;        // C-PML tables (ec_stage_tables)
+    c.lpx = lpx; c.lpz = lpz; c.PL = PL; c.fsurf = p.fsurf; c.K = p.K;
     const unsigned ncell = (unsigned)p.nz * p.gp;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long xplane = (long long)p.nz * p.wx, zplane = 2LL * p.W * p.gp;
+    // strip slots of a group in the global C-PML state (or -1)
+    auto strip_x = [&](int g) { const int c0 = 4 * g; return p.W <= 0 ? -1 : c0 < p.wl ? c0 : c0 >= p.xr0 ? p.wl + (c0 - p.xr0) : -1; };
+    auto strip_z = [&](int j) { return p.W <= 0 ? -1 : j < p.W ? j : j >= p.nz - p.W ? j - (p.nz - 2 * p.W) : -1; };
 
     // ---- this thread's groups ---------------------------------------------------------------------
     EcGroup G[NG];
     bool slow = p.nrec > kEcThreads;
-    int tsrc = -1, src_mask = 0;         // (source index << 3) | (slot << 2) | cell of the group; slots with sources
-    float tsrc_wt = 0.f, tamp = 0.f;     // tamp: this step's source term, fetched one step ahead
+    int tsq = -1;                        // group slot holding this thread's source cell (fast path: at most one), or -1
+    unsigned tsrc4 = 0;                  // byte offset of that source inside a [nsrc] row of f
+    unsigned tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;   // all ones on the source's cell of the group (exact +0 elsewhere)
+    float tw = 0.f, tnext = 0.f;         // its weight; f of the next step for that source, fetched one step ahead
+    int src_mask = 0;                    // slots with sources (slow path)
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
         EcGroup &g = G[q];
         const int gi = t + q * kEcThreads;
-        g.own = gi < R * p.ng;
-        const int lrw = g.own ? gi / p.ng : 0;
-        g.g = g.own ? gi - lrw * p.ng : 0;
+        const bool own = gi < R * p.ng;
+        const int lrw = own ? gi / p.ng : 0;
+        g.g = own ? gi - lrw * p.ng : 0;
         g.j = r0 + lrw;
-        g.inner = g.own && lrw >= 2 && lrw < R - 2;           // stencils stay inside the own rows
+        g.cls = !own ? 0 : (lrw >= 2 && lrw < R - 2) ? 1 : 2;   // 1: stencils stay inside the own rows
+        g.lo = (lrw + 2) * PL + 4 + 4 * g.g;
         const unsigned gcc = (unsigned)g.j * p.gp + 4 * g.g;
+        g.gcb = 4u * gcc;
         g.mL = g.mM = g.mMu = g.mBx = g.mBz = zero4;
         g.s1 = g.s2 = g.s3 = g.s4 = g.s5 = g.s6 = g.s7 = g.s8 = zero4;
-        g.xs_off = -1; g.zs = -1;
-        if (g.own) {
+        g.xtab = -1; g.ztab = -1;
+        int xs_off = -1, zs = -1;
+        if (own) {
             g.mL = ld4(p.mat + M_L * ncell + gcc); g.mM = ld4(p.mat + M_M * ncell + gcc);
             g.mMu = ld4(p.mat + M_MU * ncell + gcc);
             g.mBx = ld4(p.mat + M_BX * ncell + gcc); g.mBz = ld4(p.mat + M_BZ * ncell + gcc);
-            if (p.W > 0) {
-                const int c0 = 4 * g.g;
-                if (c0 < p.wl) g.xs_off = c0; else if (c0 >= p.xr0) g.xs_off = p.wl + (c0 - p.xr0);
-                if (g.j < p.W) g.zs = g.j; else if (g.j >= p.nz - p.W) g.zs = g.j - (p.nz - 2 * p.W);
-            }
+            xs_off = strip_x(g.g); zs = strip_z(g.j);
         }
-        if (g.xs_off >= 0) {
-            const float *q = p.psix + (long long)s * p.psix_shot + (long long)g.j * p.wx + g.xs_off;
+        if (xs_off >= 0) {
+            g.xtab = 24 * g.g;
+            const float *q = p.psix + (long long)s * p.psix_shot + (long long)g.j * p.wx + xs_off;
             g.s1 = ld4(q); g.s3 = ld4(q + xplane); g.s5 = ld4(q + 2 * xplane); g.s8 = ld4(q + 3 * xplane);
         }
-        if (g.zs >= 0) {
-            const float *q = p.psiz + (long long)s * p.psiz_shot + (long long)g.zs * p.gp + 4 * g.g;
+        if (zs >= 0) {
+            g.ztab = 8 * lrw;
+            const float *q = p.psiz + (long long)s * p.psiz_shot + (long long)zs * p.gp + 4 * g.g;
             g.s2 = ld4(q); g.s4 = ld4(q + zplane); g.s6 = ld4(q + 2 * zplane); g.s7 = ld4(q + 3 * zplane);
         }
-        // at most one source tap per group (otherwise: slow path, rescan per step)
+        // at most one source tap per thread (otherwise: slow path, rescan per step)
         for (int e = 0; e < p.nsrc; ++e) {
             const int cell = p.src_cell[(long long)s * p.nsrc + e];
             if (cell < 0) continue;
             const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
-            if (g.own && i0 == g.j && (i1 >> 2) == g.g) {
-                if (tsrc >= 0) slow = true;             // fast path: one source cell per thread
-                tsrc = (e << 3) | (q << 2) | (i1 & 3); tsrc_wt = p.src_w[(long long)s * p.nsrc + e];
+            if (own && i0 == g.j && (i1 >> 2) == g.g) {
+                if (tsq >= 0) slow = true;
+                tw = p.src_w[(long long)s * p.nsrc + e];
+                tsq = q; tsrc4 = 4u * e;
+                tm0 = (i1 & 3) == 0 ? ~0u : 0u; tm1 = (i1 & 3) == 1 ? ~0u : 0u;
+                tm2 = (i1 & 3) == 2 ? ~0u : 0u; tm3 = (i1 & 3) == 3 ? ~0u : 0u;
                 src_mask |= 1 << q;
             }
         }
@@ -435,12 +591,12 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         }
     }
     slow = __syncthreads_or(slow ? 1 : 0) != 0;
-    if (!slow && tsrc >= 0 && p.n_first < p.n_last)
-        tamp = tsrc_wt * p.f[((long long)p.n_first * p.nshot + s) * p.nsrc + (tsrc >> 3)];
+    const float *f_shot = p.f + (long long)s * p.nsrc;                 // f of step n: f_shot + n * f_step
+    const long long f_step = (long long)p.nshot * p.nsrc;
+    if (!slow && tsq >= 0 && p.n_first < p.n_last) tnext = *ec_at(f_shot + p.n_first * f_step, tsrc4);
 
     // ---- stage tables and the slab (+2 halo rows, + halo groups) of all five fields ----------------
-    for (int e = t; e < 6 * p.gp; e += kEcThreads) lpx[e] = p.px[e];
-    for (int e = t; e < 6 * R; e += kEcThreads) lpz[e] = p.pz[(e / R) * p.nz + r0 + (e % R)];
+    ec_stage_tables(lpx, lpz, p.px, p.pz, p.gp, p.nz, r0, R, t);
     {
         const float *gf = p.fields + (long long)s * p.shot_stride;
         const int ngl = PL / 4;
@@ -457,31 +613,37 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 
     // ---- halo hand-off: kind 0 = velocities after V, kind 1 = stresses after S ------------------
     EcHandoff X;
-    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, (kDbg(p) & 4) != 0, p.nap);
+    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, (kDbg(p) & 4) != 0, p.nap, fsz);
     const bool do_x = p.NW > 1 && !(kDbg(p) & 1);
-    auto receive = [&](int kind, unsigned epoch, int parity) {
-        X.receive(kind, epoch, parity, [&](int is_a, int off, float v) {
-            // plane address by arithmetic: indexing the pointer array with a run-time field would push the
-            // whole array into scratch memory (every access a vector-memory load)
-            (lds + (kind == 0 ? (is_a ? F_VZ : F_VX) : (is_a ? F_SXZ : F_SZZ)) * fsz)[off] = v;
-        });
-    };
-    auto publish = [&](int lrw, int gq, int kind, unsigned epoch, int parity, const float4 &o0, const float4 &o1) {
-        X.publish(lrw, gq, kind, epoch, parity, o0, o1);
-    };
-    // source term of step n for a group: fetched one step ahead (a global load in the update itself
-    // would put a memory round trip on the workgroup's critical path every step)
-    auto source_amp = [&](const EcGroup &g, int q, int n) -> float4 {
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!slow) {
-            if (tsrc >= 0 && ((tsrc >> 2) & 1) == q) {
+    // The first pass of a poll is requested before the wave's last interior update and examined after it (its
+    // flight hides behind the update); q_req = that group slot, -1: this wave has no interior group
+    EcHandoff::Pending P;
+    P.clear();
+    int q_req = -1;
+#ifdef EC_EARLY_POLL
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k == (tsrc & 3)) a[k] = tamp;
-                if (n + 1 < p.n_last)
-                    tamp = tsrc_wt * p.f[((long long)(n + 1) * p.nshot + s) * p.nsrc + (tsrc >> 3)];
+    for (int q = 0; q < NG; ++q)
+        if (__any(G[q].cls == 1)) q_req = q;
+#endif
+    auto complete = [&](int kind, unsigned epoch) {
+        // planes [vx | vz] and [szz | sxz]: the offset already selects the second one for the A field
+        float *base = kind == 0 ? c.Lf[F_VX] : c.Lf[F_SZZ];
+        X.complete(P, epoch, q_req >= 0, [&](int off, float v) { base[off] = v; });
+    };
+    // source term of step n for the cells of a group
+    auto source_amp = [&](const EcGroup &g, int q, int n) -> float4 {
+        float4 a = zero4;
+        if (!slow) {
+            if (ec_opaque(tsq) == q) {
+                // f of this step arrived during the last one; request the next (a global load in the update
+                // itself would put a memory round trip on the workgroup's critical path every step)
+                const unsigned amp = __float_as_uint(tw * tnext);
+                a = make_float4(__uint_as_float(amp & tm0), __uint_as_float(amp & tm1), __uint_as_float(amp & tm2),
+                                __uint_as_float(amp & tm3));
+                if (n + 1 < p.n_last) tnext = *ec_at(f_shot + (n + 1) * f_step, ec_opaque(tsrc4));
             }
         } else if ((src_mask >> q) & 1) {   // several sources in this thread's cells: rescan the list every step
+            float av[4] = {0.f, 0.f, 0.f, 0.f};
             for (int e = 0; e < p.nsrc; ++e) {
                 const int cell = p.src_cell[(long long)s * p.nsrc + e];
                 if (cell < 0) continue;
@@ -490,83 +652,106 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
                 const float v = p.src_w[(long long)s * p.nsrc + e] * p.f[((long long)n * p.nshot + s) * p.nsrc + e];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (k == (i1 & 3)) a[k] += v;
+                    if (k == (i1 & 3)) av[k] += v;
             }
+            a = make_float4(av[0], av[1], av[2], av[3]);
         }
-        return make_float4(a[0], a[1], a[2], a[3]);
+        return a;
     };
 
     const int nsteps = p.n_last - p.n_first;
-    const long long sshot = (long long)s * 5 * ncell;
     // Snapshot terms are stored right after they are produced; the interior update that follows gives
     // them time to retire before the next poll is issued (vector memory operations retire in order).
+    float *S_shot = SAVE ? p.S + (long long)s * 5 * ncell : nullptr;   // step n: S_shot + (n - s_first) * s_step
     auto do_v = [&](EcGroup &g, int n, int it, bool edge) {
         float4 S4, S5, o0, o1;
-        // per-step opaque: the addresses derived from these are recomputed, not hoisted out of the loop
-        const int gq = ec_opaque(g.g), jq = ec_opaque(g.j), lrw = jq - r0, lo = (lrw + 2) * PL + 4 + 4 * gq;
-        if (edge) ec_update_v<true>(g, c, lo, gq, lrw, S4, S5, o0, o1);
-        else ec_update_v<false>(g, c, lo, gq, lrw, S4, S5, o0, o1);
-        if (edge && do_x && !(kDbg(p) & 16)) publish(lrw, gq, 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
+        const int lo = ec_opaque(g.lo);
+        if (edge) {
+            const int jq = ec_opaque(g.j);
+            ec_update_v<true>(g, c, lo, jq, S4, S5, o0, o1);
+            if (do_x && !(kDbg(p) & 16)) X.publish(jq - r0, ec_opaque(g.g), 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
+        } else {
+            ec_update_v<false>(g, c, lo, 2, S4, S5, o0, o1);
+        }
         if (SAVE && !(kDbg(p) & 2)) {
-            float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(jq * p.gp + 4 * gq);
-            mifwi::stnt4(Sn + 3 * (long long)ncell, S4); mifwi::stnt4(Sn + 4 * (long long)ncell, S5);
+            float *Sn = S_shot + (long long)(n - p.s_first) * p.s_step;
+            const unsigned gcb = ec_opaque(g.gcb), nc = ec_su(ncell);
+            mifwi::stnt4(ec_at(Sn + 3 * (long long)nc, gcb), S4); mifwi::stnt4(ec_at(Sn + 4 * (long long)nc, gcb), S5);
         }
     };
     auto do_s = [&](EcGroup &g, int q, int n, int it, bool edge) {
         float4 S1, S2, S3, o0, o1;
-        const int gq = ec_opaque(g.g), jq = ec_opaque(g.j), lrw = jq - r0, lo = (lrw + 2) * PL + 4 + 4 * gq;
+        const int lo = ec_opaque(g.lo);
         const float4 amp = source_amp(g, q, n);
-        if (edge) ec_update_s<true>(g, c, lo, gq, lrw, amp, S1, S2, S3, o0, o1);
-        else ec_update_s<false>(g, c, lo, gq, lrw, amp, S1, S2, S3, o0, o1);
-        if (edge && do_x && !(kDbg(p) & 16)) publish(lrw, gq, 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
+        if (edge) {
+            const int jq = ec_opaque(g.j);
+            ec_update_s<true>(g, c, lo, jq, amp, S1, S2, S3, o0, o1);
+            if (do_x && !(kDbg(p) & 16)) X.publish(jq - r0, ec_opaque(g.g), 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
+        } else {
+            ec_update_s<false>(g, c, lo, 2, amp, S1, S2, S3, o0, o1);
+        }
         if (SAVE && !(kDbg(p) & 2)) {
-            float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot + (unsigned)(jq * p.gp + 4 * gq);
-            mifwi::stnt4(Sn, S1); mifwi::stnt4(Sn + (long long)ncell, S2); mifwi::stnt4(Sn + 2 * (long long)ncell, S3);
+            float *Sn = S_shot + (long long)(n - p.s_first) * p.s_step;
+            const unsigned gcb = ec_opaque(g.gcb), nc = ec_su(ncell);
+            mifwi::stnt4(ec_at(Sn, gcb), S1); mifwi::stnt4(ec_at(Sn + (long long)nc, gcb), S2);
+            mifwi::stnt4(ec_at(Sn + 2 * (long long)nc, gcb), S3);
         }
     };
 #ifdef MIFWI_ABLATIONS
     const bool tr_on = w == p.NW / 2 && s == p.shot0;
 #endif
+    ec_drain_vmem();
     for (int it = 0; it < nsteps; ++it) {
         const int n = p.n_first + it;
         EC_STAMP(0);
         // ---- V: interior rows first, then receive the stress halo, then the boundary rows --------
+        const bool poll_s = do_x && it > 0 && !(kDbg(p) & 32);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].inner) do_v(G[q], n, it, false);
+            if (poll_s && q == q_req) X.request(P, 1, (it - 1) & 1);
+            if (ec_opaque(G[q].cls) == 1) do_v(G[q], n, it, false);
             __builtin_amdgcn_sched_barrier(0);             // one group at a time: bounds the register peak
         }
         EC_STAMP(1);
-        if (do_x && it > 0 && !(kDbg(p) & 32)) receive(1, (unsigned)(2 * it), (it - 1) & 1);
+        if (poll_s) {
+            if (q_req < 0) X.request(P, 1, (it - 1) & 1);
+            complete(1, (unsigned)(2 * it));
+        }
         EC_STAMP(2);
         __syncthreads();                                   // A: stress halo rows are in LDS
         EC_STAMP(3);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].own && !G[q].inner) do_v(G[q], n, it, true);
+            if (ec_opaque(G[q].cls) == 2) do_v(G[q], n, it, true);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(4);
         __syncthreads();                                   // B: all velocities of the slab are in LDS
         EC_STAMP(5);
         // ---- S: interior rows, receive the velocity halo, boundary rows -----------------------------
+        const bool poll_v = do_x && !(kDbg(p) & 32);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].inner) do_s(G[q], q, n, it, false);
+            if (poll_v && q == q_req) X.request(P, 0, it & 1);
+            if (ec_opaque(G[q].cls) == 1) do_s(G[q], q, n, it, false);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(6);
-        if (do_x && !(kDbg(p) & 32)) receive(0, (unsigned)(2 * it + 1), it & 1);
+        if (poll_v) {
+            if (q_req < 0) X.request(P, 0, it & 1);
+            complete(0, (unsigned)(2 * it + 1));
+        }
         EC_STAMP(7);
         // ---- receivers sample the new velocities (stores after the poll) ----------------------------
         if (p.rec_vx != nullptr && !(kDbg(p) & 8)) {
             if (!slow) {
-                const long long ro = ((long long)n * p.nshot + s) * p.nrec + t;
-                if (smp_lo >= 0) {
-                    p.rec_vx[ro] = fmaf(smp_w, c.Lf[F_VX][smp_lo], 0.f);
-                    p.rec_vz[ro] = fmaf(smp_w, c.Lf[F_VZ][smp_lo], 0.f);
-                } else if (smp_lo == -2) {
-                    p.rec_vx[ro] = 0.f; p.rec_vz[ro] = 0.f;
+                const long long ro = ((long long)n * p.nshot + s) * p.nrec;
+                const int sl = ec_opaque(smp_lo);
+                if (sl >= 0) {
+                    *ec_at(p.rec_vx + ro, 4u * t) = fmaf(smp_w, c.Lf[F_VX][sl], 0.f);
+                    *ec_at(p.rec_vz + ro, 4u * t) = fmaf(smp_w, c.Lf[F_VZ][sl], 0.f);
+                } else if (sl == -2) {
+                    *ec_at(p.rec_vx + ro, 4u * t) = 0.f; *ec_at(p.rec_vz + ro, 4u * t) = 0.f;
                 }
             } else {
                 for (int e = t; e < p.nrec; e += kEcThreads) {
@@ -588,7 +773,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         EC_STAMP(9);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].own && !G[q].inner) do_s(G[q], q, n, it, true);
+            if (ec_opaque(G[q].cls) == 2) do_s(G[q], q, n, it, true);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(10);
@@ -600,6 +785,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         } else {
             __syncthreads();                               // D: all stresses of the slab are in LDS
         }
+#ifdef EC_EARLY_POLL
+        P.keep();
+#endif
         EC_STAMP(11);
     }
 
@@ -608,16 +796,17 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
         const EcGroup &g = G[q];
-        if (!g.own) continue;
+        if (g.cls == 0) continue;
         const long long o = (long long)(g.j + 2) * p.pitch + 4 + 4 * g.g;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) st4(gf + k * p.field_stride + o, ld4(c.Lf[k] + (g.j - r0 + 2) * PL + 4 + 4 * g.g));
-        if (g.xs_off >= 0) {
-            float *q2 = p.psix + (long long)s * p.psix_shot + (long long)g.j * p.wx + g.xs_off;
+        for (int k = 0; k < 5; ++k) st4(gf + k * p.field_stride + o, ld4(c.Lf[k] + g.lo));
+        const int xs_off = strip_x(g.g), zs = strip_z(g.j);
+        if (xs_off >= 0) {
+            float *q2 = p.psix + (long long)s * p.psix_shot + (long long)g.j * p.wx + xs_off;
             st4(q2, g.s1); st4(q2 + xplane, g.s3); st4(q2 + 2 * xplane, g.s5); st4(q2 + 3 * xplane, g.s8);
         }
-        if (g.zs >= 0) {
-            float *q2 = p.psiz + (long long)s * p.psiz_shot + (long long)g.zs * p.gp + 4 * g.g;
+        if (zs >= 0) {
+            float *q2 = p.psiz + (long long)s * p.psiz_shot + (long long)zs * p.gp + 4 * g.g;
             st4(q2, g.s2); st4(q2 + zplane, g.s4); st4(q2 + 2 * zplane, g.s6); st4(q2 + 3 * zplane, g.s7);
         }
     }
@@ -662,6 +851,7 @@ struct EaParams {
     const int *slab_cnt, *slab_list;     // receivers per slab: [nshot][NW], [nshot][NW][nrec]
     unsigned long long *xbuf;
     int *err;
+    int *xcc_tab;                        // [nshot][NW] XCC_ID + 1 of each slab's workgroup (mifwi::same_xcd)
     int dbg, nap;
     FdK K;                               // stencil weights (fd_order)
 };
@@ -688,8 +878,8 @@ __global__ void ec_build_slab_lists(const int *rec_cell, int nrec, int nz, int n
 }
 
 struct EaGroup {
-    bool own, inner;
-    int lrw, g, j, lo;
+    int cls;                                      // 0: none, 1: interior rows of the slab, 2: boundary rows
+    int g, j, lo;                                 // group in the row, grid row, LDS float offset inside a plane
     int xsl, zsl;                                 // LDS float offset of the group's psi-bar slot, or -1
     float4 bxx, bzz, bxz, vx, vz;                 // adjoint fields
     float4 a0, a1, a2, a3, a4;                    // gradient accumulators (M_L, M_M, M_MU, M_BX, M_BZ order = index)
@@ -710,13 +900,16 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     // ablation builds only: slab 1 of the first shot never shows up (a workgroup that was not resident in time)
     if ((kDbg(p) & 64) && w == 1 && s == p.shot0) return;
     const int t = (int)threadIdx.x;
+    if (!mifwi::same_xcd(p.xcc_tab, s, p.NW, w, t, p.err, kEcMaxSpin, kDbg(p) & 128)) return;
     int r0, R;
     ec_slab_rows(p.nz, p.NW, w, r0, R);
     const int PL = p.PL, LR = R + 4;
     const int fsz = LR * PL;
-    float *pln = lds;                                         // 4 planes [LR][PL]
-    float *lpx = lds + 4 * fsz, *lpz = lpx + 6 * p.gp;        // C-PML tables: px [6][gp], pz [6][R]
-    float *lxs = lpz + 6 * ((R + 3) & ~3);                    // psi-bar of the x strips [4][R][wx]
+    // 4 planes [LR][PL]: E1 E2 E3 E4 in the S^T half, D1 D2 D4 D3 in the V^T half - in both the plane a
+    // backward difference reads across slabs (E3, D4) sits one plane after the forward one (E2, D2)
+    float *pln = lds;
+    float *lpx = lds + 4 * fsz, *lpz = lpx + 6 * p.gp;        // C-PML tables (ec_stage_tables)
+    float *lxs = lpz + 8 * R;                                 // psi-bar of the x strips [4][R][wx]
     float *lzs = lxs + 4 * R * p.wx;                          // psi-bar of the z strips [4][zrows][gp]
     const unsigned ncell = (unsigned)p.nz * p.gp;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -727,6 +920,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     const int zbot_beg = p.W > 0 ? max(r0, p.nz - p.W) : r0 + R;
     const int zrows = ntop + max(0, r0 + R - zbot_beg);
     const int xsz = R * p.wx, zsz = zrows * p.gp;             // floats per memory variable
+    const int PL_ = PL, fsz_ = fsz, xsz_ = xsz, zsz_ = zsz;   // the phase bodies take these through ec_su()
+    const unsigned ncell_ = ncell;
 
     // the buffer the per-step path would READ at step n_first, and the one it would read next
     const int par_in = (p.nt - 1 - p.n_first) & 1;
@@ -740,17 +935,17 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     for (int q = 0; q < NG; ++q) {
         EaGroup &g = G[q];
         const int gi = t + q * kEcThreads;
-        g.own = gi < R * p.ng;
-        g.lrw = g.own ? gi / p.ng : 0;
-        g.g = g.own ? gi - g.lrw * p.ng : 0;
-        g.j = r0 + g.lrw;
-        g.lo = (g.lrw + 2) * PL + 4 + 4 * g.g;
-        g.inner = g.own && g.lrw >= 2 && g.lrw < R - 2;
+        const bool own = gi < R * p.ng;
+        const int lrw = own ? gi / p.ng : 0;
+        g.g = own ? gi - lrw * p.ng : 0;
+        g.j = r0 + lrw;
+        g.lo = (lrw + 2) * PL + 4 + 4 * g.g;
+        g.cls = !own ? 0 : (lrw >= 2 && lrw < R - 2) ? 1 : 2;
         g.bxx = g.bzz = g.bxz = g.vx = g.vz = zero4;
         g.a0 = g.a1 = g.a2 = g.a3 = g.a4 = zero4;
         g.S1 = g.S2 = g.S3 = g.S4 = g.S5 = zero4;
         g.xsl = -1; g.zsl = -1; g.src = -1; g.src_wt = 0.f;
-        if (g.own) {
+        if (own) {
             const unsigned gcc = (unsigned)g.j * p.gp + 4 * g.g;
             const long long o = (long long)(g.j + 2) * p.pitch + 4 + 4 * g.g;
             const float *gf = p.fields + (long long)s * p.shot_stride;
@@ -766,7 +961,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
                 if (c0 < p.wl) xs_off = c0; else if (c0 >= p.xr0) xs_off = p.wl + (c0 - p.xr0);
                 if (g.j < p.W) zs = g.j; else if (g.j >= p.nz - p.W) zs = g.j - (p.nz - 2 * p.W);
                 if (xs_off >= 0) {
-                    g.xsl = g.lrw * p.wx + xs_off;
+                    g.xsl = lrw * p.wx + xs_off;
                     const float *qx = psi_in + (long long)s * p.psix_shot + (long long)g.j * p.wx + xs_off;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) st4(lxs + k * xsz + g.xsl, ld4(qx + k * xplane));
@@ -785,7 +980,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
                 const int cell = p.src_cell[(long long)s * p.nsrc + e];
                 if (cell < 0) continue;
                 const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
-                if (g.own && i0 == g.j && (i1 >> 2) == g.g) {
+                if (own && i0 == g.j && (i1 >> 2) == g.g) {
                     if (g.src >= 0) slow = true;
                     g.src = (e << 2) | (i1 & 3); g.src_wt = p.src_w[(long long)s * p.nsrc + e];
                 }
@@ -797,63 +992,71 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     // fetched one step ahead
     const int cnt = p.slab_cnt[s * p.NW + w];
     const bool inj_fast = cnt <= kEcThreads;
-    int inj_lo = -1, inj_id = 0;
+    int inj_lo = -1;
+    unsigned inj_id4 = 0;
     float inj_w = 0.f, amp_x = 0.f, amp_z = 0.f;
     if (inj_fast && t < cnt) {
-        inj_id = p.slab_list[((long long)s * p.NW + w) * p.nrec + t];
+        const int inj_id = p.slab_list[((long long)s * p.NW + w) * p.nrec + t];
         const int cell = p.rec_cell[(long long)s * p.nrec + inj_id];
         const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
         inj_lo = (i0 - r0 + 2) * PL + 4 + i1;
         inj_w = p.rec_w[(long long)s * p.nrec + inj_id];
+        inj_id4 = 4u * inj_id;
     }
 
     // ---- tables; planes zeroed once (halo rows/columns outside the grid stay zero) -----------------
-    for (int e = t; e < 6 * p.gp; e += kEcThreads) lpx[e] = p.px[e];
-    for (int e = t; e < 6 * R; e += kEcThreads) lpz[e] = p.pz[(e / R) * p.nz + r0 + (e % R)];
+    ec_stage_tables(lpx, lpz, p.px, p.pz, p.gp, p.nz, r0, R, t);
     for (int e = t; e < fsz; e += kEcThreads) { pln[e] = 0.f; pln[fsz + e] = 0.f; pln[2 * fsz + e] = 0.f; pln[3 * fsz + e] = 0.f; }
     __syncthreads();
 
-    // ---- halo hand-off: kind 0 = E2 (plane 1), E3 (plane 2); kind 1 = D2 (plane 1), D4 (plane 3) ----
+    // ---- halo hand-off: kind 0 = E2 (plane 1), E3 (plane 2); kind 1 = D2 (plane 1), D4 (plane 2) ----
     EcHandoff X;
-    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, false, p.nap);
+    X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, false, p.nap, fsz);
     const bool do_x = p.NW > 1 && !(kDbg(p) & 1);
-    auto receive = [&](int kind, unsigned epoch, int parity) {
-        X.receive(kind, epoch, parity, [&](int is_a, int off, float v) {
-            pln[(is_a ? (kind == 0 ? 2 : 3) : 1) * fsz + off] = v;
-        });
-    };
-    auto publish = [&](int lrw, int gq, int kind, unsigned epoch, int parity, const float4 &o0, const float4 &o1) {
-        X.publish(lrw, gq, kind, epoch, parity, o0, o1);
-    };
-    const long long sshot = (long long)s * 5 * ncell;
+    EcHandoff::Pending P;                   // first pass requested before the wave's last interior update (forward kernel)
+    int q_req = -1;
+#ifdef EC_EARLY_POLL
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+        if (__any(G[q].cls == 1)) q_req = q;
+#endif
+    auto complete = [&](unsigned epoch) { X.complete(P, epoch, q_req >= 0, [&](int off, float v) { (pln + fsz)[off] = v; }); };
+    // byte offset of a group inside a [nz][gp] plane (snapshots, materials)
+    auto cell_bytes = [&](int jq, int gq) { return 4u * (unsigned)(jq * p.gp + 4 * gq); };
+    const float *S_shot = p.S + (long long)s * 5 * ncell;           // step n: S_shot + (n - s_first) * s_step
     auto request_S = [&](EaGroup &g, int n) {
-        if (!g.own || (kDbg(p) & 2)) return;
-        const float *Sn = p.S + (long long)(n - p.s_first) * p.s_step + sshot +
-                          (unsigned)(ec_opaque(g.j) * p.gp + 4 * ec_opaque(g.g));
-        g.S1 = mifwi::ldnt4(Sn); g.S2 = mifwi::ldnt4(Sn + (long long)ncell); g.S3 = mifwi::ldnt4(Sn + 2 * (long long)ncell);
-        g.S4 = mifwi::ldnt4(Sn + 3 * (long long)ncell); g.S5 = mifwi::ldnt4(Sn + 4 * (long long)ncell);
+        if (ec_opaque(g.cls) == 0 || (kDbg(p) & 2)) return;
+        const unsigned ncell = ec_su(ncell_);
+        const float *Sn = S_shot + (long long)(n - p.s_first) * p.s_step;
+        const unsigned gcb = cell_bytes(ec_opaque(g.j), ec_opaque(g.g));
+        g.S1 = mifwi::ldnt4(ec_at(Sn, gcb)); g.S2 = mifwi::ldnt4(ec_at(Sn + (long long)ncell, gcb));
+        g.S3 = mifwi::ldnt4(ec_at(Sn + 2 * (long long)ncell, gcb));
+        g.S4 = mifwi::ldnt4(ec_at(Sn + 3 * (long long)ncell, gcb)); g.S5 = mifwi::ldnt4(ec_at(Sn + 4 * (long long)ncell, gcb));
     };
     auto request_amp = [&](int n) {
-        if (inj_lo >= 0 && n >= p.n_last) {
+        if (ec_opaque(inj_lo) >= 0 && n >= p.n_last) {
             const long long o = ((long long)n * p.nshot + s) * p.nrec;
-            amp_x = (p.g_vx + o)[ec_opaque(inj_id)];
-            amp_z = (p.g_vz + o)[ec_opaque(inj_id)];
+            amp_x = *ec_at(p.g_vx + o, ec_opaque(inj_id4));
+            amp_z = *ec_at(p.g_vz + o, ec_opaque(inj_id4));
         }
     };
 
     // ---- phase bodies ----------------------------------------------------------------------------------
     // A: E from the owner's sigma-bar through the transposed C-PML -> planes; boundary rows publish E2,E3
-    auto phase_a = [&](EaGroup &g, int n, int it) {
+    auto phase_a = [&](EaGroup &g, int n, int it, const int cls) {
+        const int fsz = ec_su(fsz_), xsz = ec_su(xsz_), zsz = ec_su(zsz_);
+        const unsigned ncell = ec_su(ncell_);
         const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g), jq = ec_opaque(g.j);
-        const unsigned gcc = (unsigned)(jq * p.gp + 4 * gq);
-        const float4 Ls = ld4(p.mat + M_L * ncell + gcc), Ms = ld4(p.mat + M_M * ncell + gcc);
-        const float4 mus = ld4(p.mat + M_MU * ncell + gcc);
+        const unsigned gcb = cell_bytes(jq, gq);
+        const float4 Ls = ld4(ec_at(p.mat + M_L * ncell, gcb)), Ms = ld4(ec_at(p.mat + M_M * ncell, gcb));
+        const float4 mus = ld4(ec_at(p.mat + M_MU * ncell, gcb));
         // adjoint of szz(0,.) is discarded.  Component-wise selects: a whole-vector select was compiled
         // into a two-entry table in scratch memory (a vector-memory load per use)
         const bool top = p.fsurf && jq == 0;
         const float4 bzz = make_float4(top ? 0.f : g.bzz.x, top ? 0.f : g.bzz.y, top ? 0.f : g.bzz.z,
                                        top ? 0.f : g.bzz.w);
-        if (p.grad_f != nullptr && g.src >= 0) {
+        const int src = ec_opaque(g.src);
+        if (p.grad_f != nullptr && src >= 0) {
             float *out = p.grad_f + ((long long)n * p.nshot + s) * p.nsrc;
             // sxx + szz of the four cells, selected with compile-time lane indices: a run-time index into a
             // float4 would move the whole field into scratch memory (vector-memory traffic in the time loop)
@@ -862,8 +1065,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
                 float v = 0.f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (c == (g.src & 3)) v = pr[c];
-                out[g.src >> 2] = fmaf(g.src_wt, v, 0.f);
+                    if (c == (src & 3)) v = pr[c];
+                *ec_at(out, 4u * (unsigned)(src >> 2)) = fmaf(g.src_wt, v, 0.f);
             } else {                                      // several sources in this group: rescan
                 for (int e = 0; e < p.nsrc; ++e) {
                     const int cell = p.src_cell[(long long)s * p.nsrc + e];
@@ -886,32 +1089,29 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             e3[c] = comp(mus, c) * comp(g.bxz, c);
             e4[c] = e3[c];
         }
-        if (g.xsl >= 0) {
-            const float *q = lpx + 4 * gq;
-            const float4 pa = ld4(q + PA * p.gp), pb = ld4(q + PB * p.gp), pk = ld4(q + PK * p.gp);
-            const float4 pah = ld4(q + PAH * p.gp), pbh = ld4(q + PBH * p.gp), pkh = ld4(q + PKH * p.gp);
-            float *sl = lxs + ec_opaque(g.xsl);
+        const int xsl = ec_opaque(g.xsl), zsl = ec_opaque(g.zsl);
+        if (xsl >= 0) {
+            const EcTabX T = ec_tab_x(lpx, 24 * gq);
+            float *sl = lxs + xsl;
             const float4 s5 = ld4(sl + 2 * xsz), s8 = ld4(sl + 3 * xsz);
             float n5[4], n8[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                e1[c] = pmlT(comp(s5, c), comp(pa, c), comp(pb, c), comp(pk, c), e1[c], n5[c]);
-                e4[c] = pmlT(comp(s8, c), comp(pah, c), comp(pbh, c), comp(pkh, c), e4[c], n8[c]);
+                e1[c] = pmlT(comp(s5, c), comp(T.v[PA], c), comp(T.v[PB], c), comp(T.v[PK], c), e1[c], n5[c]);
+                e4[c] = pmlT(comp(s8, c), comp(T.v[PAH], c), comp(T.v[PBH], c), comp(T.v[PKH], c), e4[c], n8[c]);
             }
             st4(sl + 2 * xsz, make_float4(n5[0], n5[1], n5[2], n5[3]));
             st4(sl + 3 * xsz, make_float4(n8[0], n8[1], n8[2], n8[3]));
         }
-        if (g.zsl >= 0) {
-            const float *z = lpz + (jq - r0);
-            const float za = z[PA * R], zb = z[PB * R], zk = z[PK * R];
-            const float zah = z[PAH * R], zbh = z[PBH * R], zkh = z[PKH * R];
-            float *sl = lzs + ec_opaque(g.zsl);
+        if (zsl >= 0) {
+            const EcTabZ Z = ec_tab_z(lpz, 8 * (jq - r0));
+            float *sl = lzs + zsl;
             const float4 s6 = ld4(sl + 2 * zsz), s7 = ld4(sl + 3 * zsz);
             float n6[4], n7[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                e2[c] = pmlT(comp(s6, c), za, zb, zk, e2[c], n6[c]);
-                e3[c] = pmlT(comp(s7, c), zah, zbh, zkh, e3[c], n7[c]);
+                e2[c] = pmlT(comp(s6, c), Z.v[PA], Z.v[PB], Z.v[PK], e2[c], n6[c]);
+                e3[c] = pmlT(comp(s7, c), Z.v[PAH], Z.v[PBH], Z.v[PKH], e3[c], n7[c]);
             }
             st4(sl + 2 * zsz, make_float4(n6[0], n6[1], n6[2], n6[3]));
             st4(sl + 3 * zsz, make_float4(n7[0], n7[1], n7[2], n7[3]));
@@ -921,10 +1121,11 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         st4(pln + fsz + lo, E2);
         st4(pln + 2 * fsz + lo, E3);
         st4(pln + 3 * fsz + lo, make_float4(e4[0], e4[1], e4[2], e4[3]));
-        if (do_x && !g.inner) publish(jq - r0, gq, 0, (unsigned)(2 * it + 1), it & 1, E2, E3);
+        if (do_x && cls == 2) X.publish(jq - r0, gq, 0, (unsigned)(2 * it + 1), it & 1, E2, E3);
     };
     // B: v_bar -= stencils(E)
     auto phase_b = [&](EaGroup &g) {
+        const int fsz = ec_su(fsz_), PL = ec_su(PL_);
         const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g);
         const float *E1 = pln + lo, *E2 = pln + fsz + lo, *E3 = pln + 2 * fsz + lo, *E4 = pln + 3 * fsz + lo;
         const float4 c1 = ld4(E1);
@@ -949,43 +1150,42 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         g.vx = make_float4(nvx[0], nvx[1], nvx[2], nvx[3]);
         g.vz = make_float4(nvz[0], nvz[1], nvz[2], nvz[3]);
     };
-    // C: D from the new v_bar -> planes; boundary rows publish D2,D4; all five gradient accumulators
-    auto phase_c = [&](EaGroup &g, int it) {
+    // C: D from the new v_bar -> planes [D1 D2 D4 D3]; boundary rows publish D2,D4; all five gradient accumulators
+    auto phase_c = [&](EaGroup &g, int it, const int cls) {
+        const int fsz = ec_su(fsz_), xsz = ec_su(xsz_), zsz = ec_su(zsz_);
+        const unsigned ncell = ec_su(ncell_);
         const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g), jq = ec_opaque(g.j);
-        const unsigned gcc = (unsigned)(jq * p.gp + 4 * gq);
-        const float4 bxs = ld4(p.mat + M_BX * ncell + gcc), bzs = ld4(p.mat + M_BZ * ncell + gcc);
+        const unsigned gcb = cell_bytes(jq, gq);
+        const float4 bxs = ld4(ec_at(p.mat + M_BX * ncell, gcb)), bzs = ld4(ec_at(p.mat + M_BZ * ncell, gcb));
         float d1[4], d2[4], d3[4], d4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             d1[c] = comp(bxs, c) * comp(g.vx, c); d2[c] = d1[c];
             d3[c] = comp(bzs, c) * comp(g.vz, c); d4[c] = d3[c];
         }
-        if (g.xsl >= 0) {
-            const float *q = lpx + 4 * gq;
-            const float4 pa = ld4(q + PA * p.gp), pb = ld4(q + PB * p.gp), pk = ld4(q + PK * p.gp);
-            const float4 pah = ld4(q + PAH * p.gp), pbh = ld4(q + PBH * p.gp), pkh = ld4(q + PKH * p.gp);
-            float *sl = lxs + ec_opaque(g.xsl);
+        const int xsl = ec_opaque(g.xsl), zsl = ec_opaque(g.zsl);
+        if (xsl >= 0) {
+            const EcTabX T = ec_tab_x(lpx, 24 * gq);
+            float *sl = lxs + xsl;
             const float4 s1 = ld4(sl), s3 = ld4(sl + xsz);
             float n1[4], n3[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                d1[c] = pmlT(comp(s1, c), comp(pah, c), comp(pbh, c), comp(pkh, c), d1[c], n1[c]);
-                d3[c] = pmlT(comp(s3, c), comp(pa, c), comp(pb, c), comp(pk, c), d3[c], n3[c]);
+                d1[c] = pmlT(comp(s1, c), comp(T.v[PAH], c), comp(T.v[PBH], c), comp(T.v[PKH], c), d1[c], n1[c]);
+                d3[c] = pmlT(comp(s3, c), comp(T.v[PA], c), comp(T.v[PB], c), comp(T.v[PK], c), d3[c], n3[c]);
             }
             st4(sl, make_float4(n1[0], n1[1], n1[2], n1[3]));
             st4(sl + xsz, make_float4(n3[0], n3[1], n3[2], n3[3]));
         }
-        if (g.zsl >= 0) {
-            const float *z = lpz + (jq - r0);
-            const float za = z[PA * R], zb = z[PB * R], zk = z[PK * R];
-            const float zah = z[PAH * R], zbh = z[PBH * R], zkh = z[PKH * R];
-            float *sl = lzs + ec_opaque(g.zsl);
+        if (zsl >= 0) {
+            const EcTabZ Z = ec_tab_z(lpz, 8 * (jq - r0));
+            float *sl = lzs + zsl;
             const float4 s2 = ld4(sl), s4 = ld4(sl + zsz);
             float n2[4], n4[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                d2[c] = pmlT(comp(s2, c), za, zb, zk, d2[c], n2[c]);
-                d4[c] = pmlT(comp(s4, c), zah, zbh, zkh, d4[c], n4[c]);
+                d2[c] = pmlT(comp(s2, c), Z.v[PA], Z.v[PB], Z.v[PK], d2[c], n2[c]);
+                d4[c] = pmlT(comp(s4, c), Z.v[PAH], Z.v[PBH], Z.v[PKH], d4[c], n4[c]);
             }
             st4(sl, make_float4(n2[0], n2[1], n2[2], n2[3]));
             st4(sl + zsz, make_float4(n4[0], n4[1], n4[2], n4[3]));
@@ -993,9 +1193,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         const float4 D2 = make_float4(d2[0], d2[1], d2[2], d2[3]), D4 = make_float4(d4[0], d4[1], d4[2], d4[3]);
         st4(pln + lo, make_float4(d1[0], d1[1], d1[2], d1[3]));
         st4(pln + fsz + lo, D2);
-        st4(pln + 2 * fsz + lo, make_float4(d3[0], d3[1], d3[2], d3[3]));
-        st4(pln + 3 * fsz + lo, D4);
-        if (do_x && !g.inner) publish(jq - r0, gq, 1, (unsigned)(2 * it + 2), it & 1, D2, D4);
+        st4(pln + 2 * fsz + lo, D4);
+        st4(pln + 3 * fsz + lo, make_float4(d3[0], d3[1], d3[2], d3[3]));
+        if (do_x && cls == 2) X.publish(jq - r0, gq, 1, (unsigned)(2 * it + 2), it & 1, D2, D4);
         // gradients (oracle order): Ms, Ls, mus from the old sigma_bar; bxs, bzs from the new v_bar
         const bool top = p.fsurf && jq == 0;
         const float4 bzz = make_float4(top ? 0.f : g.bzz.x, top ? 0.f : g.bzz.y, top ? 0.f : g.bzz.z,
@@ -1015,8 +1215,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     };
     // D: sigma_bar -= stencils(D) (+ transposed free-surface mirroring on grid rows 0 and 1)
     auto phase_d = [&](EaGroup &g, const bool edge) {
-        const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g), jq = ec_opaque(g.j);
-        const float *D1 = pln + lo, *D2 = pln + fsz + lo, *D3 = pln + 2 * fsz + lo, *D4 = pln + 3 * fsz + lo;
+        const int fsz = ec_su(fsz_), PL = ec_su(PL_);
+        const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g);
+        const float *D1 = pln + lo, *D2 = pln + fsz + lo, *D4 = pln + 2 * fsz + lo, *D3 = pln + 3 * fsz + lo;
         const float4 c1 = ld4(D1);
         const float2 L1 = ld2(D1 - 2), R1 = ld2(D1 + 4);
         const float4 c3 = ld4(D3);
@@ -1036,14 +1237,17 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             nxz[c] = comp(g.bxz, c) - (dz2 + dx3);
             nzz[c] = comp(g.bzz, c) - dz4;
         }
-        if (edge && p.fsurf && jq < 2) {
-            // grid rows 0 and 1 are local rows 2 and 3 of slab 0
-            const float4 r0d2 = ld4(pln + fsz + 2 * PL + 4 + 4 * gq), r1d2 = ld4(pln + fsz + 3 * PL + 4 + 4 * gq);
-            const float4 r0d4 = ld4(pln + 3 * fsz + 2 * PL + 4 + 4 * gq);
+        if (edge && p.fsurf) {
+            const int jq = ec_opaque(g.j);
+            if (jq < 2) {
+                // grid rows 0 and 1 are local rows 2 and 3 of slab 0
+                const float4 r0d2 = ld4(pln + fsz + 2 * PL + 4 + 4 * gq), r1d2 = ld4(pln + fsz + 3 * PL + 4 + 4 * gq);
+                const float4 r0d4 = ld4(pln + 2 * fsz + 2 * PL + 4 + 4 * gq);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (jq == 0) nxz[c] = nxz[c] + fmaf(K.c1, comp(r0d2, c), K.c2 * comp(r1d2, c));
-                else { nxz[c] = nxz[c] + K.c2 * comp(r0d2, c); nzz[c] = nzz[c] + K.c2 * comp(r0d4, c); }
+                for (int c = 0; c < 4; ++c) {
+                    if (jq == 0) nxz[c] = nxz[c] + fmaf(K.c1, comp(r0d2, c), K.c2 * comp(r1d2, c));
+                    else { nxz[c] = nxz[c] + K.c2 * comp(r0d2, c); nzz[c] = nzz[c] + K.c2 * comp(r0d4, c); }
+                }
             }
         }
 #pragma unroll
@@ -1055,6 +1259,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     };
 
     const int nsteps = p.n_first - p.n_last + 1;
+    ec_drain_vmem();
 #pragma unroll
     for (int q = 0; q < NG; ++q) request_S(G[q], p.n_first);
     request_amp(p.n_first);
@@ -1063,7 +1268,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         // ---- A ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].own) phase_a(G[q], n, it);
+            const int cls = ec_opaque(G[q].cls);
+            if (cls != 0) phase_a(G[q], n, it, cls);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (p.grad_f != nullptr && w == 0) {               // inactive source taps: slab 0 writes their zeros
@@ -1075,14 +1281,18 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         // ---- B ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].inner) phase_b(G[q]);
+            if (do_x && q == q_req) X.request(P, 0, it & 1);
+            if (ec_opaque(G[q].cls) == 1) phase_b(G[q]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (do_x) receive(0, (unsigned)(2 * it + 1), it & 1);
+        if (do_x) {
+            if (q_req < 0) X.request(P, 0, it & 1);
+            complete((unsigned)(2 * it + 1));
+        }
         __syncthreads();                                   // 2: E halo rows are in LDS
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].own && !G[q].inner) phase_b(G[q]);
+            if (ec_opaque(G[q].cls) == 2) phase_b(G[q]);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                   // 3: every read of E is done
@@ -1090,12 +1300,13 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         if (cnt > 0) {
 #pragma unroll
             for (int q = 0; q < NG; ++q)
-                if (G[q].own) { st4(pln + ec_opaque(G[q].lo), zero4); st4(pln + fsz + ec_opaque(G[q].lo), zero4); }
+                if (ec_opaque(G[q].cls) != 0) { st4(pln + ec_opaque(G[q].lo), zero4); st4(pln + fsz + ec_opaque(G[q].lo), zero4); }
             __syncthreads();
             if (inj_fast) {
-                if (inj_lo >= 0) {
-                    atomicAdd(pln + ec_opaque(inj_lo), inj_w * amp_x);
-                    atomicAdd(pln + fsz + ec_opaque(inj_lo), inj_w * amp_z);
+                const int il = ec_opaque(inj_lo);
+                if (il >= 0) {
+                    atomicAdd(pln + il, inj_w * amp_x);
+                    atomicAdd(pln + fsz + il, inj_w * amp_z);
                 }
             } else {
                 const int *lst = p.slab_list + ((long long)s * p.NW + w) * p.nrec;
@@ -1112,7 +1323,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < NG; ++q)
-                if (G[q].own) {
+                if (ec_opaque(G[q].cls) != 0) {
                     const float4 ix = ld4(pln + ec_opaque(G[q].lo)), iz = ld4(pln + fsz + ec_opaque(G[q].lo));
                     G[q].vx = make_float4(G[q].vx.x + ix.x, G[q].vx.y + ix.y, G[q].vx.z + ix.z, G[q].vx.w + ix.w);
                     G[q].vz = make_float4(G[q].vz.x + iz.x, G[q].vz.y + iz.y, G[q].vz.z + iz.z, G[q].vz.w + iz.w);
@@ -1122,17 +1333,22 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         // ---- C ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].own) phase_c(G[q], it);
+            const int cls = ec_opaque(G[q].cls);
+            if (cls != 0) phase_c(G[q], it, cls);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                   // 4: D planes complete on the own rows
         // ---- D ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].inner) phase_d(G[q], false);
+            if (do_x && q == q_req) X.request(P, 1, it & 1);
+            if (ec_opaque(G[q].cls) == 1) phase_d(G[q], false);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (do_x) receive(1, (unsigned)(2 * it + 2), it & 1);
+        if (do_x) {
+            if (q_req < 0) X.request(P, 1, it & 1);
+            complete((unsigned)(2 * it + 2));
+        }
         if (it + 1 < nsteps) {
 #pragma unroll
             for (int q = 0; q < NG; ++q) request_S(G[q], n - 1);      // after the poll: loads retire in order
@@ -1140,7 +1356,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         __syncthreads();                                   // 5: D halo rows are in LDS
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (G[q].own && !G[q].inner) phase_d(G[q], true);
+            if (ec_opaque(G[q].cls) == 2) phase_d(G[q], true);
             __builtin_amdgcn_sched_barrier(0);
         }
         if ((it & 31) == 31 || it == nsteps - 1) {
@@ -1158,7 +1374,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
         const EaGroup &g = G[q];
-        if (!g.own) continue;
+        if (g.cls == 0) continue;
         const long long o = (long long)(g.j + 2) * p.pitch + 4 + 4 * g.g;
         st4(gf + F_VX * p.field_stride + o, g.vx); st4(gf + F_VZ * p.field_stride + o, g.vz);
         st4(gf + F_SXX * p.field_stride + o, g.bxx); st4(gf + F_SZZ * p.field_stride + o, g.bzz);
@@ -1168,7 +1384,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         st4(ga, g.a0); st4(ga + ncell, g.a1); st4(ga + 2 * (long long)ncell, g.a2);
         st4(ga + 3 * (long long)ncell, g.a3); st4(ga + 4 * (long long)ncell, g.a4);
         if (g.xsl >= 0) {
-            const int xs_off = g.xsl - g.lrw * p.wx;
+            const int xs_off = g.xsl - (g.j - r0) * p.wx;
             float *qx = psi_out + (long long)s * p.psix_shot + (long long)g.j * p.wx + xs_off;
 #pragma unroll
             for (int k = 0; k < 4; ++k) st4(qx + k * xplane, ld4(lxs + k * xsz + g.xsl));

@@ -131,12 +131,16 @@ np.savez(sys.argv[1], rec=rec.detach().cpu().numpy(), gr=r.grad.cpu().numpy(), v
 """
 
 
-def test_a_workgroup_that_never_shows_up_times_out_on_the_device_and_the_call_falls_back(tmp_path):
+@pytest.mark.parametrize("bit", ["64", "128"])
+def test_a_workgroup_that_never_shows_up_times_out_on_the_device_and_the_call_falls_back(tmp_path, bit):
     """The device side of the time-out, once: in the ablation build (libmifwi_ablations.so, built by
     __graft_entry__.build() with -DMIFWI_ABLATIONS) debug bit 64 makes slab 1 of the first shot of every
     single-launch kernel exit at once.  Its neighbours spin out, the first to give up publishes the error word, the
     rest of the launch bails within 256 polls, the host zeroes the state and runs the per-step kernels: same
-    traces bit for bit, gradients to summation order."""
+    traces bit for bit, gradients to summation order.
+    Bit 128: every workgroup reports a different XCD.  The hand-off granules are published with stores that stay in
+    the XCD's L2, so the slabs of a shot must share an XCD; the placement check at the head of the kernels
+    (mifwi::same_xcd) sees the mismatch, the launch bails out at once and the call falls back the same way."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "physicsbasedfwi2_amd", "libmifwi_ablations.so")
     if not os.path.exists(lib):
@@ -144,7 +148,7 @@ def test_a_workgroup_that_never_shows_up_times_out_on_the_device_and_the_call_fa
     script = tmp_path / "child.py"
     script.write_text(_CHILD % {"tests": os.path.join(root, "tests"), "root": root})
     outs = []
-    for tag, env in (("ref", {}), ("abl", {"MIFWI_LIB": lib, "MIFWI_AC_CL_DBG": "64", "MIFWI_EL_CL_DBG": "64"})):
+    for tag, env in (("ref", {}), ("abl", {"MIFWI_LIB": lib, "MIFWI_AC_CL_DBG": bit, "MIFWI_EL_CL_DBG": bit})):
         out = tmp_path / (tag + ".npz")
         res = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, **env), capture_output=True,
                              text=True, timeout=600)
