@@ -712,17 +712,15 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     bool failed = false;
     const bool do_x = p.NW > 1 && !(kDbg(p) & 1);
     // forward: all four boundary rows live in slot 0 when a row has at most kClThreads/4 groups
-#ifdef CL_NO_EARLY_FWD
-    const bool early_pub = false;
-#else
     const bool early_pub = !adj && do_x && 4 * p.ng <= kClThreads;
-#endif
     // adjoint: the same, once the receivers that sit IN the boundary rows have been injected (the other
     // receivers are injected after the interior slots, as before)
-#ifdef CL_NO_EARLY_ADJ
-    const bool early_adj = false;
-#else
+    // (worth 3 % while a hand-off crossed the fabric; with granules that stay in the XCD's L2 the two extra barriers
+    // cost more than the head start gains: C2 adjoint 6.2 -> 5.95 us per step without it.  -DCL_EARLY_ADJ builds it.)
+#ifdef CL_EARLY_ADJ
     const bool early_adj = adj && do_x && 4 * p.ng <= kClThreads && !slow_sparse;
+#else
+    const bool early_adj = false;
 #endif
     const bool edge_recv_any = early_adj && __syncthreads_or((inj_pack >= 0 && inj_edge()) ? 1 : 0) != 0;
 
