@@ -1698,6 +1698,14 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         float *backup = reinterpret_cast<float *>(lists) + pl->list_elems;
         rc = el_cluster_backup(work, adj_state, backup, flags, st);
         if (rc) return rc;
+#ifdef MIFWI_ABLATIONS
+        const char *trace_path = getenv("MIFWI_EL_CL_TRACE");
+        const size_t trace_n = 64 * 8 * 16;
+        if (trace_path && *trace_path) {
+            MIFWI_HIP_TRY(hipMalloc(&c.trace, trace_n * sizeof(long long)));
+            MIFWI_HIP_TRY(hipMemsetAsync(c.trace, 0, trace_n * sizeof(long long), st));
+        }
+#endif
         for (int s0 = 0; s0 < d.nshot && mifwi::fake_timeout() != 1; s0 += pl->adj_shots) {
             c.shot0 = s0;
             c.shot1 = std::min(d.nshot, s0 + pl->adj_shots);
@@ -1711,6 +1719,21 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         int err = 0;
         MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
         MIFWI_HIP_TRY(hipStreamSynchronize(st));
+#ifdef MIFWI_ABLATIONS
+        if (c.trace) {
+            std::vector<long long> h(trace_n);
+            MIFWI_HIP_TRY(hipMemcpy(h.data(), c.trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost));
+            MIFWI_HIP_TRY(hipFree(c.trace));
+            if (FILE *fp = fopen(trace_path, "a")) {
+                fprintf(fp, "# el_cluster_adj steps=%d\n", n_hi - n_lo + 1);
+                for (size_t i = 0; i < trace_n; i += 16) {
+                    for (int k = 0; k < 16; ++k) fprintf(fp, "%lld ", h[i + k]);
+                    fprintf(fp, "\n");
+                }
+                fclose(fp);
+            }
+        }
+#endif
         if (err != 0 || mifwi::fake_timeout()) {
             rc = el_cluster_restore(work, adj_state, backup, flags, st);
             if (rc) return rc;

@@ -698,7 +698,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         }
     };
 #ifdef MIFWI_ABLATIONS
-    const bool tr_on = w == p.NW / 2 && s == p.shot0;
+    const bool tr_on = w == (((kDbg(p) >> 8) & 15) ? ((kDbg(p) >> 8) & 15) - 1 : p.NW / 2) && s == p.shot0;   // dbg bits 8-11: traced slab + 1
 #endif
     ec_drain_vmem();
     for (int it = 0; it < nsteps; ++it) {
@@ -854,6 +854,9 @@ struct EaParams {
     int *xcc_tab;                        // [nshot][NW] XCC_ID + 1 of each slab's workgroup (mifwi::same_xcd)
     int dbg, nap;
     FdK K;                               // stencil weights (fd_order)
+#ifdef MIFWI_ABLATIONS
+    long long *trace;                    // phase time stamps of one workgroup (MIFWI_EL_CL_TRACE), see EC_STAMP
+#endif
 };
 
 // receivers of each slab (adjoint sources), one block per shot
@@ -1259,12 +1262,16 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     };
 
     const int nsteps = p.n_first - p.n_last + 1;
+#ifdef MIFWI_ABLATIONS
+    const bool tr_on = w == (((kDbg(p) >> 8) & 15) ? ((kDbg(p) >> 8) & 15) - 1 : p.NW / 2) && s == p.shot0;   // dbg bits 8-11: traced slab + 1
+#endif
     ec_drain_vmem();
 #pragma unroll
     for (int q = 0; q < NG; ++q) request_S(G[q], p.n_first);
     request_amp(p.n_first);
     for (int it = 0; it < nsteps; ++it) {
         const int n = p.n_first - it;
+        EC_STAMP(0);
         // ---- A ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
@@ -1277,7 +1284,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             for (int e = t + kEcThreads; e < p.nsrc; e += kEcThreads)
                 if (p.src_cell[(long long)s * p.nsrc + e] < 0) p.grad_f[((long long)n * p.nshot + s) * p.nsrc + e] = 0.f;
         }
+        EC_STAMP(1);
         __syncthreads();                                   // 1: E planes complete on the own rows
+        EC_STAMP(2);
         // ---- B ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
@@ -1285,17 +1294,22 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             if (ec_opaque(G[q].cls) == 1) phase_b(G[q]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        EC_STAMP(3);
         if (do_x) {
             if (q_req < 0) X.request(P, 0, it & 1);
             complete((unsigned)(2 * it + 1));
         }
+        EC_STAMP(4);
         __syncthreads();                                   // 2: E halo rows are in LDS
+        EC_STAMP(5);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             if (ec_opaque(G[q].cls) == 2) phase_b(G[q]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        EC_STAMP(6);
         __syncthreads();                                   // 3: every read of E is done
+        EC_STAMP(7);
         // ---- receivers of this slab: v_bar += w g, through planes 0 and 1 ---------------------------
         if (cnt > 0) {
 #pragma unroll
@@ -1330,6 +1344,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
                 }
             request_amp(n - 1);
         }
+        EC_STAMP(8);
         // ---- C ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
@@ -1337,7 +1352,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             if (cls != 0) phase_c(G[q], it, cls);
             __builtin_amdgcn_sched_barrier(0);
         }
+        EC_STAMP(9);
         __syncthreads();                                   // 4: D planes complete on the own rows
+        EC_STAMP(10);
         // ---- D ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
@@ -1345,20 +1362,25 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             if (ec_opaque(G[q].cls) == 1) phase_d(G[q], false);
             __builtin_amdgcn_sched_barrier(0);
         }
+        EC_STAMP(11);
         if (do_x) {
             if (q_req < 0) X.request(P, 1, it & 1);
             complete((unsigned)(2 * it + 2));
         }
+        EC_STAMP(12);
         if (it + 1 < nsteps) {
 #pragma unroll
             for (int q = 0; q < NG; ++q) request_S(G[q], n - 1);      // after the poll: loads retire in order
         }
+        EC_STAMP(13);
         __syncthreads();                                   // 5: D halo rows are in LDS
+        EC_STAMP(14);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             if (ec_opaque(G[q].cls) == 2) phase_d(G[q], true);
             __builtin_amdgcn_sched_barrier(0);
         }
+        EC_STAMP(15);
         if ((it & 31) == 31 || it == nsteps - 1) {
             if (__syncthreads_or(X.failed ? 1 : 0)) {        // 6 (+ collective time-out check)
                 if (t == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

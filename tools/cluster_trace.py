@@ -6,6 +6,9 @@ import numpy as np
 
 NAMES = ["V interior", "poll S halo", "wait barrier A", "V boundary", "wait barrier B", "S interior", "poll V halo",
          "receivers", "wait barrier C", "S boundary", "wait barrier D"]
+NAMES_ADJ = ["A: E + publish", "wait barrier 1", "B interior", "poll E halo", "wait barrier 2", "B boundary",
+             "wait barrier 3", "receivers", "C: D + publish + grad", "wait barrier 4", "D interior", "poll D halo",
+             "request S", "wait barrier 5", "D boundary"]
 
 
 def main(path):
@@ -20,18 +23,20 @@ def main(path):
     if cur:
         blocks.append((head, cur))
     for head, rows in blocks:
-        a = np.array(rows, dtype=np.int64).reshape(64, 8, 16)[:, :, :12]
+        adj = "adj" in head
+        names = NAMES_ADJ if adj else NAMES
+        a = np.array(rows, dtype=np.int64).reshape(64, 8, 16)[:, :, :len(names) + 1]
         if not a.any():
             continue
         a = a[4:60]                                        # steps with every stamp written
         d = np.diff(a, axis=2).astype(np.float64)          # [step][wave][phase]
         step = (a[1:, :, 0] - a[:-1, :, 0]).mean()
         print(head, "| s_memtime ticks per step %.0f" % step)
-        print("%-16s" % "phase" + "".join("  wave%d" % w for w in range(8)) + "    max")
-        for k, nm in enumerate(NAMES):
+        print("%-22s" % "phase" + "".join("  wave%d" % w for w in range(8)) + "    max")
+        for k, nm in enumerate(names):
             m = d[:, :, k].mean(axis=0)
-            print("%-16s" % nm + "".join("%7.0f" % x for x in m) + "%7.0f" % m.max())
-        print("%-16s" % "sum" + "".join("%7.0f" % x for x in d.mean(axis=0).sum(axis=1)))
+            print("%-22s" % nm + "".join("%7.0f" % x for x in m) + "%7.0f" % m.max())
+        print("%-22s" % "sum" + "".join("%7.0f" % x for x in d.mean(axis=0).sum(axis=1)))
 
 
 if __name__ == "__main__":
