@@ -260,6 +260,12 @@ struct EcHandoff {
 #pragma unroll
         for (int k = 0; k < kEcGr; ++k)
             if (lo[k] >= 0) dest(lo[k], __uint_as_float((unsigned)q.v[k]));
+        // Vector-memory operations of a wave complete in order, so with the last sweep landed nothing this wave
+        // issued before it is in flight any more: vmcnt(0) costs nothing here, and it is the only way to tell the
+        // compiler.  Without it the registers of the sweep count as "possibly pending" on some path through the
+        // spin loop, and the first reuse of each one in the update that follows is guarded by an s_waitcnt vmcnt -
+        // which by then waits for the snapshot traffic issued in between (adjoint: 1500 clocks per step).
+        ec_drain_vmem();
     }
     template <class Dest>
     __device__ __forceinline__ void receive(int kind, unsigned epoch, int parity, Dest dest)
@@ -1368,6 +1374,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             complete((unsigned)(2 * it + 2));
         }
         EC_STAMP(12);
+        if (!do_x) ec_drain_vmem();                        // one slab: no poll has said so (EcHandoff::complete)
         if (it + 1 < nsteps) {
 #pragma unroll
             for (int q = 0; q < NG; ++q) request_S(G[q], n - 1);      // after the poll: loads retire in order
