@@ -925,6 +925,10 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
 #pragma unroll
             for (int kk = 0; kk < kGr; ++kk)
                 if (rcv_lo[kk] >= 0) prv[rcv_lo[kk]] = __uint_as_float((unsigned)v[kk]);
+            // the sweep has landed, so (vector memory completes in order) nothing this wave issued before it is in
+            // flight: stating vmcnt(0) is free and stops the compiler from guarding the reuse of the sweep registers
+            // with waits that would later stall on the snapshot stores / prefetches issued below
+            __builtin_amdgcn_s_waitcnt(0x0f70);
         }
         // global traffic that nobody waits for goes AFTER the hand-off (vector memory operations
         // retire in order: a poll issued behind these would wait for them)
