@@ -886,6 +886,18 @@ __global__ void ec_build_slab_lists(const int *rec_cell, int nrec, int nz, int n
     if ((int)threadIdx.x < NW) slab_cnt[s * NW + threadIdx.x] = cnt[threadIdx.x];
 }
 
+// Where the snapshot planes of the coming phase C are requested (80 KB per workgroup and step, from HBM): slot 0 right
+// after the poll of the previous step's phase D (0), the other slots at the head of the B boundary update (2) - half
+// the burst at either point.  All of it after the poll, as in round 1, kept the wave's memory queue busy for 3800 clocks
+// and delayed the material loads of phase A behind it (vector memory returns in order); measured on 100x300,
+// adjoint us per step: (0,0) 10.6, (0,1) 10.2, (1,1) 10.5, (1,2) 10.1, (2,2) 10.3, (0,2) 9.95.
+#ifndef EA_S0
+#define EA_S0 0
+#endif
+#ifndef EA_S1
+#define EA_S1 2
+#endif
+
 struct EaGroup {
     int cls;                                      // 0: none, 1: interior rows of the slab, 2: boundary rows
     int g, j, lo;                                 // group in the row, grid row, LDS float offset inside a plane
@@ -1293,6 +1305,11 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         EC_STAMP(1);
         __syncthreads();                                   // 1: E planes complete on the own rows
         EC_STAMP(2);
+        if (it > 0) {
+#pragma unroll
+            for (int q = 0; q < NG; ++q)
+                if ((q == 0 ? EA_S0 : EA_S1) == 1) request_S(G[q], n);
+        }
         // ---- B ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
@@ -1308,6 +1325,11 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         EC_STAMP(4);
         __syncthreads();                                   // 2: E halo rows are in LDS
         EC_STAMP(5);
+        if (it > 0) {
+#pragma unroll
+            for (int q = 0; q < NG; ++q)
+                if ((q == 0 ? EA_S0 : EA_S1) == 2) request_S(G[q], n);
+        }
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             if (ec_opaque(G[q].cls) == 2) phase_b(G[q]);
@@ -1377,7 +1399,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         if (!do_x) ec_drain_vmem();                        // one slab: no poll has said so (EcHandoff::complete)
         if (it + 1 < nsteps) {
 #pragma unroll
-            for (int q = 0; q < NG; ++q) request_S(G[q], n - 1);      // after the poll: loads retire in order
+            for (int q = 0; q < NG; ++q)
+                if ((q == 0 ? EA_S0 : EA_S1) == 0) request_S(G[q], n - 1);      // after the poll: loads retire in order
         }
         EC_STAMP(13);
         __syncthreads();                                   // 5: D halo rows are in LDS
