@@ -11,6 +11,16 @@ traces.  Conventions that are this library's own (deepwave's binaries are not av
 pin against): the absorbing layer is the reference's in-tree sponge
 (seisgan/fwi/pde/seismic/model.py:6-29), `pml_width` cells wide (default 20), the model is
 edge-replicated into it, and rec[n] samples the field before step n.
+
+``Propagator(..., absorbing="cpml")`` swaps the sponge for a convolutional PML of the same width: the scalar
+equation u_tt = vp^2 (lap u + f) is then advanced as the first-order pressure-velocity system on the staggered
+grid - the P-SV solver of this library in a fluid (Vs = 0, rho = 1), which carries the C-PML with memory variables
+on every derivative and its exact transposed adjoint (csrc/mifwi_elastic.hip; DENISE's PHYSICS = 2 runs the same
+way).  u is the pressure -(sxx + szz)/2; the source enters as the stress increment -vp^2 dt^2 cumsum(f) at the
+source cell, which makes the second time difference of u receive vp^2 dt^2 f exactly as in the sponge scheme.  Same
+orders of accuracy (2 in time, 4 in space), a different discretisation: inside the model the two modes agree to the
+discretisation error (tests/test_compat_gpu.py), at the edges the C-PML reflects an order of magnitude less.  Such
+runs use the one-launch-per-half-step kernels (pressure receivers).
 """
 import functools
 import math
@@ -18,7 +28,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from ... import acoustic, profiles
+from ... import acoustic, elastic, profiles
 from ..._lib import MifwiError
 
 DEFAULT_PML_WIDTH = 20
@@ -85,8 +95,12 @@ def _sponge(n, width, d, h, dt, device):
 
 
 class Propagator(torch.nn.Module):
-    def __init__(self, model, dx, pml_width=None, survey_pad=None, vpmax=None):
+    def __init__(self, model, dx, pml_width=None, survey_pad=None, vpmax=None, absorbing="sponge", pml_freq=None):
         super().__init__()
+        if absorbing not in ("sponge", "cpml"):
+            raise MifwiError("absorbing must be 'sponge' or 'cpml'")
+        self.absorbing = absorbing
+        self.pml_freq = pml_freq                 # C-PML only: dominant frequency (Hz) of the frequency shift
         if not isinstance(model, dict) or "vp" not in model:
             raise MifwiError("model must be a dict holding 'vp'")
         vp = model["vp"]
@@ -98,10 +112,42 @@ class Propagator(torch.nn.Module):
         self.vpmax = vpmax
         self.shots_per_group = 0
 
+    def _forward_cpml(self, source_amplitudes, source_locations, receiver_locations, dt):
+        vp = self.vp
+        dev = vp.device
+        P = self.pml_width
+        dz, dx = self.spacing
+        if abs(dz - dx) > 1e-9 * max(dz, dx):
+            raise MifwiError("absorbing='cpml' needs square cells (dz == dx)")
+        h = dz
+        vmax = float(self.vpmax) if self.vpmax is not None else float(vp.detach().max())
+        dt_max = CFL_SAFETY * profiles.elastic_cfl_limit(h, vmax, 4)
+        ratio = max(1, int(math.ceil(abs(dt) / dt_max - 1e-9)))
+        dti = dt / ratio
+        vp_pad = _EdgePad.apply(vp.float(), P)
+        nz, nx = vp_pad.shape
+        mat = elastic.staggered_materials(vp_pad, torch.zeros_like(vp_pad), torch.ones_like(vp_pad), dti, h)
+        sc, sw = profiles.cells_truncate(source_locations.detach(), self.spacing, P, nx)
+        rc, rw = profiles.cells_truncate(receiver_locations.detach(), self.spacing, P, nx)
+        f = _upsample(source_amplitudes.to(device=dev, dtype=torch.float32), ratio)
+        # stress increment whose second time difference is vp^2 dt^2 f at the source cell (differentiable in vp)
+        vp_src = vp_pad.reshape(-1)[sc.to(dev).long().clamp(min=0)].reshape(f.shape[1:])
+        a = -(dti * dti) * vp_src * vp_src * torch.cumsum(f, dim=0)
+        fpml = float(self.pml_freq) if self.pml_freq is not None else 0.25 / abs(dt) / 5.0
+        pz = torch.tensor(profiles.cpml_tables(nz, P, h, dti, vmax, fpml))
+        px = torch.tensor(profiles.cpml_tables(nx, P, h, dti, vmax, fpml))
+        _, _, rp = elastic.propagate(mat, a, pz, px, sc, sw, rc, rw, P, shots_per_group=self.shots_per_group,
+                                     record_pressure=True)
+        # u = -(sxx + szz)/2 after the stress update of step n is u^{n+1}; rec[n] samples u^n (sponge convention)
+        u = torch.cat([torch.zeros_like(rp[:1]), -0.5 * rp[:-1]], dim=0)
+        return u[::ratio] if ratio > 1 else u
+
     def forward(self, source_amplitudes, source_locations, receiver_locations, dt):
         vp = self.vp
         if not vp.is_cuda:
             raise MifwiError("model must live on a HIP device: libmifwi has no CPU fallback")
+        if self.absorbing == "cpml":
+            return self._forward_cpml(source_amplitudes, source_locations, receiver_locations, dt)
         dev = vp.device
         P = self.pml_width
         dz, dx = self.spacing

@@ -1323,6 +1323,7 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *pl, const float *r, const float 
         if (rc) return rc;
         rc = snap ? cluster_run<1>(pl, c, xbuf, st) : cluster_run<0>(pl, c, xbuf, st);
         if (rc != mifwi::kClusterTimedOut) return rc;
+        mifwi::note_fallback("acoustic");
         rc = cluster_restore(work, 2 * pl->field_elems, backup, flags, st);
         if (rc) return rc;
     }
@@ -1379,6 +1380,7 @@ int mifwi_acoustic_born(mifwi_acoustic_plan *pl, const float *r, const float *q0
         if (rc) return rc;
         rc = cluster_run<3>(pl, c, xbuf, st);
         if (rc != mifwi::kClusterTimedOut) return rc;
+        mifwi::note_fallback("acoustic");
         rc = cluster_restore(work, 2 * pl->field_elems, backup, flags, st);
         if (rc) return rc;
     }
@@ -1457,6 +1459,7 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
         if (rc) return rc;
         rc = cluster_run<2>(pl, c, xbuf, st);
         if (rc == mifwi::kClusterTimedOut) {
+            mifwi::note_fallback("acoustic");
             rc = cluster_restore(work, state, backup, flags, st);
             if (rc) return rc;
         } else {

@@ -39,6 +39,17 @@ inline int fail(int code, const char *fmt, ...)
 // launch per (half) step: from the zero state when it started there, otherwise from the copy of its
 // input state that resumed calls keep (time checkpointing).
 constexpr int kClusterTimedOut = 1;
+// A single-launch time loop gave up (a workgroup was not resident in time, or the slabs of a shot were not placed on
+// one XCD) and the call is re-run with one launch per step: correct, but several times slower on small grids, so it
+// is said once per process on stderr (MIFWI_QUIET=1 silences it) rather than left to be discovered in a profile.
+inline void note_fallback(const char *what)
+{
+    static bool said = false;
+    if (said || getenv("MIFWI_QUIET")) return;
+    said = true;
+    fprintf(stderr, "libmifwi: %s: single-launch time loop gave up (hand-off time-out or XCD placement); "
+                    "falling back to one launch per step for this call\n", what);
+}
 
 // test hook, read per call: MIFWI_TEST_FAKE_TIMEOUT=1 treats every single-launch attempt as timed out before it
 // runs, =2 after it has run (the state has been advanced and must really be restored)

@@ -1522,6 +1522,7 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
         if (rc) return rc;
         rc = snap ? el_cluster_run<true>(pl, c, xbuf, st) : el_cluster_run<false>(pl, c, xbuf, st);
         if (rc != mifwi::kClusterTimedOut) return rc;
+        mifwi::note_fallback("elastic");
         rc = el_cluster_restore(work, pl->fields_elems + psi, backup, flags, st);
         if (rc) return rc;
     }
@@ -1735,6 +1736,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         }
 #endif
         if (err != 0 || mifwi::fake_timeout()) {
+            mifwi::note_fallback("elastic adjoint");
             rc = el_cluster_restore(work, adj_state, backup, flags, st);
             if (rc) return rc;
         } else {
