@@ -21,6 +21,9 @@
 // -ffp-contract=off) so wavefields can be compared bitwise.
 #include "mifwi_common.h"
 
+#include <type_traits>
+#include <vector>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -344,6 +347,17 @@ __global__ void ac_finalize(const float *acc, int ngroups, int n0, int n1, int g
 constexpr int kClThreads = 1024;
 constexpr int kClMaxNG = 4;                  // groups of 4 cells a thread may own
 constexpr unsigned kClMaxSpin = 400000;
+// Ablation builds: wave 0..15 of slab NW/2 of the first shot writes s_memtime at phase boundary k of steps 64..127 to
+// trace[((it - 64) * 16 + wave) * 16 + k]; tools/cluster_trace.py turns them into a per-phase table.
+#ifdef MIFWI_ABLATIONS
+#define CL_STAMP(k)                                                                                        \
+    do {                                                                                                   \
+        if (p.trace && tr_on && it >= 64 && it < 128 && (t & 63) == 0)                                     \
+            p.trace[((it - 64) * 16 + (t >> 6)) * 16 + (k)] = (long long)__builtin_readcyclecounter();     \
+    } while (0)
+#else
+#define CL_STAMP(k) do { } while (0)
+#endif
 // publishes stay in the XCD's L2 (mifwi::same_xcd in mifwi_common.h); -DMIFWI_HANDOFF_AGENT: written through the fabric
 #ifdef MIFWI_HANDOFF_AGENT
 #define CL_PUBLISH_SCOPE __HIP_MEMORY_SCOPE_AGENT
@@ -385,6 +399,9 @@ struct ClParams {
     unsigned long long *xbuf;    // granules [nshot][NW][2 epoch slots][2 sides][2 rows][gp]
     int *err;
     int *xcc_tab;                        // [nshot][NW] XCC_ID + 1 of each slab's workgroup (mifwi::same_xcd)
+#ifdef MIFWI_ABLATIONS
+    long long *trace;                    // phase time stamps of one workgroup (MIFWI_AC_CL_TRACE), see CL_STAMP
+#endif
 };
 
 // Row slabs of a shot.  rt == 0: n0 rows split evenly over NW slabs.  rt > 0 (NW >= 3): the first and
@@ -602,7 +619,6 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     // unpacked from an opaque copy at every use: a hoisted field would take a register of its own again
     auto inj_off = [&]() { return cl_opaque(inj_pack) & 0x3ffff; };
     auto inj_id = [&]() { return (cl_opaque(inj_pack) >> 18) & 0xfff; };
-    auto inj_edge = [&]() { return (inj_pack >> 30) != 0; };
     constexpr bool slow_sparse = SLOW;                   // more points than one per thread: rescan per step
     if (!adj) {
         for (int e = 0; e < p.nsrc; ++e) {
@@ -711,19 +727,6 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     const long long plane = (long long)s * p.n0 * p.gp;
     bool failed = false;
     const bool do_x = p.NW > 1 && !(kDbg(p) & 1);
-    // forward: all four boundary rows live in slot 0 when a row has at most kClThreads/4 groups
-    const bool early_pub = !adj && do_x && 4 * p.ng <= kClThreads;
-    // adjoint: the same, once the receivers that sit IN the boundary rows have been injected (the other
-    // receivers are injected after the interior slots, as before)
-    // (worth 3 % while a hand-off crossed the fabric; with granules that stay in the XCD's L2 the two extra barriers
-    // cost more than the head start gains: C2 adjoint 6.2 -> 5.95 us per step without it.  -DCL_EARLY_ADJ builds it.)
-#ifdef CL_EARLY_ADJ
-    const bool early_adj = adj && do_x && 4 * p.ng <= kClThreads && !slow_sparse;
-#else
-    const bool early_adj = false;
-#endif
-    const bool edge_recv_any = early_adj && __syncthreads_or((inj_pack >= 0 && inj_edge()) ? 1 : 0) != 0;
-
     // software prefetch of the next step's global operands (issued before this step's stores, so
     // that they do not queue behind them): source / adjoint-source amplitude and, in the adjoint,
     // the snapshot values the imaging condition multiplies with
@@ -746,10 +749,14 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         }
     };
     prefetch(0);
+#ifdef MIFWI_ABLATIONS
+    const bool tr_on = w == p.NW / 2 && s == p.shot0;
+#endif
 
     for (int it = 0; it < nsteps; ++it) {
         const int n = adj ? (p.n_first - it) : (p.n_first + it);
         const float amp = amp_next;
+        CL_STAMP(0);
         // ---- sampling of the current field (owner slab writes) -------------------------------
         if (kDbg(p) & 8) {
         } else if (!slow_sparse) {
@@ -786,14 +793,15 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 }
             }
         }
+        CL_STAMP(1);
         // ---- stencil: new field overwrites prv in place (prv is only read at the own cell) --
         float *Gn = (MODE == 1) ? p.G + (long long)(n - p.g_first) * p.g_step + plane : nullptr;
         const unsigned epoch = (unsigned)(it + 1);
         unsigned long long *xmine = xmine0 + (epoch & 1u) * 4 * p.gp;
-        const unsigned long long *xup = xup0 + (epoch & 1u) * 4 * p.gp;
-        const unsigned long long *xdn = xdn0 + (epoch & 1u) * 4 * p.gp;
-#pragma unroll
-        for (int i = 0; i < kClMaxNG; ++i) {
+        // One slot = one 4-cell group of this thread.  Slot 0 holds the groups of the slab's four boundary rows (the
+        // only ones whose stencil reaches the halo rows), slots 1.. the interior.
+        auto update_slot = [&](auto I) {
+            constexpr int i = decltype(I)::value;
             if (i < nown && !(kDbg(p) & 4)) {
                 float un[4], gk[4];
                 float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -834,27 +842,70 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 if (MODE == 1) Gbuf[i] = make_float4(gk[0], gk[1], gk[2], gk[3]);
             }
             __builtin_amdgcn_sched_barrier(0);   // one group at a time: keeps the register peak below 128
-            if ((early_pub || early_adj) && i == 0) {
-                // every boundary row is complete after slot 0 -> publish now, so that the hand-off
-                // travels while the interior (slots 1..) is computed
-                __syncthreads();
-                if (edge_recv_any) {             // workgroup-uniform
-                    if (inj_pack >= 0 && inj_edge()) atomicAdd(&prv[inj_off()], (smp_w * amp) * inj_scale);
-                    __syncthreads();
-                }
+        };
+        // Interior first: it needs no halo, and the boundary rows the neighbours published at the end of the last step
+        // travel meanwhile.  Then the poll, the boundary rows, and the publish of the new boundary rows - whose flight the
+        // interior of the NEXT step hides.  (Round 1 updated and published the boundary rows first and polled at the end
+        // of the step: same overlap, one barrier more; the adjoint, which can only publish after the receivers have
+        // been injected, had no overlap at all.)
+        update_slot(std::integral_constant<int, 1>());
+        update_slot(std::integral_constant<int, 2>());
+        update_slot(std::integral_constant<int, 3>());
+        static_assert(kClMaxNG == 4, "slots 1..3 are spelled out");
+        CL_STAMP(2);
+        // ---- receive the neighbours' boundary rows of the CURRENT field (published as epoch `it`) into the halo rows
+        const unsigned long long *xup_in = xup0 + ((unsigned)it & 1u) * 4 * p.gp;
+        const unsigned long long *xdn_in = xdn0 + ((unsigned)it & 1u) * 4 * p.gp;
+        if (do_x && it > 0) {
+            // sweep: each pass re-reads ALL of this thread's granules back to back (one memory round
+            // trip per pass, not one per granule) until every tag carries the epoch
+            unsigned long long v[kGr];
+            const unsigned long long *src[kGr];
+#pragma unroll
+            for (int kk = 0; kk < kGr; ++kk) {
+                // our top halo = the upper neighbour's "down" rows, our bottom halo = the lower one's "up" rows
+                src[kk] = (((upmask >> kk) & 1u) ? xup_in : xdn_in) + src_idx(kk);
+                v[kk] = 0;
+            }
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
 #pragma unroll
                 for (int kk = 0; kk < kGr; ++kk)
                     if (rcv_lo[kk] >= 0)
-                        __hip_atomic_store(xmine + t + kk * kClThreads,
-                                           ((unsigned long long)epoch << 32) | __float_as_uint(prv[pub_off(kk)]),
-                                           __ATOMIC_RELAXED, CL_PUBLISH_SCOPE);
+                        v[kk] = __hip_atomic_load(src[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int kk = 0; kk < kGr; ++kk)
+                    if (rcv_lo[kk] >= 0) ok = ok && (unsigned)(v[kk] >> 32) == (unsigned)it;
+                if (ok || failed) break;            // once failed: one pass per step, garbage forward until the check
+                if (spins > kClMaxSpin ||
+                    ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    // publish at once: every other workgroup of the launch bails within 256 spins instead of
+                    // running into its own time-out, one hand-off after the other
+                    if (spins > kClMaxSpin) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    failed = true;
+                    break;
+                }
+                mifwi::poll_nap(p.nap);
             }
+#pragma unroll
+            for (int kk = 0; kk < kGr; ++kk)
+                if (rcv_lo[kk] >= 0) cur[rcv_lo[kk]] = __uint_as_float((unsigned)v[kk]);
+            // the sweep has landed, so (vector memory completes in order) nothing this wave issued before it is in
+            // flight: stating vmcnt(0) is free and stops the compiler from guarding the reuse of the sweep registers
+            // with waits that would later stall on the snapshot stores / prefetches issued below
+            __builtin_amdgcn_s_waitcnt(0x0f70);
         }
-        __syncthreads();
+        CL_STAMP(3);
+        __syncthreads();                     // A: halo rows of the current field are in LDS
+        CL_STAMP(4);
+        update_slot(std::integral_constant<int, 0>());
+        CL_STAMP(5);
+        __syncthreads();                     // B: the new field is complete on the own rows; every read of the old one is done
+        CL_STAMP(6);
         if (adj) {
             // ---- adjoint sources: receiver taps of this slab, z^k[cell] += (w g) (r inv) -------
             if (!slow_sparse) {
-                if (inj_pack >= 0 && !(early_adj && inj_edge()))
+                if (inj_pack >= 0)
                     atomicAdd(&prv[inj_off()], (smp_w * amp) * inj_scale);
             } else {
                 const int cnt = p.slab_cnt[s * p.NW + w];
@@ -882,7 +933,8 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 }
             }
         }
-        if (do_x && !early_pub && !early_adj) {
+        CL_STAMP(7);
+        if (do_x) {
 #pragma unroll
             for (int kk = 0; kk < kGr; ++kk)
                 if (rcv_lo[kk] >= 0)
@@ -890,46 +942,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                                        ((unsigned long long)epoch << 32) | __float_as_uint(prv[pub_off(kk)]),
                                        __ATOMIC_RELAXED, CL_PUBLISH_SCOPE);
         }
-        // ---- receive the neighbours' boundary rows of the NEW field into the halo rows -------------
-        if (do_x) {
-            // sweep: each pass re-reads ALL of this thread's granules back to back (one memory round
-            // trip per pass, not one per granule) until every tag carries the epoch
-            unsigned long long v[kGr];
-            const unsigned long long *src[kGr];
-#pragma unroll
-            for (int kk = 0; kk < kGr; ++kk) {
-                // our top halo = the upper neighbour's "down" rows, our bottom halo = the lower one's "up" rows
-                src[kk] = (((upmask >> kk) & 1u) ? xup : xdn) + src_idx(kk);
-                v[kk] = 0;
-            }
-            for (unsigned spins = 0;; ++spins) {
-                bool ok = true;
-#pragma unroll
-                for (int kk = 0; kk < kGr; ++kk)
-                    if (rcv_lo[kk] >= 0)
-                        v[kk] = __hip_atomic_load(src[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int kk = 0; kk < kGr; ++kk)
-                    if (rcv_lo[kk] >= 0) ok = ok && (unsigned)(v[kk] >> 32) == epoch;
-                if (ok || failed) break;            // once failed: one pass per step, garbage forward until the check
-                if (spins > kClMaxSpin ||
-                    ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    // publish at once: every other workgroup of the launch bails within 256 spins instead of
-                    // running into its own time-out, one hand-off after the other
-                    if (spins > kClMaxSpin) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    failed = true;
-                    break;
-                }
-                mifwi::poll_nap(p.nap);
-            }
-#pragma unroll
-            for (int kk = 0; kk < kGr; ++kk)
-                if (rcv_lo[kk] >= 0) prv[rcv_lo[kk]] = __uint_as_float((unsigned)v[kk]);
-            // the sweep has landed, so (vector memory completes in order) nothing this wave issued before it is in
-            // flight: stating vmcnt(0) is free and stops the compiler from guarding the reuse of the sweep registers
-            // with waits that would later stall on the snapshot stores / prefetches issued below
-            __builtin_amdgcn_s_waitcnt(0x0f70);
-        }
+        CL_STAMP(8);
         // global traffic that nobody waits for goes AFTER the hand-off (vector memory operations
         // retire in order: a poll issued behind these would wait for them)
         if (MODE == 1 && !(kDbg(p) & 2)) {
@@ -938,16 +951,18 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 if (i < nown) mifwi::stnt4(Gn + goff_of(cl_opaque(jg[i])), Gbuf[i]);
         }
         prefetch(it + 1);
+        CL_STAMP(9);
         // a timed-out thread carries garbage forward until the next collective check (fatal anyway)
+        // No barrier at the end of a step: the next step reads the field just written (complete since B, injected since
+        // the barrier behind the injection) and writes the buffer whose last readers finished before B.
         if ((it & 31) == 31 || it == nsteps - 1) {
             if (__syncthreads_or(failed ? 1 : 0)) {
                 if (t == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 failed = true;
                 break;
             }
-        } else {
-            __syncthreads();
         }
+        CL_STAMP(10);
         float *tmp = cur; cur = prv; prv = tmp;
     }
 
@@ -1113,6 +1128,15 @@ int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStrea
 {
     if (mifwi::fake_timeout() == 1) return mifwi::kClusterTimedOut;
     MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
+#ifdef MIFWI_ABLATIONS
+    // MIFWI_AC_CL_TRACE=<file>: phase time stamps (CL_STAMP) of one workgroup, steps 64..127, appended as text
+    const char *trace_path = getenv("MIFWI_AC_CL_TRACE");
+    const size_t trace_n = 64 * 16 * 16;
+    if (trace_path && *trace_path) {
+        MIFWI_HIP_TRY(hipMalloc(&c.trace, trace_n * sizeof(long long)));
+        MIFWI_HIP_TRY(hipMemsetAsync(c.trace, 0, trace_n * sizeof(long long), st));
+    }
+#endif
     for (int s0 = 0; s0 < pl->d.nshot; s0 += pl->cl_shots) {
         c.shot0 = s0;
         c.shot1 = std::min(pl->d.nshot, s0 + pl->cl_shots);
@@ -1129,6 +1153,21 @@ int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStrea
     int err = 0;
     MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
     MIFWI_HIP_TRY(hipStreamSynchronize(st));
+#ifdef MIFWI_ABLATIONS
+    if (c.trace) {
+        std::vector<long long> h(trace_n);
+        MIFWI_HIP_TRY(hipMemcpy(h.data(), c.trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost));
+        MIFWI_HIP_TRY(hipFree(c.trace));
+        if (FILE *fp = fopen(trace_path, "a")) {
+            fprintf(fp, "# ac_cluster mode=%d waves=16\n", MODE);
+            for (size_t i = 0; i < trace_n; i += 16) {
+                for (int k = 0; k < 16; ++k) fprintf(fp, "%lld ", h[i + k]);
+                fprintf(fp, "\n");
+            }
+            fclose(fp);
+        }
+    }
+#endif
     return (err != 0 || mifwi::fake_timeout() == 2) ? mifwi::kClusterTimedOut : MIFWI_OK;
 }
 
