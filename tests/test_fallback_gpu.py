@@ -158,3 +158,21 @@ def test_a_workgroup_that_never_shows_up_times_out_on_the_device_and_the_call_fa
     assert np.abs(ref["rec"]).max() > 0 and np.array_equal(ref["rec"], abl["rec"])
     assert np.array_equal(ref["vx"], abl["vx"]) and np.array_equal(ref["vz"], abl["vz"])
     assert rel_l2(abl["gr"], ref["gr"]) <= 2e-5 and rel_l2(abl["gm"], ref["gm"]) <= 2e-5
+
+
+def test_a_healthy_run_stays_on_the_single_launch_kernels(tmp_path):
+    """The fall-back is silent in its results by design, so a regression that made every launch bail out (say, a
+    placement check that never passes on this GPU) would only show as lost speed.  The library says so once per process
+    on stderr: a plain run of both physics must not."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD % {"tests": os.path.join(root, "tests"), "root": root})
+    env = {k: v for k, v in os.environ.items() if k not in ("MIFWI_QUIET", "MIFWI_LIB", "MIFWI_TEST_FAKE_TIMEOUT")}
+    res = subprocess.run([sys.executable, str(script), str(tmp_path / "ok.npz")], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "falling back" not in res.stderr, res.stderr[-2000:]
+    # and the note does appear when a launch is made to give up
+    res = subprocess.run([sys.executable, str(script), str(tmp_path / "fb.npz")],
+                         env=dict(env, MIFWI_TEST_FAKE_TIMEOUT="1"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "falling back" in res.stderr
