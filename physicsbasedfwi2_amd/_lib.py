@@ -130,3 +130,12 @@ def check(rc):
 def ptr(t):
     """Device pointer of a torch tensor (None -> NULL)."""
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def free_device_bytes(dev):
+    """Memory a new tensor could get on `dev`: what the driver reports free plus what torch's caching allocator holds
+    without using it (the snapshot tensor of the previous call, freed a moment ago, sits there - counting only the
+    driver's figure made every second gradient pass plan for a fraction of the device)."""
+    import torch
+    free = torch.cuda.mem_get_info(dev)[0]
+    return int(free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))

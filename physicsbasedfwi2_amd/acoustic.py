@@ -124,7 +124,7 @@ class _AcousticFn(torch.autograd.Function):
             if need_grad:
                 # never plan for more than most of the memory that is free right now (other tensors of
                 # the training loop share the device); segmentation does not change the results
-                snapshot_budget = min(snapshot_budget, int(0.8 * torch.cuda.mem_get_info(dev)[0]))
+                snapshot_budget = min(snapshot_budget, int(0.8 * _lib.free_device_bytes(dev)))
                 if nt * step_bytes > snapshot_budget:
                     seg = max(1, int(snapshot_budget // (2 * step_bytes)))
                 if seg >= nt:

@@ -168,7 +168,7 @@ class _ElasticFn(torch.autograd.Function):
             if need_grad:
                 # never plan for more than most of the memory that is free right now (other tensors of
                 # the training loop share the device); segmentation does not change the results
-                snapshot_budget = min(snapshot_budget, int(0.8 * torch.cuda.mem_get_info(dev)[0]))
+                snapshot_budget = min(snapshot_budget, int(0.8 * _lib.free_device_bytes(dev)))
                 if nt * step_bytes > snapshot_budget:
                     seg = max(1, int(snapshot_budget // (2 * step_bytes)))
                 if seg >= nt:
@@ -296,6 +296,59 @@ def propagate(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width,
 
 
 SOURCE_TYPES = {"explosive": 0, "fx": 1, "fz": 2, 0: 0, 1: 1, 2: 2}
+
+
+def resident_shot_chunk(nshot, nt, nz, nx, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET, snapshot_format=None, device=None):
+    """How many shots at a time keep the snapshots of ALL `nt` steps inside the budget (and inside 80 % of the memory
+    that is free right now): ``nshot`` when everything fits, 0 when not even one shot does.
+
+    :func:`propagate` cuts the time axis into checkpointed segments when the snapshots of a call do not fit, which
+    costs one extra forward sweep.  When the misfit is known before the backward pass starts (observed data in hand,
+    as in DENISE's ``grad`` or seisgan's ``FWILoss``) the cheaper cut is across SHOTS: they are independent, so a few at
+    a time run forward with resident snapshots and straight into their adjoint, gradients adding up
+    (:func:`gradient_in_shot_chunks`) - no recomputation at all."""
+    per_shot = nt * nz * (4 * ((nx + 3) // 4)) * snapshot_bytes_per_cell(snapshot_format)
+    budget = int(snapshot_budget)
+    if device is not None and torch.cuda.is_available():
+        budget = min(budget, int(0.8 * _lib.free_device_bytes(device)))
+    return int(min(nshot, budget // max(per_shot, 1)))
+
+
+def gradient_in_shot_chunks(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width, loss_fn, chunk, **kw):
+    """Loss and its gradient with the shots taken ``chunk`` at a time (see :func:`resident_shot_chunk`).
+
+    ``loss_fn(rec_vx, rec_vz, shots)`` -> scalar loss of the shots in the slice ``shots`` (the total loss is their
+    sum).  d loss / d mat is accumulated into ``mat.grad`` (``mat`` may be a non-leaf: the chain rule runs once, after
+    the last chunk), d loss / d f into ``f.grad`` when ``f`` requires it.  Returns the detached total loss.  Other
+    keyword arguments go to :func:`propagate`."""
+    ns = f.shape[1]
+    chunk = max(1, min(int(chunk), ns))
+    leaf = mat.detach().requires_grad_(mat.requires_grad)
+    total = None
+    fgrad = torch.zeros_like(f) if f.requires_grad else None
+    last = None
+    for a in range(0, ns, chunk):
+        sl = slice(a, min(a + chunk, ns))
+        if last is not None and sl.stop - sl.start != last:
+            torch.cuda.empty_cache()         # a different snapshot size: hand the cached block back instead of splitting it
+        last = sl.stop - sl.start
+        fc = f[:, sl].detach().requires_grad_(f.requires_grad)
+        out = propagate(leaf, fc, pz, px, src_cell[sl], src_w[sl], rec_cell[sl], rec_w[sl], pml_width, **kw)
+        loss = loss_fn(out[0], out[1], sl)
+        loss.backward()
+        total = loss.detach() if total is None else total + loss.detach()
+        if fgrad is not None:
+            fgrad[:, sl] = fc.grad
+    if ns % chunk:
+        torch.cuda.empty_cache()
+    if mat.requires_grad:
+        if mat.is_leaf:
+            mat.grad = leaf.grad if mat.grad is None else mat.grad + leaf.grad
+        else:
+            mat.backward(leaf.grad)
+    if fgrad is not None:
+        f.grad = fgrad if f.grad is None else f.grad + fgrad
+    return total
 
 
 def force_amplitude(wavelet, mat, src_cell, src_w, h, source_type):

@@ -355,3 +355,39 @@ def test_second_order_stencils(oracle32, monkeypatch, env):
                                        case["rc"], case["rw"], free_surface=1)
     _, _, rvx, _ = _run_hip(case, fd_order=2)
     assert rel_l2(rvx.detach().cpu().numpy(), ovx4) > 1e-3
+
+
+def test_gradient_in_shot_chunks_equals_the_all_shots_gradient():
+    """Shots are independent: taking them two at a time (each chunk forward with resident snapshots, straight into its
+    adjoint) gives the loss and the material / wavelet gradients of the all-shots call - the cut that replaces time
+    checkpointing when the misfit is known up front (elastic.gradient_in_shot_chunks)."""
+    from physicsbasedfwi2_amd import elastic, misfit
+    case = elastic_case(seed=97, nz=60, nx=150, fw=10, ns=5, nrec=40, nt=90)
+    dev = "cuda:0"
+    t = lambda n: torch.tensor(case[n])
+    obs = [torch.randn(90, 5, 40, device=dev) * 1e-3 for _ in range(2)]
+
+    def loss_fn(rvx, rvz, sl):
+        return misfit.l2_half(rvx, obs[0][:, sl].contiguous()) + misfit.l2_half(rvz, obs[1][:, sl].contiguous())
+
+    def run(chunk):
+        mat = torch.tensor(case["mat"], dtype=torch.float32, device=dev, requires_grad=True)
+        f = torch.tensor(case["f"], dtype=torch.float32, device=dev, requires_grad=True)
+        args = (t("pz"), t("px"), t("sc"), t("sw"), t("rc"), t("rw"), case["fw"])
+        if chunk:
+            loss = elastic.gradient_in_shot_chunks(mat, f, *args, loss_fn, chunk)
+        else:
+            rvx, rvz = elastic.propagate(mat, f, *args)
+            loss = loss_fn(rvx, rvz, slice(0, 5))
+            loss.backward()
+            loss = loss.detach()
+        return float(loss), mat.grad.cpu().numpy(), f.grad.cpu().numpy()
+
+    l0, gm0, gf0 = run(0)
+    assert l0 > 0 and np.abs(gm0).max() > 0 and np.abs(gf0).max() > 0
+    for chunk in (2, 5, 1):
+        l1, gm1, gf1 = run(chunk)
+        assert abs(l1 - l0) <= 1e-6 * l0
+        assert rel_l2(gm1, gm0) <= 2e-6 and rel_l2(gf1, gf0) <= 2e-6
+    assert elastic.resident_shot_chunk(32, 3000, 350, 1700) == 2        # 35.7 GB of f32 planes per shot, 96 GB budget
+    assert elastic.resident_shot_chunk(32, 3000, 100, 300) == 32 and elastic.resident_shot_chunk(16, 5000, 1000, 3000) == 0
