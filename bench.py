@@ -446,28 +446,40 @@ class ElasticMarmousi:
             return None
         return int(max(20, min(200, 0.25 * self.elastic.DEFAULT_SNAPSHOT_BUDGET // per_step)))
 
-    def _slabs(self):
+    def _plan_facts(self):
+        """(slabs forward, slabs adjoint, kernel_flags) of the plan a call of this workload creates - for the chunk size
+        when the shots are taken in chunks."""
         from physicsbasedfwi2_amd.elastic import ElasticPlan
-        pl = ElasticPlan(self.nz, self.nx, self.nt, self.ns, 1, self.nrec, 1, self.pml, self.dev.index or 0,
+        ns = self.shot_chunk() or self.ns
+        pl = ElasticPlan(self.nz, self.nx, self.nt, ns, 1, self.nrec, 1, self.pml, self.dev.index or 0,
                          0, int(self.free_surface))
-        out = pl.cluster_slabs(False), pl.cluster_slabs(True)
+        out = pl.cluster_slabs(False), pl.cluster_slabs(True), int(pl.layout.kernel_flags)
         pl.close()
         return out
 
     def resident(self):
-        f, a = self._slabs()
+        f, a, _ = self._plan_facts()
         return bool(f), bool(a)
 
     def kernel_family(self):
+        f, a, flags = self._plan_facts()
+        names = self.elastic.kernel_family(flags)
         return "forward: %s; adjoint: %s" % tuple(
-            "single-launch time loop, %d row slabs per shot" % n if n else self.elastic.per_step_family()
-            for n in self._slabs())
+            "%s, %d row slabs per shot" % (nm, n) if n else nm for nm, n in zip(names, (f, a)))
 
     def other_family_env(self):
-        f, a = self._slabs()
+        f, a, flags = self._plan_facts()
         if f or a:
             return {"MIFWI_EL_CLUSTER": "0", "MIFWI_EL_CLUSTER_ADJ": "0"}, "one launch per half step"
-        return self.elastic.other_per_step_env()
+        return self.elastic.other_per_step_env(flags)
+
+    def this_family_env(self):
+        """Environment that makes a ONE-shot run (the cross-check) use the formulation the timed run used: the default
+        of the per-step forward depends on the size of a launch."""
+        f, a, flags = self._plan_facts()
+        if f or a:
+            return {}
+        return {"MIFWI_EL_FUSED": "1" if flags & 4 else "0"}
 
     def kernel_times(self):
         """avg duration (s) of one forward step and one adjoint step of the time loops."""
@@ -587,7 +599,8 @@ def cross_check(wl, name, dev, kw):
         return {"verified": None, "note": "this plan has one kernel family only"}
     nt = min(wl.nt, 400) if wl.resident_nt() else wl.nt
     outs = []
-    for e in ({}, env):
+    this = wl.this_family_env() if hasattr(wl, "this_family_env") else {}
+    for e in (this, env):
         with _env(**e):
             one = WORKLOADS[name](dev, 0, 1, nt=nt, shots=1, **kw)
             grad, _ = one.step(False)

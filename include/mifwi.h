@@ -194,8 +194,13 @@ typedef struct {
     int64_t work_backward_elems;
     int64_t snap_step_elems;      /* floats one time step of the snapshot buffer takes (all shots)  */
     int32_t snapshot_format;      /* the format this plan writes and reads                          */
-    int32_t reserved0;
+    int32_t kernel_flags;         /* MIFWI_EL_KERNEL_*: which formulation of the time loops the plan picked   */
 } mifwi_elastic_layout;
+
+/* kernel_flags: forward / adjoint as ONE launch for the whole time loop (LDS-resident slabs), or - on grids that do not
+   fit - V+S (S^T+V^T) fused into one launch per step; neither bit = one launch per half step */
+enum { MIFWI_EL_KERNEL_FWD_SINGLE_LAUNCH = 1, MIFWI_EL_KERNEL_ADJ_SINGLE_LAUNCH = 2, MIFWI_EL_KERNEL_FWD_FUSED_STEP = 4,
+       MIFWI_EL_KERNEL_ADJ_FUSED_STEP = 8 };
 
 typedef struct mifwi_elastic_plan mifwi_elastic_plan;
 

@@ -48,9 +48,10 @@ class ElasticLayout(ctypes.Structure):
                 ("shots_per_group", ctypes.c_int32), ("coef_elems", ctypes.c_int64),
                 ("state_elems", ctypes.c_int64), ("work_forward_elems", ctypes.c_int64),
                 ("work_backward_elems", ctypes.c_int64), ("snap_step_elems", ctypes.c_int64),
-                ("snapshot_format", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("snapshot_format", ctypes.c_int32), ("kernel_flags", ctypes.c_int32)]
 
 
+EL_KERNEL_FWD_SINGLE_LAUNCH, EL_KERNEL_ADJ_SINGLE_LAUNCH, EL_KERNEL_FWD_FUSED_STEP, EL_KERNEL_ADJ_FUSED_STEP = 1, 2, 4, 8
 SNAPSHOT_F32, SNAPSHOT_BF16 = 0, 1
 _P = ctypes.c_void_p
 

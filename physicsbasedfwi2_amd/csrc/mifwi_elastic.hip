@@ -1398,9 +1398,11 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
         pl->pass_groups = std::min(pl->ngroups, std::max(1, k));
     }
     // V+S in one launch pays where the time loop has to be cut into Infinity-Cache-sized passes anyway (measured,
-    // 1000x3000 x 16 shots: 622 -> 558 us per step, 516 with bf16 planes; 350x1700 x 32: 232 -> 232, 214 -> 209)
+    // 1000x3000 x 16 shots: 622 -> 558 us per step, 516 with bf16 planes; 350x1700 x 32: 232 -> 232, 214 -> 209) and
+    // on any launch of a million cells or more (350x1700 x 4 shots, the chunks of a shot-chunked gradient pass:
+    // 286 -> 260 us per step of all 32 shots)
     pl->fused = !pl->cluster && d->source_type == 0 && !d->record_pressure &&
-                env_int("MIFWI_EL_FUSED", pl->pass_shots < d->nshot ? 1 : 0) != 0;
+                env_int("MIFWI_EL_FUSED", (pl->pass_shots < d->nshot || (double)d->nz * d->nx * d->nshot >= 1e6) ? 1 : 0) != 0;
     {
         const double cells = (double)pl->coef_elems, mats = 4.0 * 5.0 * cells;
         const double fstate = 4.0 * (double)pl->shot_stride + 4.0 * (double)(pl->psix_elems + pl->psiz_elems) / d->nshot;
@@ -1455,6 +1457,8 @@ int mifwi_elastic_plan_layout(const mifwi_elastic_plan *pl, mifwi_elastic_layout
     out->coef_elems = pl->coef_elems;
     out->snap_step_elems = pl->snap_shot * pl->d.nshot;
     out->snapshot_format = pl->snap_bf16 ? MIFWI_SNAPSHOT_BF16 : MIFWI_SNAPSHOT_F32;
+    out->kernel_flags = (pl->cluster ? MIFWI_EL_KERNEL_FWD_SINGLE_LAUNCH : 0) | (pl->cl_adj ? MIFWI_EL_KERNEL_ADJ_SINGLE_LAUNCH : 0) |
+                        (pl->fused ? MIFWI_EL_KERNEL_FWD_FUSED_STEP : 0) | (pl->fused_adj ? MIFWI_EL_KERNEL_ADJ_FUSED_STEP : 0);
     const long long psi = pl->psi_elems;
     const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
     out->state_elems = pl->fields_elems + psi;

@@ -35,18 +35,19 @@ def snapshot_bytes_per_cell(fmt=None):
     return 10.0 if (fmt or snapshot_mode()) == "bf16" else 20.0
 
 
-def per_step_family():
-    """Name of the per-step (large-grid) kernel family the plan picks when a shot does not fit the LDS."""
-    import os
-    return ("one fused V+S launch per step (forward)" if os.environ.get("MIFWI_EL_FUSED", "0") == "1"
-            else "one launch per half step")
+def kernel_family(flags):
+    """(forward, adjoint) description of the formulation a plan picked (``plan.layout.kernel_flags``)."""
+    fwd = ("single-launch time loop" if flags & _lib.EL_KERNEL_FWD_SINGLE_LAUNCH else
+           "one fused V+S launch per step" if flags & _lib.EL_KERNEL_FWD_FUSED_STEP else "one launch per half step")
+    adj = ("single-launch time loop" if flags & _lib.EL_KERNEL_ADJ_SINGLE_LAUNCH else
+           "one fused S^T+V^T launch per step" if flags & _lib.EL_KERNEL_ADJ_FUSED_STEP else "one launch per half step")
+    return fwd, adj
 
 
-def other_per_step_env():
-    """(environment, label) selecting the other formulation of the per-step family: bench.py's in-run
+def other_per_step_env(flags=0):
+    """(environment, label) selecting the other formulation of the per-step forward: bench.py's in-run
     cross-check runs one shot through both."""
-    import os
-    if os.environ.get("MIFWI_EL_FUSED", "0") == "1":
+    if flags & _lib.EL_KERNEL_FWD_FUSED_STEP:
         return {"MIFWI_EL_FUSED": "0"}, "one launch per half step"
     return {"MIFWI_EL_FUSED": "1"}, "fused V+S forward launch"
 
