@@ -75,6 +75,7 @@ struct ElParams {
     const float *inj_w;
     const float *inj_amp0, *inj_amp1;     // [nshot][ninj] of this step (amp1 only in S^T)
     const int *inj_bbox;
+    const int *tile_start, *tile_list;   // el_adj_s: receiver taps of each (shot, tile): [nshot][ntiles + 1], [nshot][ninj * ntap_inj]
     // sampling (S launch: vx, vz ; S^T launch: sxx+szz)
     int nsmp, ntap_smp;
     const int *smp_cell;
@@ -628,9 +629,45 @@ __device__ __forceinline__ void stage_E(const ElParams &p, int s, int j, int g, 
     E3 = make_float4(e3[0], e3[1], e3[2], e3[3]); E4 = make_float4(e4[0], e4[1], e4[2], e4[3]);
 }
 
+// Receiver taps (adjoint sources) of every tile of el_adj_s, one block per shot: start[s][tile .. tile+1) indexes
+// list[s][], which holds tap numbers (receiver * ntap + tap) sorted by tile, ascending inside a tile.  Built once
+// per backward call; the time loop then injects v_bar += R^T g inside el_adj_s, by the tile that owns the cells
+// (workgroup-uniform branch, taken by the few tiles that hold receivers), instead of a launch of its own per step
+// and shot pass (4.7 us each: 5 % of a step where the passes are small, e.g. the chunks of a shot-chunked gradient).
+__global__ void el_build_tile_taps(const int *cell, int ntaps, int nx, int tx, int ntiles, int *start, int *cursor,
+                                   int *list)
+{
+    const int s = (int)blockIdx.x, t = (int)threadIdx.x, T = (int)blockDim.x;
+    start += (long long)s * (ntiles + 1); cursor += (long long)s * ntiles; list += (long long)s * ntaps;
+    cell += (long long)s * ntaps;
+    for (int k = t; k < ntiles; k += T) cursor[k] = 0;
+    __syncthreads();
+    auto tile_of = [&](int c) { const int j = c / nx, i = c - j * nx; return (j / ATZ) * tx + (i >> 2) / AGO; };
+    for (int e = t; e < ntaps; e += T)
+        if (cell[e] >= 0) atomicAdd(cursor + tile_of(cell[e]), 1);
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < ntiles; ++k) { start[k] = run; run += cursor[k]; cursor[k] = start[k]; }
+        start[ntiles] = run;
+    }
+    __syncthreads();
+    for (int e = t; e < ntaps; e += T)
+        if (cell[e] >= 0) list[atomicAdd(cursor + tile_of(cell[e]), 1)] = e;
+    __syncthreads();
+    for (int k = t; k < ntiles; k += T)                   // ascending tap order inside a tile (a few entries each)
+        for (int a = start[k] + 1; a < start[k + 1]; ++a) {
+            const int v = list[a];
+            int b = a - 1;
+            while (b >= start[k] && list[b] > v) { list[b + 1] = list[b]; --b; }
+            list[b + 1] = v;
+        }
+}
+
 // S^T:  E = C^T sigma_bar through the transposed C-PML;  v_bar -= stencils(E);  all five material-gradient
-//       accumulators.  (v_bar += R^T g has been applied to the state by el_inject_adjsrc, as the oracle does at
-//       the head of an adjoint step.)
+//       accumulators.  The adjoint sources of the tile's cells (v_bar += R^T g, which the oracle applies at the head
+//       of an adjoint step) are added to the loaded v_bar first, through the E planes while they are still empty
+//       (p.tile_start set), or have been applied to the state by el_inject_adjsrc.
 // Every global load of a shot (own group, halo group, adjoint velocities, the five snapshot planes) is
 // requested before the first use: one memory round trip per shot instead of three.
 template <bool BF16>
@@ -691,6 +728,31 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
             halo.a = ld4(fl + F_SXX * fs + ho); halo.b = ld4(fl + F_SZZ * fs + ho); halo.c = ld4(fl + F_SXZ * fs + ho);
         }
         if (own_ok) { vxb = ld4(fl + F_VX * fs + oo); vzb = ld4(fl + F_VZ * fs + oo); }
+        // ---- adjoint sources of this tile (workgroup-uniform branch; E[0], E[1] are free until the staging) -----
+        if (p.tile_start != nullptr) {
+            const int ntiles = (int)gridDim.x * p.tiles_z, per = p.ninj * p.ntap_inj;
+            const int *ts = p.tile_start + (long long)s * (ntiles + 1) + by * (int)gridDim.x + bx;
+            const int e0 = ts[0], e1 = ts[1];
+            if (e1 > e0) {
+                const int x = 4 * (ogrp + 1);
+                st4(&E[0][orow + 2][x], zero4); st4(&E[1][orow + 2][x], zero4);
+                __syncthreads();
+                for (int e = e0 + t; e < e1; e += kThreads) {
+                    const int tap = p.tile_list[(long long)s * per + e];
+                    const int cell = p.inj_cell[(long long)s * per + tap];
+                    const int j = cell / p.nx, i = cell - j * p.nx;
+                    const float w = p.inj_w[(long long)s * per + tap];
+                    const long long ai = (long long)s * p.ninj + tap / p.ntap_inj;
+                    atomicAdd(&E[0][j - tile_j + 2][i - 4 * tile_g + 4], w * p.inj_amp0[ai]);
+                    atomicAdd(&E[1][j - tile_j + 2][i - 4 * tile_g + 4], w * p.inj_amp1[ai]);
+                }
+                __syncthreads();
+                const float4 ix = ld4(&E[0][orow + 2][x]), iz = ld4(&E[1][orow + 2][x]);
+                vxb = make_float4(vxb.x + ix.x, vxb.y + ix.y, vxb.z + ix.z, vxb.w + ix.w);
+                vzb = make_float4(vzb.x + iz.x, vzb.y + iz.y, vzb.z + iz.z, vzb.w + iz.w);
+                __syncthreads();
+            }
+        }
         // ---- stage E1..E4 on the tile + halo -------------------------------------------------
         if (p.fsurf && oj == 0) own.b = zero4;            // adjoint of szz(0,.) is discarded
         if (p.fsurf && hj == 0) halo.b = zero4;
@@ -1083,6 +1145,7 @@ struct mifwi_elastic_plan {
     // adjoint cluster kernel (its own slab count: different LDS footprint)
     int cl_adj, adj_NW, adj_shots, adj_lds, adj_ng, adj_zrows;
     long long xbuf_elems, list_elems, xcc_elems;
+    long long tile_elems;                  // per-tile receiver lists of el_adj_s (ints, in floats)
 };
 
 namespace {
@@ -1139,6 +1202,10 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
 {
     pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0; pl->xbuf_elems = 0; pl->xcc_elems = 0;
     pl->cl_adj = 0; pl->adj_NW = 0; pl->adj_shots = 0; pl->adj_lds = 0; pl->adj_ng = 0; pl->adj_zrows = 0; pl->list_elems = 0;
+    {   // el_build_tile_taps: start [nshot][ntiles + 1], cursor [nshot][ntiles], list [nshot][nrec * ntap]
+        const long long ntiles = (long long)mifwi::ceil_div(pl->ng, AGO) * mifwi::ceil_div(pl->d.nz, ATZ);
+        pl->tile_elems = mifwi::round_up64(pl->d.nshot * (2 * ntiles + 1 + (long long)pl->d.nrec * pl->d.ntap), 64);
+    }
     if (pl->d.ntap != 1 || pl->d.source_type != 0 || pl->d.record_pressure) return;   // per-step kernels only
     const bool want_fwd = env_int("MIFWI_EL_CLUSTER", 1) != 0;
     int ncu = 0;
@@ -1467,7 +1534,7 @@ int mifwi_elastic_plan_layout(const mifwi_elastic_plan *pl, mifwi_elastic_layout
                               (pl->fused ? out->state_elems : 0);
     const long long adj_state = pl->fields_elems + 2 * psi + 5LL * pl->ngroups * pl->coef_elems;
     out->work_backward_elems = adj_state + bbox + (pl->cl_adj ? pl->xbuf_elems + pl->list_elems + adj_state : 0) +
-                               (pl->fused_adj ? pl->fields_elems : 0);
+                               (pl->fused_adj ? pl->fields_elems : 0) + pl->tile_elems;
     return MIFWI_OK;
 }
 
@@ -1669,6 +1736,19 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
     const bool want_f = grad_f != nullptr && d.nsrc > 0;
     ps.nsmp = want_f ? d.nsrc : 0; ps.ntap_smp = d.ntap; ps.smp_cell = src_cell; ps.smp_w = src_w;
     const long long snap_step = pl->snap_shot * d.nshot;
+    // per-tile receiver lists of el_adj_s, at the tail of the work buffer (mifwi_elastic_plan_layout)
+    int *tile_start = nullptr, *tile_list = nullptr;
+    const int tiles_x = mifwi::ceil_div(pl->ng, AGO), ntiles = tiles_x * mifwi::ceil_div(d.nz, ATZ);
+    auto build_tile_lists = [&]() {
+        mifwi_elastic_layout lay;
+        mifwi_elastic_plan_layout(pl, &lay);
+        int *base = reinterpret_cast<int *>(work + lay.work_backward_elems - pl->tile_elems);
+        tile_start = base;
+        int *cursor = base + (long long)d.nshot * (ntiles + 1);
+        tile_list = cursor + (long long)d.nshot * ntiles;
+        hipLaunchKernelGGL(el_build_tile_taps, dim3(d.nshot), dim3(256), 0, st, rec_cell, d.nrec * d.ntap, d.nx, tiles_x,
+                           ntiles, tile_start, cursor, tile_list);
+    };
     bool per_step = true;
     if (pl->cl_adj && n_hi >= n_lo) {
         float *xbuf = reinterpret_cast<float *>(bbox) + mifwi::round_up64(4LL * d.nshot, 64);
@@ -1747,6 +1827,13 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
             per_step = false;
         }
     }
+    // the two-launch form adds the adjoint sources inside el_adj_s (per-tile lists); the fused launch keeps the pre-pass
+    const bool inj_in_tile = per_step && !pl->fused_adj && d.nrec > 0 && n_hi >= n_lo &&
+                             env_int("MIFWI_EL_INJ_PREPASS", 0) == 0;
+    if (inj_in_tile) {
+        build_tile_lists();
+        ps.tile_start = tile_start; ps.tile_list = tile_list;
+    }
     // shot groups are independent: a few at a time keep fields, accumulators and materials in the Infinity Cache
     for (int g0 = 0; per_step && g0 < pl->ngroups; g0 += pl->pass_groups)
     for (int n = n_hi; n >= n_lo; --n) {
@@ -1769,7 +1856,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
             ps.fields = par ? fieldsB : fields;
             ps.fields_out = par ? fields : fieldsB;
         }
-        if (d.nrec > 0) {
+        if (d.nrec > 0 && !inj_in_tile) {
             ElParams pq = ps;
             pq.gs = cs;
             hipLaunchKernelGGL(el_inject_adjsrc, dim3(mifwi::ceil_div(cs * d.nrec * d.ntap, 64)), dim3(64), 0, st, pq);
