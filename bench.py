@@ -369,10 +369,8 @@ class ElasticMarmousi:
         k = self.elastic.resident_shot_chunk(self.ns, self.nt, self.nz, self.nx, snapshot_budget=1 << 60, device=self.dev)
         if os.environ.get("MIFWI_BENCH_CHUNK"):
             k = int(os.environ["MIFWI_BENCH_CHUNK"])
-        # equal chunks only (the largest divisor of the shot count that fits): the snapshot tensor of one chunk is then
-        # the cached block of the previous one; an odd last chunk splits that block and the next full-size request
-        # has to be malloc'ed again (measured: 4x on the forward sweep of 350x1700 with chunks of 6,6,6,6,6,2)
-        k = max([c for c in range(1, max(k, 1) + 1) if self.ns % c == 0] or [0]) if 1 <= k < self.ns else 0
+        # as few chunks as fit, of (nearly) equal size; they share one snapshot tensor (elastic.snapshot_arena)
+        k = -(-self.ns // -(-self.ns // k)) if 1 <= k < self.ns else 0
         self._chunk = k if k >= 2 else 0
         return self._chunk
 
@@ -389,12 +387,13 @@ class ElasticMarmousi:
         # per-chunk events around the forward and the adjoint time loops (the autograd hooks of propagate)
         leaf = mat.detach().requires_grad_(True)
         total = None
-        last = None
+        # the chunks - of this pass and of the next ones - share the snapshot tensor of the first (largest) one: freed and
+        # re-requested per pass, torch's allocator splits the cached 200 GB block for smaller requests in between
+        if getattr(self, "_arena", None) is None:
+            self._arena = self.elastic.snapshot_arena()
+        self._arena.__enter__()
         for a in range(0, self.ns, chunk):
             sl = slice(a, min(a + chunk, self.ns))
-            if last is not None and sl.stop - sl.start != last:
-                torch.cuda.empty_cache()     # a different snapshot size: hand the cached block back instead of splitting it
-            last = sl.stop - sl.start
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
             rvx, rvz = self.elastic.propagate(leaf, self.f[:, sl], self.pz, self.px, self.sc[sl], self.sw[sl], self.rc[sl],
@@ -408,9 +407,8 @@ class ElasticMarmousi:
             ev[3].record()
             t_f.append((ev[0], ev[1])); t_b.append((ev[2], ev[3]))
             total = loss.detach() if total is None else total + loss.detach()
+        self.elastic.snapshot_arena.current = None      # leave the arena, keep its tensor
         mat.backward(leaf.grad)
-        if self.ns % chunk:
-            torch.cuda.empty_cache()
         if timed:
             self._ev_chunks.append((t_f, t_b))
         self.last_rec = torch.cat(recs, dim=2)

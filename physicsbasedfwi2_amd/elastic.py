@@ -125,6 +125,31 @@ class ElasticPlan:
             pass
 
 
+class _SnapshotArena:
+    """One snapshot tensor shared by consecutive propagate() calls (gradient_in_shot_chunks): the first call allocates
+    it, later ones whose snapshots are not larger take a prefix - no call pays a malloc of >100 GB again, and chunks need
+    not be of equal size to hit torch's cached block."""
+    current = None
+
+    def __init__(self):
+        self.buf = None
+
+    def __enter__(self):
+        self._prev, _SnapshotArena.current = _SnapshotArena.current, self      # re-entering keeps the tensor
+        return self
+
+    def __exit__(self, *exc):
+        _SnapshotArena.current = self._prev
+        self.buf = None
+        return False
+
+    def take(self, nt, elems, dev):
+        need = nt * elems
+        if self.buf is None or self.buf.device != dev or self.buf.numel() < need:
+            return None
+        return self.buf[:need].view(nt, elems)
+
+
 class _ElasticFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mat, f, pz, px, geom, pml_width, shots_per_group, snapshot_budget, free_surface,
@@ -166,7 +191,10 @@ class _ElasticFn(torch.autograd.Function):
             need_grad = mat.requires_grad or f.requires_grad
             step_bytes = 4 * lay.snap_step_elems
             seg, snap, ckpt = nt, None, None
-            if need_grad:
+            arena = _SnapshotArena.current
+            if need_grad and arena is not None:
+                snap = arena.take(nt, lay.snap_step_elems, dev)       # memory already held: no budget question
+            if need_grad and snap is None:
                 # never plan for more than most of the memory that is free right now (other tensors of
                 # the training loop share the device); segmentation does not change the results
                 snapshot_budget = min(snapshot_budget, int(0.8 * _lib.free_device_bytes(dev)))
@@ -175,6 +203,8 @@ class _ElasticFn(torch.autograd.Function):
                 if seg >= nt:
                     seg = nt
                     snap = torch.empty((nt, lay.snap_step_elems), device=dev, dtype=torch.float32)
+                    if arena is not None and arena.buf is None:
+                        arena.buf = snap.view(-1)
             args = (plan.handle, _lib.ptr(mat_p), _lib.ptr(pz_d), _lib.ptr(px_p), _lib.ptr(f_d),
                     _lib.ptr(geom.src_cell), _lib.ptr(geom.src_w), _lib.ptr(geom.rec_cell),
                     _lib.ptr(geom.rec_w), _lib.ptr(rvx), _lib.ptr(rvz))
@@ -315,6 +345,9 @@ def resident_shot_chunk(nshot, nt, nz, nx, snapshot_budget=DEFAULT_SNAPSHOT_BUDG
     return int(min(nshot, budget // max(per_shot, 1)))
 
 
+snapshot_arena = _SnapshotArena          # `with elastic.snapshot_arena(): ...` around hand-written chunk loops
+
+
 def gradient_in_shot_chunks(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pml_width, loss_fn, chunk, **kw):
     """Loss and its gradient with the shots taken ``chunk`` at a time (see :func:`resident_shot_chunk`).
 
@@ -327,21 +360,16 @@ def gradient_in_shot_chunks(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pm
     leaf = mat.detach().requires_grad_(mat.requires_grad)
     total = None
     fgrad = torch.zeros_like(f) if f.requires_grad else None
-    last = None
-    for a in range(0, ns, chunk):
-        sl = slice(a, min(a + chunk, ns))
-        if last is not None and sl.stop - sl.start != last:
-            torch.cuda.empty_cache()         # a different snapshot size: hand the cached block back instead of splitting it
-        last = sl.stop - sl.start
-        fc = f[:, sl].detach().requires_grad_(f.requires_grad)
-        out = propagate(leaf, fc, pz, px, src_cell[sl], src_w[sl], rec_cell[sl], rec_w[sl], pml_width, **kw)
-        loss = loss_fn(out[0], out[1], sl)
-        loss.backward()
-        total = loss.detach() if total is None else total + loss.detach()
-        if fgrad is not None:
-            fgrad[:, sl] = fc.grad
-    if ns % chunk:
-        torch.cuda.empty_cache()
+    with _SnapshotArena():                   # the chunks share the snapshot tensor of the first (largest) one
+        for a in range(0, ns, chunk):
+            sl = slice(a, min(a + chunk, ns))
+            fc = f[:, sl].detach().requires_grad_(f.requires_grad)
+            out = propagate(leaf, fc, pz, px, src_cell[sl], src_w[sl], rec_cell[sl], rec_w[sl], pml_width, **kw)
+            loss = loss_fn(out[0], out[1], sl)
+            loss.backward()
+            total = loss.detach() if total is None else total + loss.detach()
+            if fgrad is not None:
+                fgrad[:, sl] = fc.grad
     if mat.requires_grad:
         if mat.is_leaf:
             mat.grad = leaf.grad if mat.grad is None else mat.grad + leaf.grad
