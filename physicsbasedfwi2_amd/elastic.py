@@ -376,7 +376,10 @@ def gradient_in_shot_chunks(mat, f, pz, px, src_cell, src_w, rec_cell, rec_w, pm
         else:
             mat.backward(leaf.grad)
     if fgrad is not None:
-        f.grad = fgrad if f.grad is None else f.grad + fgrad
+        if f.is_leaf:
+            f.grad = fgrad if f.grad is None else f.grad + fgrad
+        else:
+            f.backward(fgrad)
     return total
 
 
