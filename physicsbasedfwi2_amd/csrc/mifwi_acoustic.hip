@@ -372,6 +372,7 @@ struct ClParams {
     int rt;                      // rows of the first / last slab (0: even split), see slab_rows
     int shot0, shot1;            // shots [shot0, shot1) are handled by this launch
     int dbg;                     // timing experiments only: 1 = skip the halo hand-off, 2 = skip snapshots
+    int rcv_plain;               // adjoint sources by a plain LDS read-add-write where every tap of a slab has a cell of its own
     int nap;                     // s_sleep units between poll passes (mifwi::poll_nap)
     int nt, n_first, n_last;     // forward: steps n_first..n_last-1 ; adjoint: k = n_first down to n_last
     float c0, c1;
@@ -620,6 +621,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     auto inj_off = [&]() { return cl_opaque(inj_pack) & 0x3ffff; };
     auto inj_id = [&]() { return (cl_opaque(inj_pack) >> 18) & 0xfff; };
     constexpr bool slow_sparse = SLOW;                   // more points than one per thread: rescan per step
+    bool taps_unique = false;                            // adjoint: every receiver tap of the slab in a cell of its own
     if (!adj) {
         for (int e = 0; e < p.nsrc; ++e) {
             const int cell = p.src_cell[(long long)s * p.nsrc + e];
@@ -659,6 +661,17 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             inj_pack = ((i0 - r0 + 2) * PL + 4 + i1) | ((id & 0xfff) << 18) | (edge ? (1 << 30) : 0);
             inj_scale = rv * inv;
             smp_w = p.rec_w[(long long)s * p.nrec + id];          // reused as the tap weight
+        }
+        // Do the taps of this slab sit in cells of their own?  Then the injection is a plain LDS read-add-write (the
+        // same single rounding) instead of ds_add_f32: a float atomic takes the LDS ~1500 clocks to drain, every step,
+        // in the slab that holds the receivers - the one all the others wait for.  One-off check through the (still
+        // empty) field plane.
+        if (!slow_sparse && cnt > 0 && p.rcv_plain) {
+            int *ib = reinterpret_cast<int *>(bufA);
+            if (inj_pack >= 0) ib[inj_pack & 0x3ffff] = t;
+            __syncthreads();
+            const int dup = (inj_pack >= 0 && ib[inj_pack & 0x3ffff] != t) ? 1 : 0;
+            taps_unique = __syncthreads_or(dup) == 0;
         }
         if (p.grad_f != nullptr && t < p.nsrc) {
             const int cell = p.src_cell[(long long)s * p.nsrc + t];
@@ -905,8 +918,11 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         if (adj) {
             // ---- adjoint sources: receiver taps of this slab, z^k[cell] += (w g) (r inv) -------
             if (!slow_sparse) {
-                if (inj_pack >= 0)
-                    atomicAdd(&prv[inj_off()], (smp_w * amp) * inj_scale);
+                if (inj_pack >= 0) {
+                    float *cell = &prv[inj_off()];
+                    if (taps_unique) *cell = *cell + (smp_w * amp) * inj_scale;
+                    else atomicAdd(cell, (smp_w * amp) * inj_scale);
+                }
             } else {
                 const int cnt = p.slab_cnt[s * p.NW + w];
                 const int *lst = p.slab_list + ((long long)s * p.NW + w) * p.nrec;
@@ -1118,6 +1134,7 @@ ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const flo
     c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
     c.xcc_tab = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64 - mifwi::round_up64((long long)pl->d.nshot * pl->NW, 64));
     c.dbg = env_int("MIFWI_AC_CL_DBG", 0);
+    c.rcv_plain = env_int("MIFWI_AC_ADJ_PLAIN", 1);
     // fat slabs nap long between poll passes, thin ones short (mifwi::poll_nap)
     c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(pl->d.n0, pl->NW) >= 16 ? 48 : 1);
     return c;

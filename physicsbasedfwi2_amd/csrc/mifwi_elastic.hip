@@ -1258,8 +1258,9 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
                 zmax = std::max(zmax, ntop + nbot);
             }
             const long long lds = (4LL * (rows + 4) * pl->PL + 6LL * pl->gp + 8LL * rows +
-                                   4LL * rows * pl->wx + 4LL * zmax * pl->gp) * sizeof(float);
-            if (lds > 150 * 1024) continue;
+                                   4LL * rows * pl->wx + 4LL * zmax * pl->gp +
+                                   (rows + 4) + 2LL * kEaRcvRows * pl->PL) * sizeof(float);   // + row map, receiver rows
+            if (lds > kEaLdsLimit) continue;
             if ((long long)rows * pl->ng > 2 * kEcThreads || kEcRowFields * pl->gp > kEcGr * kEcThreads) continue;
             const int per_launch = 8 * (ncu / (8 * nw));
             if (per_launch < 8) break;
@@ -1272,7 +1273,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
         }
         if (pl->cl_adj)
             for (const void *fn : {(const void *)el_cluster_adj<1>, (const void *)el_cluster_adj<2>})
-                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mifwi::kClusterLdsLimit) != hipSuccess) {
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kEaLdsLimit) != hipSuccess) {
                     (void)hipGetLastError();
                     pl->cl_adj = 0;
                 }
@@ -1772,6 +1773,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         c.grad_f = want_f ? grad_f : nullptr;
         c.rec_cell = rec_cell; c.rec_w = rec_w; c.g_vx = g_vx; c.g_vz = g_vz;
         c.slab_cnt = lists; c.slab_list = lists + (long long)d.nshot * pl->adj_NW;
+        c.rcv_direct = env_int("MIFWI_EL_ADJ_DIRECT", 1);
         c.dbg = env_int("MIFWI_EL_CL_DBG", 0);
         c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(d.nz, c.NW) >= 8 ? 48 : 1);   // mifwi::poll_nap
         c.K = fd_weights(d.fd_order);

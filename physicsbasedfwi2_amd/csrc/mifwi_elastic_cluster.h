@@ -151,6 +151,9 @@ __device__ __forceinline__ void ec_pin(float2 &a, float2 &b, float2 &c, float2 &
 // prologue's global loads as "possibly pending" into the loop and waits on vmcnt before the first use of
 // each such register in EVERY iteration - where the wait then drains the snapshot stores and publishes.
 __device__ __forceinline__ void ec_drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // vmcnt(0)
+// A value requested long ago is declared arrived HERE (the wait the compiler puts in front of this is free where the
+// caller knows the queue has drained): its later use no longer waits for whatever was requested in between.
+__device__ __forceinline__ void ec_settle(float &x) { asm volatile("" : "+v"(x)); }
 
 // publishes stay in the XCD's L2 (mifwi::same_xcd in mifwi_common.h); -DMIFWI_HANDOFF_AGENT: written through the fabric
 #ifdef MIFWI_HANDOFF_AGENT
@@ -831,6 +834,18 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 // planes 0,1] | C (D, publish, gradients) | D interior, receive D, D boundary.
 // Arithmetic per cell = el_adj_s / el_adj_v.
 // ================================================================================================
+// Adjoint sources of the single-launch adjoint ("direct" mode): the slab's receiver taps write w g straight into a
+// small LDS buffer of their own ([2][kEaRcvRows][PL]: the rows of the slab that hold receivers, compacted) ahead of
+// barrier 1, and the owners of those rows add it to v_bar after barrier 3 - no zeroing, no barrier, no atomic.
+// It replaced "zero two planes, barrier, ds_add_f32, barrier, read": an LDS float atomic took the receiver slab 1700
+// clocks to drain and the two extra barriers 1100 more, per step, in the slab every other slab waits for.  Needs every
+// tap of the slab in a cell of its own and at most kEaRcvRows receiver rows (checked once, in LDS, at kernel start);
+// anything else keeps the atomic path.
+constexpr int kEaRcvRows = 4;
+// dynamic LDS the adjoint time loop may ask for: the CU's 160 KB less the kernel's static 256 B and a margin (100x300 in
+// 8 slabs takes 144 KB of planes, tables and memory variables + 10 KB of receiver rows)
+constexpr int kEaLdsLimit = 158 * 1024;
+
 struct EaParams {
     int nz, nx, ng, gp, pitch;
     unsigned field_stride;
@@ -855,6 +870,7 @@ struct EaParams {
     const int *rec_cell;
     const float *rec_w, *g_vx, *g_vz;    // g [nt][nshot][nrec]
     const int *slab_cnt, *slab_list;     // receivers per slab: [nshot][NW], [nshot][NW][nrec]
+    int rcv_direct;                      // adjoint sources through the receiver-row buffer where the taps allow (kEaRcvRows)
     unsigned long long *xbuf;
     int *err;
     int *xcc_tab;                        // [nshot][NW] XCC_ID + 1 of each slab's workgroup (mifwi::same_xcd)
@@ -1013,13 +1029,14 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     // fetched one step ahead
     const int cnt = p.slab_cnt[s * p.NW + w];
     const bool inj_fast = cnt <= kEcThreads;
-    int inj_lo = -1;
+    int inj_lo = -1, inj_row = 0, inj_col = 0;
     unsigned inj_id4 = 0;
     float inj_w = 0.f, amp_x = 0.f, amp_z = 0.f;
     if (inj_fast && t < cnt) {
         const int inj_id = p.slab_list[((long long)s * p.NW + w) * p.nrec + t];
         const int cell = p.rec_cell[(long long)s * p.nrec + inj_id];
         const int i0 = cell / p.nx, i1 = cell - i0 * p.nx;
+        inj_row = i0 - r0; inj_col = i1;
         inj_lo = (i0 - r0 + 2) * PL + 4 + i1;
         inj_w = p.rec_w[(long long)s * p.nrec + inj_id];
         inj_id4 = 4u * inj_id;
@@ -1028,6 +1045,37 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     // ---- tables; planes zeroed once (halo rows/columns outside the grid stay zero) -----------------
     ec_stage_tables(lpx, lpz, p.px, p.pz, p.gp, p.nz, r0, R, t);
     for (int e = t; e < fsz; e += kEcThreads) { pln[e] = 0.f; pln[fsz + e] = 0.f; pln[2 * fsz + e] = 0.f; pln[3 * fsz + e] = 0.f; }
+    // ---- direct mode of the adjoint sources (kEaRcvRows): row map, tap uniqueness ------------------------------
+    int *rowmap = reinterpret_cast<int *>(lzs + 4 * zsz);     // [R (+ pad)]: compact receiver row of a slab row, or -1
+    float *rbuf = lzs + 4 * zsz + ((R + 4) & ~3);             // [2][kEaRcvRows][PL]
+    int inj_co = -1;                                          // my tap's offset in rbuf (direct mode)
+    bool direct = false;
+    if (cnt > 0 && inj_fast && p.rcv_direct) {                // MIFWI_EL_ADJ_DIRECT=0 keeps the atomic path
+        for (int e = t; e <= R; e += kEcThreads) rowmap[e] = 0;
+        for (int e = t; e < 2 * kEaRcvRows * PL; e += kEcThreads) rbuf[e] = 0.f;
+        __syncthreads();
+        if (t < cnt) rowmap[inj_row] = 1;
+        __syncthreads();
+        if (t == 0) {
+            int k = 0;
+            for (int r = 0; r < R; ++r) rowmap[r] = rowmap[r] ? k++ : -1;
+            rowmap[R] = k;
+        }
+        __syncthreads();
+        direct = rowmap[R] <= kEaRcvRows;
+        if (direct) {
+            int *ib = reinterpret_cast<int *>(rbuf);
+            if (t < cnt) {
+                inj_co = rowmap[inj_row] * PL + 4 + inj_col;
+                ib[inj_co] = t;
+            }
+            __syncthreads();
+            const int dup = (t < cnt && ib[inj_co] != t) ? 1 : 0;
+            direct = __syncthreads_or(dup) == 0;
+            if (t < cnt) ib[inj_co] = 0;                      // = 0.0f
+            if (!direct) inj_co = -1;
+        }
+    }
     __syncthreads();
 
     // ---- halo hand-off: kind 0 = E2 (plane 1), E3 (plane 2); kind 1 = D2 (plane 1), D4 (plane 2) ----
@@ -1302,6 +1350,13 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             for (int e = t + kEcThreads; e < p.nsrc; e += kEcThreads)
                 if (p.src_cell[(long long)s * p.nsrc + e] < 0) p.grad_f[((long long)n * p.nshot + s) * p.nsrc + e] = 0.f;
         }
+        if (direct) {                                      // this step's adjoint sources: read after barrier 3
+            const int co = ec_opaque(inj_co);
+            if (co >= 0) {
+                rbuf[co] = inj_w * amp_x;
+                rbuf[kEaRcvRows * PL_ + co] = inj_w * amp_z;
+            }
+        }
         EC_STAMP(1);
         __syncthreads();                                   // 1: E planes complete on the own rows
         EC_STAMP(2);
@@ -1325,6 +1380,13 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         EC_STAMP(4);
         __syncthreads();                                   // 2: E halo rows are in LDS
         EC_STAMP(5);
+#ifndef MIFWI_EA_NO_SETTLE
+        // the adjoint-source amplitudes of this step (requested a step ago, arrived before the poll's drain) must not
+        // wait behind the snapshot planes requested next: in the slab that holds the receivers - the slowest one, which
+        // every other slab waits for - their first use stalled 3500 clocks on loads it does not need
+        ec_settle(amp_x);
+        ec_settle(amp_z);
+#endif
         if (it > 0) {
 #pragma unroll
             for (int q = 0; q < NG; ++q)
@@ -1339,7 +1401,19 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         __syncthreads();                                   // 3: every read of E is done
         EC_STAMP(7);
         // ---- receivers of this slab: v_bar += w g, through planes 0 and 1 ---------------------------
-        if (cnt > 0) {
+        if (direct) {
+#pragma unroll
+            for (int q = 0; q < NG; ++q)
+                if (ec_opaque(G[q].cls) != 0) {
+                    const int rr = rowmap[ec_opaque(G[q].j) - r0];
+                    if (rr >= 0) {
+                        const float *b = rbuf + rr * PL_ + 4 + 4 * ec_opaque(G[q].g);
+                        const float4 ix = ld4(b), iz = ld4(b + kEaRcvRows * PL_);
+                        G[q].vx = make_float4(G[q].vx.x + ix.x, G[q].vx.y + ix.y, G[q].vx.z + ix.z, G[q].vx.w + ix.w);
+                        G[q].vz = make_float4(G[q].vz.x + iz.x, G[q].vz.y + iz.y, G[q].vz.z + iz.z, G[q].vz.w + iz.w);
+                    }
+                }
+        } else if (cnt > 0) {
 #pragma unroll
             for (int q = 0; q < NG; ++q)
                 if (ec_opaque(G[q].cls) != 0) { st4(pln + ec_opaque(G[q].lo), zero4); st4(pln + fsz + ec_opaque(G[q].lo), zero4); }
@@ -1370,7 +1444,6 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
                     G[q].vx = make_float4(G[q].vx.x + ix.x, G[q].vx.y + ix.y, G[q].vx.z + ix.z, G[q].vx.w + ix.w);
                     G[q].vz = make_float4(G[q].vz.x + iz.x, G[q].vz.y + iz.y, G[q].vz.z + iz.z, G[q].vz.w + iz.w);
                 }
-            request_amp(n - 1);
         }
         EC_STAMP(8);
         // ---- C ----------------------------------------------------------------------------------------
@@ -1402,6 +1475,11 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
             for (int q = 0; q < NG; ++q)
                 if ((q == 0 ? EA_S0 : EA_S1) == 0) request_S(G[q], n - 1);      // after the poll: loads retire in order
         }
+        // The next step's adjoint-source amplitudes ride with the snapshot planes: loads retire in order, so the first
+        // wait after a request pays its full latency.  Requested where they are used (ahead of phase C's material
+        // loads), they cost the slab that holds the receivers - the one every other slab ends up waiting for - a
+        // memory round trip per step (3300 of 24 000 clocks).
+        if (cnt > 0) request_amp(n - 1);
         EC_STAMP(13);
         __syncthreads();                                   // 5: D halo rows are in LDS
         EC_STAMP(14);

@@ -13,7 +13,7 @@ NAMES_ADJ = ["A: E + publish", "wait barrier 1", "B interior", "poll E halo", "w
              "request S", "wait barrier 5", "D boundary"]
 
 
-def main(path):
+def main(path, brief=False):
     blocks, cur = [], []
     for line in open(path):
         if line.startswith("#"):
@@ -34,6 +34,10 @@ def main(path):
         a = a[4:60]                                        # steps with every stamp written
         d = np.diff(a, axis=2).astype(np.float64)          # [step][wave][phase]
         step = (a[1:, :, 0] - a[:-1, :, 0]).mean()
+        if brief:                                          # one line per kernel: phase means over the waves
+            m = d.mean(axis=(0, 1))
+            print(head.split("|")[0].strip("# ")[:32], "step %.0f |" % step, " ".join("%s %.0f" % (nm.split(":")[0][:14], x) for nm, x in zip(names, m)))
+            continue
         print(head, "| s_memtime ticks per step %.0f" % step)
         print("%-22s" % "phase" + "".join("%7s" % ("w%d" % w) for w in range(a.shape[1])) + "    max")
         for k, nm in enumerate(names):
@@ -43,4 +47,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], "--brief" in sys.argv)
