@@ -763,7 +763,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     };
     prefetch(0);
 #ifdef MIFWI_ABLATIONS
-    const bool tr_on = w == p.NW / 2 && s == p.shot0;
+    const bool tr_on = w == (((p.dbg >> 8) & 15) ? ((p.dbg >> 8) & 15) - 1 : p.NW / 2) && s == p.shot0;   // dbg bits 8-11: traced slab + 1
 #endif
 
     for (int it = 0; it < nsteps; ++it) {

@@ -189,6 +189,38 @@ def test_cluster_path_with_halo_handoff(oracle32, monkeypatch, nw, edge):
     assert rel_l2(f.grad.cpu().numpy(), gf_o) <= TOL_GRAD
 
 
+def test_cluster_adjoint_source_paths_agree(oracle32, monkeypatch):
+    """Adjoint sources of the single-launch time loop: a plain LDS read-add-write where every tap of a slab has a cell of
+    its own, an LDS float atomic otherwise (MIFWI_AC_ADJ_PLAIN=0 forces it) - the same single rounding, the same bits.
+    Two receivers in one cell must take the atomic path by themselves."""
+    monkeypatch.setenv("MIFWI_AC_NW", "3")
+    case = acoustic_case(seed=59, n0=61, n1=83, nb=9, nt=120, ns=2, nrec=40)
+    outs = []
+    for flag in (None, "0"):
+        if flag is not None:
+            monkeypatch.setenv("MIFWI_AC_ADJ_PLAIN", flag)
+        r, f, rec = _run_hip(case)
+        rec.backward(torch.sign(rec.detach()))
+        outs.append((r.grad.clone(), f.grad.clone()))
+    assert float(outs[0][0].abs().max()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    monkeypatch.delenv("MIFWI_AC_ADJ_PLAIN")
+    rc = case["rc"].copy()
+    rc.reshape(2, -1)[:, 1] = rc.reshape(2, -1)[:, 0]             # two taps in one cell
+    case["rc"] = rc
+    o = oracle32
+    rec_o, G_o = o.acoustic_forward(case["r"], case["q0"], case["q1"], case["f"], case["sc"], case["sw"], case["rc"],
+                                    case["rw"], save=True)
+    r, f, rec = _run_hip(case)
+    assert np.abs(rec.detach().cpu().numpy() - rec_o).max() == 0.0
+    g = np.sign(rec_o).astype(np.float32)
+    rec.backward(torch.tensor(g, device=rec.device))
+    gr_o, gf_o = o.acoustic_backward(case["r"], case["q0"], case["q1"], case["sc"], case["sw"], case["rc"], case["rw"],
+                                     g, G_o)
+    assert rel_l2(r.grad.cpu().numpy(), gr_o) <= TOL_GRAD
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= TOL_GRAD
+
+
 def test_cluster_and_per_step_paths_agree(monkeypatch):
     case = acoustic_case(seed=19, n0=70, n1=120, nb=10, nt=90, ns=2, nrec=21)
     outs = []

@@ -104,6 +104,34 @@ def test_cluster_adjoint_receivers_everywhere(oracle32, monkeypatch):
     _check_parity(oracle32, case)
 
 
+def test_cluster_adjoint_source_paths_agree(oracle32, monkeypatch):
+    """The single-launch adjoint adds its sources through a receiver-row buffer (plain LDS stores) where every tap of a
+    slab has a cell of its own on at most four rows, and through LDS float atomics otherwise (MIFWI_EL_ADJ_DIRECT=0
+    forces them): same bits either way.  Two receivers sharing a cell must drop to the atomic path by themselves."""
+    monkeypatch.setenv("MIFWI_EL_NW", "3")
+    case = elastic_case(seed=53, nz=60, nx=100, fw=8, ns=2, nrec=60, nt=90)
+    nx = 100
+    rc = np.empty((2, 60), dtype=np.int32)
+    rc[:, :30] = 12 * nx + 5 + 3 * np.arange(30)                  # two receiver rows in the first slab,
+    rc[:, 30:50] = 15 * nx + 7 + 4 * np.arange(20)
+    rc[:, 50:] = 33 * nx + 10 + 8 * np.arange(10)                 # one in the second
+    case["rc"] = rc.reshape(case["rc"].shape)
+    outs = []
+    for flag in (None, "0"):
+        if flag is not None:
+            monkeypatch.setenv("MIFWI_EL_ADJ_DIRECT", flag)
+        mat, f, rvx, rvz = _run_hip(case)
+        torch.autograd.backward([rvx, rvz], [torch.sign(rvx.detach()), torch.sign(rvz.detach())])
+        outs.append((mat.grad.clone(), f.grad.clone()))
+    assert float(outs[0][0].abs().max()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    monkeypatch.delenv("MIFWI_EL_ADJ_DIRECT")
+    _check_parity(oracle32, case, bitwise=True)
+    rc[:, 1] = rc[:, 0]                                           # two taps in one cell
+    case["rc"] = rc.reshape(case["rc"].shape)
+    _check_parity(oracle32, case, bitwise=True)
+
+
 def test_cluster_and_per_step_paths_agree(monkeypatch):
     case = elastic_case(seed=29, nz=70, nx=300, fw=10, ns=2, nrec=40, nt=100)   # two groups per thread
     outs = []
