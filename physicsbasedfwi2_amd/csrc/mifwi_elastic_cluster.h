@@ -308,6 +308,47 @@ struct EcHandoff {
 };
 
 // per-thread state of one owned group of 4 cells (registers for the whole run)
+// Which group thread t holds in slot q (v = t + q * kEcThreads).  The interior groups of the slab come first (rows
+// 2 .. R-3, row-major), the boundary groups (rows 0, 1, R-2, R-1) start at the next wave boundary where that fits: a
+// wave's slot then holds ONE class.  class 1 = interior, first slot: updated before the poll; 2 = boundary: after it;
+// 3 = interior, second slot: updated LATE, together with the boundary rows.  With the plain row-major deal
+// (v -> row v / ng) three of the eight waves of a 13-row slab of 100x300 made two interior passes before the poll while
+// five waited, then idled while those five did the boundary rows, and two waves held both classes in one slot (a
+// whole extra pass for 7 and 22 lanes): 2 I + B per half step on the critical path.  Now every wave makes one interior
+// pass, and the second interior pass of three waves runs beside the boundary pass of the others: I + max(I, B).
+#ifndef EC_LATE_INTERIOR
+#define EC_LATE_INTERIOR 1
+#endif
+#ifndef EA_PUBLISH_FIRST
+#define EA_PUBLISH_FIRST 1
+#endif
+struct EcSlot { int lrw, g, cls; };
+__device__ __forceinline__ EcSlot ec_slot(int v, int R, int ng)
+{
+    EcSlot s;
+    s.lrw = 0; s.g = 0; s.cls = 0;
+#if EC_LATE_INTERIOR
+    const int nint = (R > 4 ? R - 4 : 0) * ng, nb = R * ng - nint;
+    int b0 = (nint + 63) & ~63;
+    if (b0 + nb > 2 * kEcThreads) b0 = nint;
+    if (v < nint) {
+        const int ir = v / ng;
+        s.lrw = 2 + ir; s.g = v - ir * ng; s.cls = v < kEcThreads ? 1 : 3;
+    } else if (v >= b0 && v < b0 + nb) {
+        const int bi = v - b0, br = bi / ng;
+        s.g = bi - br * ng;
+        s.lrw = (R > 4 && br >= 2) ? R - 4 + br : br;
+        s.cls = 2;
+    }
+#else
+    if (v < R * ng) {
+        s.lrw = v / ng; s.g = v - s.lrw * ng;
+        s.cls = (s.lrw >= 2 && s.lrw < R - 2) ? 1 : 2;
+    }
+#endif
+    return s;
+}
+
 struct EcGroup {
     int cls;                                      // 0: none, 1: interior rows of the slab, 2: boundary rows (stencils reach the halo)
     int g, j;                                     // group in the row, grid row
@@ -543,12 +584,12 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
         EcGroup &g = G[q];
-        const int gi = t + q * kEcThreads;
-        const bool own = gi < R * p.ng;
-        const int lrw = own ? gi / p.ng : 0;
-        g.g = own ? gi - lrw * p.ng : 0;
+        const EcSlot sl = ec_slot(t + q * kEcThreads, R, p.ng);
+        const bool own = sl.cls != 0;
+        const int lrw = sl.lrw;
+        g.g = sl.g;
         g.j = r0 + lrw;
-        g.cls = !own ? 0 : (lrw >= 2 && lrw < R - 2) ? 1 : 2;   // 1: stencils stay inside the own rows
+        g.cls = sl.cls;                      // 1, 3: stencils stay inside the own rows
         g.lo = (lrw + 2) * PL + 4 + 4 * g.g;
         const unsigned gcc = (unsigned)g.j * p.gp + 4 * g.g;
         g.gcb = 4u * gcc;
@@ -718,7 +759,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             if (poll_s && q == q_req) X.request(P, 1, (it - 1) & 1);
-            if (ec_opaque(G[q].cls) == 1) do_v(G[q], n, it, false);
+            if ((!EC_LATE_INTERIOR || q == 0) && ec_opaque(G[q].cls) == 1) do_v(G[q], n, it, false);
             __builtin_amdgcn_sched_barrier(0);             // one group at a time: bounds the register peak
         }
         EC_STAMP(1);
@@ -731,7 +772,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         EC_STAMP(3);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (ec_opaque(G[q].cls) == 2) do_v(G[q], n, it, true);
+            const int cls = ec_opaque(G[q].cls);
+            if (cls == 2) do_v(G[q], n, it, true);
+            else if (q > 0 && cls == 3) do_v(G[q], n, it, false);          // late interior (ec_slot)
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(4);
@@ -742,7 +785,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             if (poll_v && q == q_req) X.request(P, 0, it & 1);
-            if (ec_opaque(G[q].cls) == 1) do_s(G[q], q, n, it, false);
+            if ((!EC_LATE_INTERIOR || q == 0) && ec_opaque(G[q].cls) == 1) do_s(G[q], q, n, it, false);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(6);
@@ -782,7 +825,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         EC_STAMP(9);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (ec_opaque(G[q].cls) == 2) do_s(G[q], q, n, it, true);
+            const int cls = ec_opaque(G[q].cls);
+            if (cls == 2) do_s(G[q], q, n, it, true);
+            else if (q > 0 && cls == 3) do_s(G[q], q, n, it, false);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(10);
@@ -971,13 +1016,13 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
         EaGroup &g = G[q];
-        const int gi = t + q * kEcThreads;
-        const bool own = gi < R * p.ng;
-        const int lrw = own ? gi / p.ng : 0;
-        g.g = own ? gi - lrw * p.ng : 0;
+        const EcSlot sl = ec_slot(t + q * kEcThreads, R, p.ng);
+        const bool own = sl.cls != 0;
+        const int lrw = sl.lrw;
+        g.g = sl.g;
         g.j = r0 + lrw;
         g.lo = (lrw + 2) * PL + 4 + 4 * g.g;
-        g.cls = !own ? 0 : (lrw >= 2 && lrw < R - 2) ? 1 : 2;
+        g.cls = sl.cls;
         g.bxx = g.bzz = g.bxz = g.vx = g.vz = zero4;
         g.a0 = g.a1 = g.a2 = g.a3 = g.a4 = zero4;
         g.S1 = g.S2 = g.S3 = g.S4 = g.S5 = zero4;
@@ -1340,7 +1385,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         EC_STAMP(0);
         // ---- A ----------------------------------------------------------------------------------------
 #pragma unroll
-        for (int q = 0; q < NG; ++q) {
+        for (int qq = 0; qq < NG; ++qq) {
+            const int q = EA_PUBLISH_FIRST ? NG - 1 - qq : qq;     // the second slot holds the rows that publish (ec_slot)
             const int cls = ec_opaque(G[q].cls);
             if (cls != 0) phase_a(G[q], n, it, cls);
             __builtin_amdgcn_sched_barrier(0);
@@ -1369,7 +1415,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             if (do_x && q == q_req) X.request(P, 0, it & 1);
-            if (ec_opaque(G[q].cls) == 1) phase_b(G[q]);
+            if ((!EC_LATE_INTERIOR || q == 0) && ec_opaque(G[q].cls) == 1) phase_b(G[q]);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(3);
@@ -1394,7 +1440,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         }
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (ec_opaque(G[q].cls) == 2) phase_b(G[q]);
+            if (ec_opaque(G[q].cls) >= 2) phase_b(G[q]);                 // boundary + late interior (ec_slot)
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(6);
@@ -1448,7 +1494,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         EC_STAMP(8);
         // ---- C ----------------------------------------------------------------------------------------
 #pragma unroll
-        for (int q = 0; q < NG; ++q) {
+        for (int qq = 0; qq < NG; ++qq) {
+            const int q = EA_PUBLISH_FIRST ? NG - 1 - qq : qq;
             const int cls = ec_opaque(G[q].cls);
             if (cls != 0) phase_c(G[q], it, cls);
             __builtin_amdgcn_sched_barrier(0);
@@ -1460,7 +1507,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             if (do_x && q == q_req) X.request(P, 1, it & 1);
-            if (ec_opaque(G[q].cls) == 1) phase_d(G[q], false);
+            if ((!EC_LATE_INTERIOR || q == 0) && ec_opaque(G[q].cls) == 1) phase_d(G[q], false);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(11);
@@ -1485,7 +1532,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         EC_STAMP(14);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (ec_opaque(G[q].cls) == 2) phase_d(G[q], true);
+            const int cls = ec_opaque(G[q].cls);
+            if (cls == 2) phase_d(G[q], true);
+            else if (q > 0 && cls == 3) phase_d(G[q], false);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(15);
