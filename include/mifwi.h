@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define MIFWI_VERSION_MAJOR 0
-#define MIFWI_VERSION_MINOR 3   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format */
+#define MIFWI_VERSION_MINOR 4   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format; 4: mifwi_fallback_count */
 
 enum {
     MIFWI_OK = 0,
@@ -42,6 +42,10 @@ enum {
 
 const char *mifwi_last_error(void);
 int mifwi_version(void);                 /* major*1000 + minor                  */
+/* Calls of this process whose single-launch time loop gave up (hand-off time-out, slabs of a shot not on one XCD) and
+ * were re-run with one launch per step: results are the same, the time is not.  Monitoring and tests read it; the
+ * first such call is also noted on stderr (MIFWI_QUIET=1 silences that). */
+int64_t mifwi_fallback_count(void);
 int mifwi_device_count(void);            /* number of visible HIP devices, >=0  */
 /* engine / memory clock (kHz) and compute units of a device, for measurement reports; 0 where unknown */
 int mifwi_device_info(int device, int32_t *sclk_khz, int32_t *mclk_khz, int32_t *compute_units);

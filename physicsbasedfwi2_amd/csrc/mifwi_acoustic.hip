@@ -1211,6 +1211,7 @@ extern "C" {
 
 const char *mifwi_last_error(void) { return mifwi::err_buf(); }
 int mifwi_version(void) { return MIFWI_VERSION_MAJOR * 1000 + MIFWI_VERSION_MINOR; }
+int64_t mifwi_fallback_count(void) { return (int64_t)mifwi::g_fallbacks.load(std::memory_order_relaxed); }
 int mifwi_device_count(void)
 {
     int n = 0;

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -42,8 +43,10 @@ constexpr int kClusterTimedOut = 1;
 // A single-launch time loop gave up (a workgroup was not resident in time, or the slabs of a shot were not placed on
 // one XCD) and the call is re-run with one launch per step: correct, but several times slower on small grids, so it
 // is said once per process on stderr (MIFWI_QUIET=1 silences it) rather than left to be discovered in a profile.
+inline std::atomic<long long> g_fallbacks{0};          // mifwi_fallback_count()
 inline void note_fallback(const char *what)
 {
+    g_fallbacks.fetch_add(1, std::memory_order_relaxed);
     static bool said = false;
     if (said || getenv("MIFWI_QUIET")) return;
     said = true;

@@ -323,14 +323,14 @@ struct EcHandoff {
 #define EA_PUBLISH_FIRST 1
 #endif
 struct EcSlot { int lrw, g, cls; };
-__device__ __forceinline__ EcSlot ec_slot(int v, int R, int ng)
+__device__ __forceinline__ EcSlot ec_slot(int v, int R, int ng, int slots)       // slots = NG * kEcThreads >= R * ng
 {
     EcSlot s;
     s.lrw = 0; s.g = 0; s.cls = 0;
 #if EC_LATE_INTERIOR
     const int nint = (R > 4 ? R - 4 : 0) * ng, nb = R * ng - nint;
     int b0 = (nint + 63) & ~63;
-    if (b0 + nb > 2 * kEcThreads) b0 = nint;
+    if (b0 + nb > slots) b0 = nint;                          // no room for the pad: classes share a wave's slot
     if (v < nint) {
         const int ir = v / ng;
         s.lrw = 2 + ir; s.g = v - ir * ng; s.cls = v < kEcThreads ? 1 : 3;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
         EcGroup &g = G[q];
-        const EcSlot sl = ec_slot(t + q * kEcThreads, R, p.ng);
+        const EcSlot sl = ec_slot(t + q * kEcThreads, R, p.ng, NG * kEcThreads);
         const bool own = sl.cls != 0;
         const int lrw = sl.lrw;
         g.g = sl.g;
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
         EaGroup &g = G[q];
-        const EcSlot sl = ec_slot(t + q * kEcThreads, R, p.ng);
+        const EcSlot sl = ec_slot(t + q * kEcThreads, R, p.ng, NG * kEcThreads);
         const bool own = sl.cls != 0;
         const int lrw = sl.lrw;
         g.g = sl.g;

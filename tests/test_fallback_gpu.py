@@ -48,6 +48,7 @@ def _same(a, b):
         assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) <= 2e-5
 
 
+@pytest.mark.expects_fallback
 def test_acoustic_falls_back_to_one_launch_per_step(monkeypatch):
     from physicsbasedfwi2_amd.acoustic import AcousticPlan
     case = acoustic_case(seed=71, n0=120, n1=200, nb=10, nt=120, ns=6, nrec=40)
@@ -60,6 +61,7 @@ def test_acoustic_falls_back_to_one_launch_per_step(monkeypatch):
     _same(ref[1:], got[1:])
 
 
+@pytest.mark.expects_fallback
 def test_acoustic_born_falls_back(monkeypatch):
     from physicsbasedfwi2_amd import acoustic
     case = acoustic_case(seed=73, n0=100, n1=160, nb=10, nt=100, ns=3, nrec=30)
@@ -75,19 +77,25 @@ def test_acoustic_born_falls_back(monkeypatch):
         assert float(a.abs().max()) > 0 and torch.equal(a, b)
 
 
+@pytest.mark.expects_fallback
 def test_elastic_falls_back_to_one_launch_per_half_step(monkeypatch):
     from physicsbasedfwi2_amd.elastic import ElasticPlan
     case = elastic_case(seed=79, nz=100, nx=300, fw=10, ns=6, nrec=100, nt=120)
     pl = ElasticPlan(100, 300, 120, 6, 1, 100, 1, 10, 0)
     assert pl.cluster_slabs(False) >= 1 and pl.cluster_slabs(True) >= 1
+    from physicsbasedfwi2_amd import _lib
+    n0 = _lib.load().mifwi_fallback_count()
     ref = _elastic(case)
+    assert _lib.load().mifwi_fallback_count() == n0          # what conftest's _no_silent_fallback watches
     monkeypatch.setenv("MIFWI_TEST_FAKE_TIMEOUT", "1")
     got = _elastic(case)
+    assert _lib.load().mifwi_fallback_count() >= n0 + 2      # forward and adjoint time loops both gave up
     assert float(ref[0].abs().max()) > 0
     assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
     _same(ref[2:], got[2:])
 
 
+@pytest.mark.expects_fallback
 @pytest.mark.parametrize("mode", ["1", "2"])
 def test_resumed_calls_fall_back_too(monkeypatch, mode):
     """A checkpointed run resumes from saved state.  The library keeps a copy of a resumed call's input state, so
