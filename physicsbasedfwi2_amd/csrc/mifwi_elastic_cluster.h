@@ -322,6 +322,12 @@ struct EcHandoff {
 #ifndef EA_PUBLISH_FIRST
 #define EA_PUBLISH_FIRST 1
 #endif
+#ifndef EA_MATS_AHEAD_A
+#define EA_MATS_AHEAD_A 0          // measured on 100x300: A ahead 8.81 us, C ahead 8.41, both 8.50 (13 VGPRs spilled), none 8.58
+#endif
+#ifndef EA_MATS_AHEAD_C
+#define EA_MATS_AHEAD_C 1
+#endif
 struct EcSlot { int lrw, g, cls; };
 __device__ __forceinline__ EcSlot ec_slot(int v, int R, int ng, int slots)       // slots = NG * kEcThreads >= R * ng
 {
@@ -1157,13 +1163,22 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
 
     // ---- phase bodies ----------------------------------------------------------------------------------
     // A: E from the owner's sigma-bar through the transposed C-PML -> planes; boundary rows publish E2,E3
-    auto phase_a = [&](EaGroup &g, int n, int it, const int cls) {
-        const int fsz = ec_su(fsz_), xsz = ec_su(xsz_), zsz = ec_su(zsz_);
+    // The material planes of BOTH group slots are requested before either is used (EA_MATS_AHEAD): they come from L2,
+    // 600-800 clocks away, and a phase that loaded them group by group paid that twice per wave.
+    auto mats_a = [&](EaGroup &g, float4 &Ls, float4 &Ms, float4 &mus) {
         const unsigned ncell = ec_su(ncell_);
+        const unsigned gcb = cell_bytes(ec_opaque(g.j), ec_opaque(g.g));
+        Ls = ld4(ec_at(p.mat + M_L * ncell, gcb)); Ms = ld4(ec_at(p.mat + M_M * ncell, gcb));
+        mus = ld4(ec_at(p.mat + M_MU * ncell, gcb));
+    };
+    auto mats_c = [&](EaGroup &g, float4 &bxs, float4 &bzs) {
+        const unsigned ncell = ec_su(ncell_);
+        const unsigned gcb = cell_bytes(ec_opaque(g.j), ec_opaque(g.g));
+        bxs = ld4(ec_at(p.mat + M_BX * ncell, gcb)); bzs = ld4(ec_at(p.mat + M_BZ * ncell, gcb));
+    };
+    auto phase_a = [&](EaGroup &g, int n, int it, const int cls, const float4 &Ls, const float4 &Ms, const float4 &mus) {
+        const int fsz = ec_su(fsz_), xsz = ec_su(xsz_), zsz = ec_su(zsz_);
         const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g), jq = ec_opaque(g.j);
-        const unsigned gcb = cell_bytes(jq, gq);
-        const float4 Ls = ld4(ec_at(p.mat + M_L * ncell, gcb)), Ms = ld4(ec_at(p.mat + M_M * ncell, gcb));
-        const float4 mus = ld4(ec_at(p.mat + M_MU * ncell, gcb));
         // adjoint of szz(0,.) is discarded.  Component-wise selects: a whole-vector select was compiled
         // into a two-entry table in scratch memory (a vector-memory load per use)
         const bool top = p.fsurf && jq == 0;
@@ -1265,12 +1280,9 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         g.vz = make_float4(nvz[0], nvz[1], nvz[2], nvz[3]);
     };
     // C: D from the new v_bar -> planes [D1 D2 D4 D3]; boundary rows publish D2,D4; all five gradient accumulators
-    auto phase_c = [&](EaGroup &g, int it, const int cls) {
+    auto phase_c = [&](EaGroup &g, int it, const int cls, const float4 &bxs, const float4 &bzs) {
         const int fsz = ec_su(fsz_), xsz = ec_su(xsz_), zsz = ec_su(zsz_);
-        const unsigned ncell = ec_su(ncell_);
         const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g), jq = ec_opaque(g.j);
-        const unsigned gcb = cell_bytes(jq, gq);
-        const float4 bxs = ld4(ec_at(p.mat + M_BX * ncell, gcb)), bzs = ld4(ec_at(p.mat + M_BZ * ncell, gcb));
         float d1[4], d2[4], d3[4], d4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1384,11 +1396,23 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         const int n = p.n_first - it;
         EC_STAMP(0);
         // ---- A ----------------------------------------------------------------------------------------
+        float4 mL[NG], mM[NG], mMu[NG];
+#if EA_MATS_AHEAD_A
+#pragma unroll
+        for (int qq = 0; qq < NG; ++qq) {
+            const int q = EA_PUBLISH_FIRST ? NG - 1 - qq : qq;
+            if (ec_opaque(G[q].cls) != 0) mats_a(G[q], mL[q], mM[q], mMu[q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int qq = 0; qq < NG; ++qq) {
             const int q = EA_PUBLISH_FIRST ? NG - 1 - qq : qq;     // the second slot holds the rows that publish (ec_slot)
             const int cls = ec_opaque(G[q].cls);
-            if (cls != 0) phase_a(G[q], n, it, cls);
+#if !EA_MATS_AHEAD_A
+            if (cls != 0) mats_a(G[q], mL[q], mM[q], mMu[q]);
+#endif
+            if (cls != 0) phase_a(G[q], n, it, cls, mL[q], mM[q], mMu[q]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (p.grad_f != nullptr && w == 0) {               // inactive source taps: slab 0 writes their zeros
@@ -1493,11 +1517,23 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         }
         EC_STAMP(8);
         // ---- C ----------------------------------------------------------------------------------------
+        float4 mBx[NG], mBz[NG];
+#if EA_MATS_AHEAD_C
+#pragma unroll
+        for (int qq = 0; qq < NG; ++qq) {
+            const int q = EA_PUBLISH_FIRST ? NG - 1 - qq : qq;
+            if (ec_opaque(G[q].cls) != 0) mats_c(G[q], mBx[q], mBz[q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int qq = 0; qq < NG; ++qq) {
             const int q = EA_PUBLISH_FIRST ? NG - 1 - qq : qq;
             const int cls = ec_opaque(G[q].cls);
-            if (cls != 0) phase_c(G[q], it, cls);
+#if !EA_MATS_AHEAD_C
+            if (cls != 0) mats_c(G[q], mBx[q], mBz[q]);
+#endif
+            if (cls != 0) phase_c(G[q], it, cls, mBx[q], mBz[q]);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(9);
