@@ -98,6 +98,7 @@ def test_committed_bench_line_has_the_contract_fields():
         assert 0 < r["frac"] <= 1.0 and r["cells"] == "interior"
         assert r["traffic"] is None or (r["traffic"] > 0 and r["traffic_profiled_at"])
         assert e["check"]["bitwise_repeatable"] is True and e["check"]["verified"] is True
+        assert e["check"].get("fallbacks", 0) == 0           # no single-launch time loop gave up inside the timed region
         assert e["check"]["loss"] > 1e-8 and e["check"]["grad_abs_sum"] > 1e-8
         c = e["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "C oracle" in c["sample"]

@@ -104,6 +104,21 @@ def test_cluster_adjoint_receivers_everywhere(oracle32, monkeypatch):
     _check_parity(oracle32, case)
 
 
+@pytest.mark.parametrize("nz,nx,nw", [(45, 272, 3), (25, 64, 5), (24, 100, 6), (27, 83, 3), (52, 300, 4)],
+                         ids=lambda v: str(v))
+def test_cluster_group_dealing_shapes(oracle32, monkeypatch, nz, nx, nw):
+    """How a slab's groups are dealt to the threads (ec_slot: interior groups first, boundary groups from the next wave
+    boundary, interior groups of the second slot updated late) on shapes at its edges: two slots with no room for the
+    pad (15 rows x 68 groups), five-row slabs (one interior row), four-row slabs (no interior row), a single slot, and
+    13-row slabs of 75 groups as in 100x300.  Bitwise traces and 2e-5 gradients against the oracle; conftest fails the
+    test if a time loop gave up and the per-step kernels produced the numbers."""
+    from physicsbasedfwi2_amd.elastic import ElasticPlan
+    monkeypatch.setenv("MIFWI_EL_NW", str(nw))
+    pl = ElasticPlan(nz, nx, 60, 2, 1, 12, 1, 6, 0)
+    assert pl.cluster_slabs(False) == nw and pl.cluster_slabs(True) == nw
+    _check_parity(oracle32, elastic_case(seed=61 + nz, nz=nz, nx=nx, fw=6, ns=2, nrec=12, nt=60), bitwise=True)
+
+
 def test_cluster_adjoint_source_paths_agree(oracle32, monkeypatch):
     """The single-launch adjoint adds its sources through a receiver-row buffer (plain LDS stores) where every tap of a
     slab has a cell of its own on at most four rows, and through LDS float atomics otherwise (MIFWI_EL_ADJ_DIRECT=0
