@@ -613,15 +613,19 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     float src_wt = 0.f;
     int smp_off = -1;                                    // sampling of `cur` (point index = t)
     float smp_w = 0.f;
-    // adjoint injection into LDS: LDS offset (18 bits) | receiver id (12 bits, fast variant: nrec <= 1024) |
+    // adjoint injection into LDS: LDS offset (16 bits: a level buffer is < 20 000 floats) | turn (2 bits) | receiver id (12 bits, fast variant: nrec <= 1024) |
     // "lies in a row the neighbours wait for" (bit 30), one register instead of three; -1 = none
     int inj_pack = -1;
     float inj_scale = 0.f;
     // unpacked from an opaque copy at every use: a hoisted field would take a register of its own again
-    auto inj_off = [&]() { return cl_opaque(inj_pack) & 0x3ffff; };
+    auto inj_off = [&]() { return cl_opaque(inj_pack) & 0xffff; };
+    auto inj_turn = [&]() { return (cl_opaque(inj_pack) >> 16) & 3; };
     auto inj_id = [&]() { return (cl_opaque(inj_pack) >> 18) & 0xfff; };
     constexpr bool slow_sparse = SLOW;                   // more points than one per thread: rescan per step
-    bool taps_unique = false;                            // adjoint: every receiver tap of the slab in a cell of its own
+    // adjoint sources without LDS float atomics: inj_turn() = the turn in which this thread adds its tap to its cell (0
+    // for a tap that has the cell to itself; taps sharing a cell take turns), tap_rounds = turns needed by the slab
+    // (workgroup-uniform; 0: atomics, the general path)
+    int tap_rounds = 0;
     if (!adj) {
         for (int e = 0; e < p.nsrc; ++e) {
             const int cell = p.src_cell[(long long)s * p.nsrc + e];
@@ -662,16 +666,26 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             inj_scale = rv * inv;
             smp_w = p.rec_w[(long long)s * p.nrec + id];          // reused as the tap weight
         }
-        // Do the taps of this slab sit in cells of their own?  Then the injection is a plain LDS read-add-write (the
-        // same single rounding) instead of ds_add_f32: a float atomic takes the LDS ~1500 clocks to drain, every step,
-        // in the slab that holds the receivers - the one all the others wait for.  One-off check through the (still
-        // empty) field plane.
+        // The injection is a plain LDS read-add-write (the same single rounding) instead of ds_add_f32: a float atomic
+        // takes the LDS ~1500 clocks to drain, every step, in the slab that holds the receivers - the one all the others
+        // wait for.  Taps that share a cell (bilinear taps of neighbouring receivers) take turns, lowest receiver number
+        // first, a barrier between turns: a fixed order of additions, unlike the atomics.  The turns are dealt once,
+        // through the (still empty) field plane.
         if (!slow_sparse && cnt > 0 && p.rcv_plain) {
             int *ib = reinterpret_cast<int *>(bufA);
-            if (inj_pack >= 0) ib[inj_pack & 0x3ffff] = t;
-            __syncthreads();
-            const int dup = (inj_pack >= 0 && ib[inj_pack & 0x3ffff] != t) ? 1 : 0;
-            taps_unique = __syncthreads_or(dup) == 0;
+            const int off = inj_pack & 0xffff, key = (inj_pack >> 18) & 0xfff;      // receiver number
+            bool waiting = inj_pack >= 0;
+            constexpr int kMaxRounds = 4;                 // bilinear taps of neighbouring receivers: 2-4 per cell (two bits)
+            int r = 0;
+            for (; r < kMaxRounds; ++r) {
+                if (waiting) ib[off] = 0x7fffffff;
+                __syncthreads();
+                if (waiting) atomicMin(&ib[off], key);
+                __syncthreads();
+                if (waiting && ib[off] == key) { inj_pack |= r << 16; waiting = false; }
+                if (!__syncthreads_or(waiting ? 1 : 0)) break;
+            }
+            tap_rounds = r < kMaxRounds ? r + 1 : 0;      // more than kMaxRounds taps in one cell: atomics
         }
         if (p.grad_f != nullptr && t < p.nsrc) {
             const int cell = p.src_cell[(long long)s * p.nsrc + t];
@@ -920,8 +934,15 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             if (!slow_sparse) {
                 if (inj_pack >= 0) {
                     float *cell = &prv[inj_off()];
-                    if (taps_unique) *cell = *cell + (smp_w * amp) * inj_scale;
-                    else atomicAdd(cell, (smp_w * amp) * inj_scale);
+                    if (tap_rounds == 0) atomicAdd(cell, (smp_w * amp) * inj_scale);
+                    else if (inj_turn() == 0) *cell = *cell + (smp_w * amp) * inj_scale;
+                }
+                for (int r = 1; r < tap_rounds; ++r) {       // taps that share a cell: one per turn, in a fixed order
+                    __syncthreads();
+                    if (inj_pack >= 0 && inj_turn() == r) {
+                        float *cell = &prv[inj_off()];
+                        *cell = *cell + (smp_w * amp) * inj_scale;
+                    }
                 }
             } else {
                 const int cnt = p.slab_cnt[s * p.NW + w];

@@ -190,9 +190,9 @@ def test_cluster_path_with_halo_handoff(oracle32, monkeypatch, nw, edge):
 
 
 def test_cluster_adjoint_source_paths_agree(oracle32, monkeypatch):
-    """Adjoint sources of the single-launch time loop: a plain LDS read-add-write where every tap of a slab has a cell of
-    its own, an LDS float atomic otherwise (MIFWI_AC_ADJ_PLAIN=0 forces it) - the same single rounding, the same bits.
-    Two receivers in one cell must take the atomic path by themselves."""
+    """Adjoint sources of the single-launch time loop: a plain LDS read-add-write instead of an LDS float atomic
+    (MIFWI_AC_ADJ_PLAIN=0 forces the atomic) - the same single rounding, the same bits where every tap has a cell of its
+    own.  Taps that share a cell take turns in a fixed order: oracle parity, and bit-identical repeats."""
     monkeypatch.setenv("MIFWI_AC_NW", "3")
     case = acoustic_case(seed=59, n0=61, n1=83, nb=9, nt=120, ns=2, nrec=40)
     outs = []
@@ -206,7 +206,9 @@ def test_cluster_adjoint_source_paths_agree(oracle32, monkeypatch):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     monkeypatch.delenv("MIFWI_AC_ADJ_PLAIN")
     rc = case["rc"].copy()
-    rc.reshape(2, -1)[:, 1] = rc.reshape(2, -1)[:, 0]             # two taps in one cell
+    rc.reshape(2, -1)[:, 1] = rc.reshape(2, -1)[:, 0]             # two taps in one cell,
+    rc.reshape(2, -1)[:, 5] = rc.reshape(2, -1)[:, 4]             # three in another: they take turns (lowest receiver
+    rc.reshape(2, -1)[:, 6] = rc.reshape(2, -1)[:, 4]             # number first), a fixed order of additions
     case["rc"] = rc
     o = oracle32
     rec_o, G_o = o.acoustic_forward(case["r"], case["q0"], case["q1"], case["f"], case["sc"], case["sw"], case["rc"],
@@ -219,6 +221,10 @@ def test_cluster_adjoint_source_paths_agree(oracle32, monkeypatch):
                                      g, G_o)
     assert rel_l2(r.grad.cpu().numpy(), gr_o) <= TOL_GRAD
     assert rel_l2(f.grad.cpu().numpy(), gf_o) <= TOL_GRAD
+    g1 = (r.grad.clone(), f.grad.clone())
+    r, f, rec = _run_hip(case)                                    # and the same bits every time
+    rec.backward(torch.tensor(g, device=rec.device))
+    assert torch.equal(g1[0], r.grad) and torch.equal(g1[1], f.grad)
 
 
 def test_cluster_and_per_step_paths_agree(monkeypatch):
