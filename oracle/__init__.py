@@ -6,8 +6,10 @@ Importable only from ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 
 PARITY STATUS: pinned against the reference's own numpy helpers
 (tests/golden/seisgan_helpers.npz), the analytical Green's function of
-accuracy.ipynb and the Taylor-gradient criterion of gradient_example.py.  Parity
-with deepwave / DENISE / Devito binaries is UNPINNED (none is present).
+accuracy.ipynb and the Taylor-gradient criterion of gradient_example.py; the elastic
+scheme against closed-form Cagniard - de Hoop solutions (full space, Garvin, Lamb:
+oracle/analytic_elastic.py, tests/test_elastic_analytic_pins.py).  Parity with the
+deepwave / DENISE / Devito BINARIES is unpinned (none is present).
 """
 import ctypes
 import os

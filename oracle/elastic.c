@@ -4,8 +4,18 @@
  * Plain-C CPU restatement of the 2-D P-SV elastic propagator the reference reaches through
  * `pyapi_denise` -> DENISE-Black-Edition (`d.forward`, `d.grad`: models/networks.py:7787,
  * 9853-9877; parameters 7698-7731, 9790-9833).  DENISE itself is a third-party MPI/C code that
- * is NOT in /root/reference and not installed here: PARITY WITH DENISE IS
- * UNPINNED.  The reference tree only fixes parameter names (FW/FPML/DAMPING/npower, FREE_SURF,
+ * is NOT in /root/reference and not installed here, and the reference's tests hold no
+ * vector for this path: parity with the DENISE BINARY is unpinned.  What IS pinned, independently of this file
+ * (tests/test_elastic_analytic_pins.py, fp64, oracle/analytic_elastic.py): the scheme below reproduces the
+ * closed-form Cagniard - de Hoop solutions of the P-SV equations -
+ *   full space, explosive source and both line forces: L-inf error 1.5e-2 / 3.0e-3 / 9.4e-4 of the peak at
+ *     h = 15 / 10 / 7.5 m (11-23 points per S wavelength), observed order 4.0 (FD_ORDER 2: order 1.8-2.0) -
+ *     amplitudes, wave speeds, every half-step / half-cell staggering convention;
+ *   Garvin's and Lamb's problems under the stress-imaging surface: second-order convergence with FD_ORDER 2;
+ *     with FD_ORDER 4 a 3-7 % error ON the surface that does not shrink with h (zero velocities above z = 0,
+ *     the image method as SOFI2D / DENISE apply it) and falls like h below it;
+ *   source-receiver reciprocity to round-off (4e-3 next to the fourth-order surface).
+ * The reference tree only fixes parameter names (FW/FPML/DAMPING/npower, FREE_SURF,
  * QUELLART/QUELLTYP, DH/DT/TIME) and the surrounding acquisition/normalisation code; the scheme
  * below is the published one DENISE implements, restated from the literature:
  *   - velocity-stress formulation on the standard staggered grid (Virieux 1986; Levander 1988),
