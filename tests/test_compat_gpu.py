@@ -168,22 +168,34 @@ def test_seisgan_fwiloss_matches_oracle(oracle32):
     sc, sw = H.bilinear_taps(sxy, h, nb, (N0, N1))
     rc, rw = H.bilinear_taps(rxy, h, nb, (N0, N1))
 
+    # The kernels and the fp32 oracle run the same fmaf chain, so they must be handed the same fp32 coefficients:
+    # r, q and f rounded the way the shim rounds them (float32 division of a float32 constant by the padded
+    # float32 model; float32 sponge profile and wavelet) - computed in float64 and rounded afterwards they differ
+    # in the last bit and the loss moves by 1e-4 (round 2's bounds were 2e-4 / 2e-3 for that reason alone).
+    _, q0_64, q1_64, _, _ = H.acoustic_coeffs(np.ones((N0, N1)), d0, d1, dt, h)
+    q0, q1, f32 = conf.q0.numpy(), conf.q1.numpy(), conf.f.cpu().numpy()          # the shim's fp32 roundings ...
+    assert np.allclose(q0, q0_64, rtol=1e-6, atol=0) and np.allclose(q1, q1_64, rtol=1e-6, atol=0)
+    assert np.allclose(f32, f, rtol=1e-6, atol=0)                                  # ... of the oracle-side formulas
+    f = f32
+    cst = np.float32(dt * dt / 100.0)
+
     def run(m):
-        r, q0, q1, c0, c1 = H.acoustic_coeffs(H.pad_edge(m.astype(np.float64), nb), d0, d1, dt, h)
-        rec, G = oracle32.acoustic_forward(r, q0, q1, f, sc, sw, rc, rw, c0, c1, save=True)
+        mp = H.pad_edge(m.astype(np.float32), nb)
+        r = cst / mp
+        rec, G = oracle32.acoustic_forward(r, q0, q1, f, sc, sw, rc, rw, 1.0, 1.0, save=True)
         syn = np.zeros_like(rec); syn[1:nt - 1] = rec[0:nt - 2]
-        return r, q0, q1, syn, G
-    _, _, _, obs, _ = run(m_true)
-    r, q0, q1, syn, G = run(m0)
+        return r, mp, syn, G
+    _, _, obs, _ = run(m_true)
+    r, mp, syn, G = run(m0)
+    assert rel_l2(conf.true_ds.cpu().numpy(), obs) < 1e-6
     res = syn - obs
     J = 0.5 * np.sum(res.astype(np.float64) ** 2)
-    assert abs(float(loss) - J) <= 2e-4 * J
+    assert abs(float(loss) - J) <= 2e-5 * J
     g = np.zeros_like(res); g[0:nt - 2] = res[1:nt - 1]
     gr, _ = oracle32.acoustic_backward(r, q0, q1, sc, sw, rc, rw, g, G, want_grad_f=False)
-    mp = H.pad_edge(m0.astype(np.float64), nb)
-    gm = (gr * (-(dt * dt / 100.0) / mp ** 2))[nb:-nb, nb:-nb]
+    gm = (gr.astype(np.float64) * (-np.float64(cst) / mp.astype(np.float64) ** 2))[nb:-nb, nb:-nb]
     gm = gm / np.abs(gm).max()
-    assert rel_l2(x.grad[0, 0].cpu().numpy(), gm) < 2e-3
+    assert rel_l2(x.grad[0, 0].cpu().numpy(), gm) < 2e-5
     assert float(x.grad.abs().max()) == pytest.approx(1.0)
 
 

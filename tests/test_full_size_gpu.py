@@ -455,3 +455,76 @@ def test_reference_elastic_grids_vs_oracle(oracle32, nz, nx, ns, nrec, fs):
     for k in range(5):
         assert rel_l2(mat.grad[k].cpu().numpy(), gm_o[k]) <= 2e-5, k
     assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 2e-5
+
+
+@pytest.mark.parametrize("ns", [1, 3])
+def test_c1_seisgan_shape_vs_oracle(oracle32, ns):
+    """BASELINE config 1 at its own size: 200x200 + 20-cell sponge (240x240), bilinear (4-tap) source and 200
+    bilinear receivers on a line (layers.py:81-89, 137-142), 1000 steps, 1 and 3 shots.  The taps are flattened
+    to single-cell points so that the single-launch time loop serves it (neighbouring receivers then share
+    cells: the turn-taking injection of the adjoint); against the C oracle with its native 4-tap points:
+    traces <= 1e-6 (the taps of a point are summed in another order), gradients <= 2e-5."""
+    from oracle import helpers as H
+    from physicsbasedfwi2_amd import acoustic
+    nt, nb = 1000, 20
+    case = acoustic_case(seed=53, n0=200, n1=200, nb=nb, nt=nt, ns=ns, nrec=200, ntap=4)
+    h = case["h"]
+    sxy = np.zeros((ns, 1, 2)); sxy[:, 0, 0] = np.linspace(20.0, 1980.0, ns) if ns > 1 else 100.0; sxy[:, 0, 1] = 20.0
+    rxy = np.zeros((ns, 200, 2)); rxy[:, :, 0] = np.linspace(0, 200 * 10.0, 200)[None]; rxy[:, :, 1] = 20.0
+    case["sc"], case["sw"] = H.bilinear_taps(sxy, h, nb, (240, 240))
+    case["rc"], case["rw"] = H.bilinear_taps(rxy, h, nb, (240, 240))
+    dev = torch.device(DEV)
+    r = torch.tensor(case["r"], dtype=torch.float32, device=dev, requires_grad=True)
+    f = torch.tensor(case["f"], dtype=torch.float32, device=dev, requires_grad=True)
+    geom = acoustic._Geometry(torch.tensor(case["sc"]), torch.tensor(case["sw"]), torch.tensor(case["rc"]),
+                              torch.tensor(case["rw"]), dev)
+    assert acoustic._flatten_taps_pays(r, f, geom, 1.0, 1.0, nb)      # the single-launch path is what runs
+    rec = acoustic.propagate(r, f, torch.tensor(case["q0"]), torch.tensor(case["q1"]), torch.tensor(case["sc"]),
+                             torch.tensor(case["sw"]), torch.tensor(case["rc"]), torch.tensor(case["rw"]),
+                             case["c0"], case["c1"], edge_rows=nb)
+    o = oracle32
+    rec_o, G_o = o.acoustic_forward(case["r"], case["q0"], case["q1"], case["f"], case["sc"], case["sw"],
+                                    case["rc"], case["rw"], case["c0"], case["c1"], save=True)
+    assert np.abs(rec_o).max() > 0 and rel_l2(rec.detach().cpu().numpy(), rec_o) <= 1e-6
+    g = (rec_o / np.abs(rec_o).max()).astype(np.float32)
+    rec.backward(torch.tensor(g, device=dev))
+    gr_o, gf_o = o.acoustic_backward(case["r"], case["q0"], case["q1"], case["sc"], case["sw"], case["rc"],
+                                     case["rw"], g, G_o, case["c0"], case["c1"])
+    assert rel_l2(r.grad.cpu().numpy(), gr_o) <= 2e-5
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 2e-5
+
+
+def test_marmousi2_10m_grid_vs_oracle(oracle32):
+    """The 350x1700 grid of the bench's third line (10 m Marmousi-II) against the oracle:
+    2 shots x 40 steps through the per-step kernels the plan picks at this size (fused V+S forward, S^T / V^T
+    adjoint pair) - one shot under the top C-PML, one in the bottom-right corner: seismograms bit for bit, the
+    five material gradients and the source gradient <= 2e-5."""
+    from oracle import helpers as H
+    from physicsbasedfwi2_amd import elastic
+    from physicsbasedfwi2_amd.elastic import ElasticPlan
+    nz, nx, nt, ns, fw = 350, 1700, 40, 2, 10
+    c = elastic_case(seed=59, nz=nz, nx=nx, fw=fw, nt=nt, ns=ns, nrec=82, h=10.0, dt=0.001, water=20, freq=25.0)
+    xs = np.arange(790, 913, 3)
+    sz, sx = [[4], [nz - 7]], [[850], [nx - 6]]
+    xc = nx - 1 - np.arange(2, 84, 2)
+    rz = [np.r_[np.full(41, 2), np.full(41, 12)], np.r_[np.full(41, nz - 4), np.full(41, nz - 12)]]
+    rx = [np.r_[xs, xs], np.r_[xc, xc]]
+    c["sc"], c["sw"] = H.cell_taps(np.array(sz), np.array(sx), nx)
+    c["rc"], c["rw"] = H.cell_taps(np.array(rz), np.array(rx), nx)
+    pl = ElasticPlan(nz, nx, nt, ns, 1, 82, 1, fw, 0)
+    assert pl.cluster_slabs(False) == 0 and pl.cluster_slabs(True) == 0
+    o = oracle32
+    ovx, ovz, S = o.elastic_forward(c["mat"], c["pz"], c["px"], c["f"], c["sc"], c["sw"], c["rc"], c["rw"], save=True)
+    mat, f, rvx, rvz = _elastic(c)
+    hx, hz = rvx.detach().cpu().numpy(), rvz.detach().cpu().numpy()
+    for s in range(ns):
+        assert np.abs(ovx[:, s]).max() > 0 and np.abs(ovz[:, s]).max() > 0
+    assert np.abs(hx - ovx).max() == 0.0 and np.abs(hz - ovz).max() == 0.0
+    gx, gz = np.sign(ovx).astype(np.float32), np.sign(ovz).astype(np.float32)
+    torch.autograd.backward([rvx, rvz], [torch.tensor(gx, device=DEV), torch.tensor(gz, device=DEV)])
+    gm_o, gf_o = o.elastic_backward(c["mat"], c["pz"], c["px"], c["sc"], c["sw"], c["rc"], c["rw"], gx, gz, S)
+    del S
+    gm_h = mat.grad.cpu().numpy()
+    for k in range(5):
+        assert np.abs(gm_o[k]).max() > 0 and rel_l2(gm_h[k], gm_o[k]) <= 2e-5, k
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 2e-5
