@@ -160,18 +160,49 @@ def butterworth(x, dt, fc_low=0.0, fc_high=0.0, order=6, zero_phase=False):
     return torch.fft.irfft(spec, n=nfft, dim=0)[:nt]
 
 
-def read_su(path):
-    """Minimal SU reader (240-byte trace header + ns native float32 samples, as DENISE writes):
-    returns (data [ntraces, ns], dt seconds)."""
+def read_su(path, endian=None, headers=False):
+    """SU reader for the `.su.shot<k>` gathers DENISE writes and the reference copies around (networks.py:7669-7692):
+    a sequence of traces, each a 240-byte SEG-Y trace header followed by ns IEEE float32 samples, no file header.
+    Header words read (1-based byte positions of the SEG-Y / SU trace header): ns at 115-116 and dt [microseconds]
+    at 117-118, both unsigned 16-bit; with ``headers=True`` also tracl 1-4, fldr 9-12, scalco 71-72, sx 73-76,
+    sy 77-80, gx 81-84, gy 85-88 (signed).  ``endian``: '<' (native SU on x86, what DENISE writes), '>' (XDR SU /
+    SEG-Y order) or None = whichever makes the file a whole number of equal traces (little-endian when both do).
+    Returns (data [ntraces, ns] float32, dt seconds) and the header dict when asked.  A file that is not a whole
+    number of traces in either byte order raises."""
     raw = open(path, "rb").read()
-    ns = struct.unpack_from("<H", raw, 114)[0]
-    dt_us = struct.unpack_from("<H", raw, 116)[0]
+    if len(raw) < 240:
+        raise MifwiError("%s: %d bytes, shorter than one SU trace header" % (path, len(raw)))
+
+    def fits(e):
+        ns = struct.unpack_from(e + "H", raw, 114)[0]
+        return ns > 0 and len(raw) % (240 + 4 * ns) == 0
+
+    if endian is None:
+        ok = [e for e in ("<", ">") if fits(e)]
+        if not ok:
+            raise MifwiError("%s: not a whole number of SU traces in either byte order (ns = %d / %d, %d bytes)"
+                             % (path, struct.unpack_from("<H", raw, 114)[0], struct.unpack_from(">H", raw, 114)[0],
+                                len(raw)))
+        endian = ok[0]
+    elif endian not in ("<", ">") or not fits(endian):
+        raise MifwiError("%s: not a whole number of SU traces with byte order %r" % (path, endian))
+    ns = struct.unpack_from(endian + "H", raw, 114)[0]
+    dt_us = struct.unpack_from(endian + "H", raw, 116)[0]
     tl = 240 + 4 * ns
     ntr = len(raw) // tl
     out = np.empty((ntr, ns), dtype=np.float32)
+    hdr = {k: np.empty(ntr, dtype=np.int64) for k in ("tracl", "fldr", "scalco", "sx", "sy", "gx", "gy", "ns", "dt")}
     for i in range(ntr):
-        out[i] = np.frombuffer(raw, dtype="<f4", count=ns, offset=i * tl + 240)
-    return out, dt_us * 1e-6
+        o = i * tl
+        if struct.unpack_from(endian + "H", raw, o + 114)[0] != ns:
+            raise MifwiError("%s: trace %d has another sample count than trace 0" % (path, i))
+        out[i] = np.frombuffer(raw, dtype=endian + "f4", count=ns, offset=o + 240)
+        if headers:
+            hdr["tracl"][i], hdr["fldr"][i] = struct.unpack_from(endian + "i", raw, o)[0], struct.unpack_from(endian + "i", raw, o + 8)[0]
+            hdr["scalco"][i] = struct.unpack_from(endian + "h", raw, o + 70)[0]
+            hdr["sx"][i], hdr["sy"][i], hdr["gx"][i], hdr["gy"][i] = struct.unpack_from(endian + "4i", raw, o + 72)
+            hdr["ns"][i], hdr["dt"][i] = ns, struct.unpack_from(endian + "H", raw, o + 116)[0]
+    return (out, dt_us * 1e-6, hdr) if headers else (out, dt_us * 1e-6)
 
 
 def write_su(path, data, dt):
@@ -214,7 +245,9 @@ class Denise:
         self.DT = None
         self.NPROCX = 1
         self.NPROCY = 1
-        self.FD_ORDER = 4
+        # the reference never sets FD_ORDER (`#d.FD_ORDER = 4` is commented out, networks.py:10447), so every prop()
+        # runs the pyapi_denise default, recorded as 2 in SURVEY.md appendix C: same default here (4 on request)
+        self.FD_ORDER = 2
         self.FW = 10
         self.DAMPING = 1500.0
         self.FPML = 10.0

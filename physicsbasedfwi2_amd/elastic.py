@@ -7,6 +7,7 @@ Stands where ``d.forward`` / ``d.grad`` of pyapi_denise stand in the reference
 with no mpirun and no files.  All wave arithmetic is in libmifwi.so; there is no CPU path.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -125,14 +126,26 @@ class ElasticPlan:
             pass
 
 
+class _ArenaLease:
+    """Held by the autograd node whose forward wrote the arena's tensor; dies with the node (a graph dropped without a
+    backward frees the arena too)."""
+
+    def __init__(self):
+        self.released = False
+
+
 class _SnapshotArena:
     """One snapshot tensor shared by consecutive propagate() calls (gradient_in_shot_chunks): the first call allocates
     it, later ones whose snapshots are not larger take a prefix - no call pays a malloc of >100 GB again, and chunks need
-    not be of equal size to hit torch's cached block."""
+    not be of equal size to hit torch's cached block.  The tensor has ONE owner at a time: a forward leases it, the
+    matching backward (or the death of its graph) gives it back; a second forward in between - two components, a
+    forward inside a loss closure, retain_graph - does not get it and allocates snapshots of its own, so its
+    predecessor's planes are never overwritten."""
     current = None
 
     def __init__(self):
         self.buf = None
+        self._lease = None          # weakref to the _ArenaLease of the forward whose snapshots live in buf
 
     def __enter__(self):
         self._prev, _SnapshotArena.current = _SnapshotArena.current, self      # re-entering keeps the tensor
@@ -141,11 +154,21 @@ class _SnapshotArena:
     def __exit__(self, *exc):
         _SnapshotArena.current = self._prev
         self.buf = None
+        self._lease = None
         return False
+
+    def busy(self):
+        lease = self._lease() if self._lease is not None else None
+        return lease is not None and not lease.released
+
+    def lease(self):
+        lease = _ArenaLease()
+        self._lease = weakref.ref(lease)
+        return lease
 
     def take(self, nt, elems, dev):
         need = nt * elems
-        if self.buf is None or self.buf.device != dev or self.buf.numel() < need:
+        if self.busy() or self.buf is None or self.buf.device != dev or self.buf.numel() < need:
             return None
         return self.buf[:need].view(nt, elems)
 
@@ -192,8 +215,11 @@ class _ElasticFn(torch.autograd.Function):
             step_bytes = 4 * lay.snap_step_elems
             seg, snap, ckpt = nt, None, None
             arena = _SnapshotArena.current
+            lease = None
             if need_grad and arena is not None:
                 snap = arena.take(nt, lay.snap_step_elems, dev)       # memory already held: no budget question
+                if snap is not None:
+                    lease = arena.lease()
             if need_grad and snap is None:
                 # never plan for more than most of the memory that is free right now (other tensors of
                 # the training loop share the device); segmentation does not change the results
@@ -205,6 +231,7 @@ class _ElasticFn(torch.autograd.Function):
                     snap = torch.empty((nt, lay.snap_step_elems), device=dev, dtype=torch.float32)
                     if arena is not None and arena.buf is None:
                         arena.buf = snap.view(-1)
+                        lease = arena.lease()
             args = (plan.handle, _lib.ptr(mat_p), _lib.ptr(pz_d), _lib.ptr(px_p), _lib.ptr(f_d),
                     _lib.ptr(geom.src_cell), _lib.ptr(geom.src_w), _lib.ptr(geom.rec_cell),
                     _lib.ptr(geom.rec_w), _lib.ptr(rvx), _lib.ptr(rvz))
@@ -222,6 +249,7 @@ class _ElasticFn(torch.autograd.Function):
                                                          _stream()))
             if need_grad:
                 ctx.plan, ctx.geom, ctx.seg, ctx.ckpt, ctx.snap = plan, geom, seg, ckpt, snap
+                ctx.lease = lease
                 ctx.dims = (nz, nx, nt, ns, nsrc, nrec)
                 ctx.need_f = f.requires_grad
                 ctx.record_pressure = record_pressure
@@ -288,6 +316,9 @@ class _ElasticFn(torch.autograd.Function):
             ctx.plan = None
             ctx.snap = None
             ctx.ckpt = None
+            if ctx.lease is not None:               # the arena's tensor may serve the next forward
+                ctx.lease.released = True
+                ctx.lease = None
         return (grad_mat[:, :, :nx].contiguous(), grad_f) + (None,) * 11
 
 

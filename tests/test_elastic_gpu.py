@@ -434,3 +434,45 @@ def test_gradient_in_shot_chunks_equals_the_all_shots_gradient():
         assert rel_l2(gm1, gm0) <= 2e-6 and rel_l2(gf1, gf0) <= 2e-6
     assert elastic.resident_shot_chunk(32, 3000, 350, 1700) == 2        # 35.7 GB of f32 planes per shot, 96 GB budget
     assert elastic.resident_shot_chunk(32, 3000, 100, 300) == 32 and elastic.resident_shot_chunk(16, 5000, 1000, 3000) == 0
+
+
+def test_snapshot_arena_has_one_owner_at_a_time():
+    """Two forward passes inside one `elastic.snapshot_arena()` before either backward (two components, a forward
+    inside a loss closure, retain_graph): the second must NOT be handed the tensor the first still needs - it gets
+    snapshots of its own - and once a backward has consumed the arena's planes the next forward may reuse them.
+    Gradients equal those of the same passes run without an arena, bit for bit."""
+    from physicsbasedfwi2_amd import elastic
+    ca = elastic_case(seed=101, nz=50, nx=90, fw=8, ns=3, nrec=20, nt=70)
+    cb = elastic_case(seed=103, nz=50, nx=90, fw=8, ns=3, nrec=20, nt=70)
+
+    def fwd(c):
+        mat, f, rvx, rvz = _run_hip(c)
+        return mat, f, rvx, rvz
+
+    def grads(use_arena):
+        import contextlib
+        ctx = elastic.snapshot_arena() if use_arena else contextlib.nullcontext()
+        with ctx as arena:
+            ma, fa, ax, az = fwd(ca)
+            mb, fb, bx, bz = fwd(cb)                              # before a's backward
+            if use_arena:
+                assert arena.busy()
+            torch.autograd.backward([bx, bz], [torch.sign(bx.detach()), torch.sign(bz.detach())])
+            torch.autograd.backward([ax, az], [torch.sign(ax.detach()), torch.sign(az.detach())])
+            if use_arena:
+                assert not arena.busy()                           # a's backward gave the tensor back
+            mc, fc, cx, cz = fwd(ca)                              # may take the arena's tensor again
+            if use_arena:
+                assert arena.busy()
+            torch.autograd.backward([cx, cz], [torch.sign(cx.detach()), torch.sign(cz.detach())])
+            md, fd_, dx, dz = fwd(cb)
+            del md, fd_, dx, dz                                   # a graph dropped without a backward frees it too
+            if use_arena:
+                import gc
+                gc.collect()
+                assert not arena.busy()
+        return [t.grad.clone() for t in (ma, fa, mb, fb, mc, fc)]
+    plain, shared = grads(False), grads(True)
+    for p, s in zip(plain, shared):
+        assert float(p.abs().max()) > 0 and torch.equal(p, s)
+    assert torch.equal(plain[0], plain[4])                        # the third pass repeats the first
