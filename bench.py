@@ -131,7 +131,7 @@ class AcousticMarmousi:
     # an LDS-resident time loop only has to move the snapshot stream (G^n, 4 B/cell-step out, 4 back in)
     resident_fwd_bytes, resident_adj_bytes = 4.0, 4.0
 
-    def __init__(self, dev, rank, world, nt=None, shots=None, grid=None):
+    def __init__(self, dev, rank, world, nt=None, shots=None, grid=None, span=None):
         import torch
         import physicsbasedfwi2_amd.compat.deepwave as deepwave
         from physicsbasedfwi2_amd import misfit
@@ -142,12 +142,15 @@ class AcousticMarmousi:
         if grid:
             self.nz, self.nx = grid
         ns = shots or self.shots_per_gpu
-        if grid or shots or nt:
-            self.name = "acoustic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, ns, self.nt)
+        total, lo = ns * world, rank * ns
+        if span:                               # strong scaling: this rank's block [lo, hi) of `total` shots
+            total, lo, hi = span
+            ns = hi - lo
+        if grid or shots or nt or span:
+            self.name = "acoustic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, total if span else ns, self.nt)
         self.ns = ns
-        total = ns * world
         xs_all = np.linspace(0.0, (self.nx - 1) * self.h, total)
-        xs = xs_all[rank * ns:(rank + 1) * ns]
+        xs = xs_all[lo:lo + ns]
         self.x_s = torch.zeros(ns, 1, 2)
         self.x_s[:, 0, 1] = torch.tensor(xs, dtype=torch.float32)
         self.x_r = torch.zeros(ns, self.nx, 2)
@@ -287,7 +290,7 @@ class ElasticMarmousi:
     src_depth, rec_depth, rec_dx, x_first, x_margin, rec_x_max = 40.0, 460.0, 20.0, 380.0, 120.0, 5880.0
     free_surface = False
 
-    def __init__(self, dev, rank, world, nt=None, shots=None, grid=None):
+    def __init__(self, dev, rank, world, nt=None, shots=None, grid=None, span=None):
         import torch
         from physicsbasedfwi2_amd import elastic, misfit, profiles
         self.torch, self.elastic, self.dev, self.misfit = torch, elastic, dev, misfit
@@ -299,8 +302,12 @@ class ElasticMarmousi:
         if grid:
             self.nz, self.nx = grid
         ns = shots or self.shots_per_gpu
-        if grid or shots or nt:
-            self.name = "elastic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, ns, self.nt)
+        total, lo = ns * world, rank * ns
+        if span:                               # strong scaling: this rank's block [lo, hi) of `total` shots
+            total, lo, hi = span
+            ns = hi - lo
+        if grid or shots or nt or span:
+            self.name = "elastic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, total if span else ns, self.nt)
         self.ns = ns
         # A shortened time axis (kernel measurements on the big grids) would end before the source wavelet has
         # peaked and long before anything has come back from below the water layer, which the model and the
@@ -314,9 +321,8 @@ class ElasticMarmousi:
             src_depth = 30 * self.h
             rec_depth = src_depth + 3 * self.h
             freq = max(self.freq, 6.0 / (self.nt * self.dt))
-        total = ns * world
         xs_all = np.linspace(self.x_first, (self.nx - 1) * self.h - self.x_margin, total)
-        xs = xs_all[rank * ns:(rank + 1) * ns]
+        xs = xs_all[lo:lo + ns]
         _, _, sc = profiles.cells_round(xs, np.full(ns, src_depth), self.h, self.nx)
         xr = np.arange(self.x_first, min(self.rec_x_max, (self.nx - 2) * self.h) + self.h, self.rec_dx)
         _, _, rc = profiles.cells_round(xr, np.full(xr.size, rec_depth), self.h, self.nx)
@@ -624,6 +630,17 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
     if steps is not None:                   # secondary workloads may time fewer passes (stated in their entry)
         args = copy.copy(args)
         args.steps, args.warmup = steps, warmup
+    strong = getattr(args, "scaling", "weak") == "strong"
+    total_shots = 0
+    if strong:
+        # strong scaling: the configuration's own shot count (C2: 29, C3: 32; --total-shots overrides) split over the
+        # ranks in balanced contiguous blocks - 29 shots on 8 ranks are 4,4,4,4,4,3,3,3
+        from physicsbasedfwi2_amd import dist as mdist
+        total_shots = args.total_shots or WORKLOADS[name].shots_per_gpu
+        lo, hi = mdist.shot_partition_balanced(total_shots, rank, world)
+        if hi <= lo:
+            raise SystemExit("bench --scaling strong: rank %d of %d owns no shot of %d" % (rank, world, total_shots))
+        kw["span"] = (total_shots, lo, hi)
     wl = WORKLOADS[name](dev, rank, world, nt=args.nt or None, shots=args.shots or None, **kw)
 
     def barrier():
@@ -631,11 +648,22 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
             dist.barrier()
         torch.cuda.synchronize()
 
+    rank_events = []
+
     def one_step(timed):
+        # events on the launch stream: [start | gradient pass done | all-reduce done]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
+        if ev:
+            ev[0].record()
         grad, loss = wl.step(timed)
+        if ev:
+            ev[1].record()
         if world > 1:
             from physicsbasedfwi2_amd import dist as mdist
             mdist.all_reduce_gradient([grad], loss)
+        if ev:
+            ev[2].record()
+            rank_events.append(ev)
         return grad, loss
 
     for _ in range(args.warmup):
@@ -658,16 +686,36 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
     losses = [float(v) for v in losses]
     gsums = [float(v) for v in gsums]
     deterministic = all(v == losses[0] for v in losses) and all(v == gsums[0] for v in gsums)
+    # per-rank breakdown (outside the timed region): gradient pass and all-reduce of every rank, so that a scaling
+    # curve explains itself - the slowest rank's pass, the spread, and what the one collective per pass costs
+    pass_ms = sum(e[0].elapsed_time(e[1]) for e in rank_events) / max(1, len(rank_events))
+    ar_ms = sum(e[1].elapsed_time(e[2]) for e in rank_events) / max(1, len(rank_events))
+    ranks = {"world_size_seen": world, "backend": "none", "shots_per_rank": [wl.ns],
+             "pass_ms_per_rank": [pass_ms], "all_reduce_ms_per_rank": [ar_ms]}
+    units_all = float(wl.units_per_step) * (1 if strong else world)
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+        mine = torch.tensor([pass_ms, ar_ms, float(wl.ns), float(wl.units_per_step)], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().numpy()
+        ranks = {"world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                 "shots_per_rank": [int(v) for v in allr[:, 2]],
+                 "pass_ms_per_rank": [float(v) for v in allr[:, 0]],
+                 "all_reduce_ms_per_rank": [float(v) for v in allr[:, 1]]}
+        units_all = float(allr[:, 3].sum())
+    ranks["pass_ms_min"], ranks["pass_ms_max"] = min(ranks["pass_ms_per_rank"]), max(ranks["pass_ms_per_rank"])
+    ranks["all_reduce_ms_max"] = max(ranks["all_reduce_ms_per_rank"])
+    ranks["all_reduce_note"] = ("event time on the launch stream from the end of this rank's pass to the end of its "
+                                "all-reduce: includes waiting for the slowest rank")
     if rank != 0:
         return None
     if not args.timing_only and not (np.isfinite(losses[0]) and losses[0] > 1e-25 and gsums[0] > 1e-25):
         raise SystemExit("bench: the timed pass produced loss %.3g, |grad| sum %.3g - nothing reached the receivers, "
                          "the kernels were timed on zeros" % (losses[0], gsums[0]))
-    value = wl.units_per_step * world * args.steps / el / 1e6
+    value = units_all * args.steps / el / 1e6
     t_f, t_b = wl.kernel_times()
     kernel_note = None
     nt_res = wl.resident_nt()
@@ -704,14 +752,17 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
         "metric": "grid-cells*timesteps/sec (forward+adjoint gradient pass)",
         "value": value, "unit": "Mcells*steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": wl.name, "shots_per_gpu": wl.ns, "nt": wl.nt,
-                   "grid": [wl.nz, wl.nx], "parallelism": "shots x%d" % world,
+                   "grid": [wl.nz, wl.nx],
+                   "parallelism": ("%d shots over %d ranks (balanced contiguous blocks)" % (total_shots, world)
+                                   if strong else "shots x%d" % world),
                    "cells": "interior cells of the physical grid in value, kernels and roofline alike",
                    "kernel_family": wl.kernel_family(),
                    "snapshots": getattr(wl, "elastic", None) and wl.elastic.snapshot_mode() or "f32"},
         "check": check,
+        "ranks": ranks,
         "roofline": roofline_of(kern, dom, interior),
         "kernels": kern,
     }
@@ -738,14 +789,34 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
     return out
 
 
+def visible_gpus():
+    """GPU agents of the KFD topology (nodes with SIMDs), capped by HIP_/ROCR_VISIBLE_DEVICES - counted from /sys so
+    that the launching parent stays free of any HIP context; None when the topology cannot be read (the ranks then
+    find out by themselves and the parent reports their exit codes)."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args, argv):
     """--gpus N without a launcher: start N ranks of this script (one per GPU, rendezvous on 127.0.0.1) from a
     parent that never touches the GPU, pass rank 0's JSON line through, fail if any rank fails."""
-    import torch
     n = args.gpus
     if args.device_index < 0 and args.backend == "nccl":
-        have = torch.cuda.device_count()            # does not initialise the GPU on this image
-        if have < n:
+        have = visible_gpus()                        # from /sys: the parent never loads the HIP runtime
+        if have is not None and have < n:
             raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (n, have))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -791,6 +862,10 @@ def main():
                     help="skip the untimed cross-check of the two kernel families (counter / ablation runs)")
     ap.add_argument("--timing-only", action="store_true",
                     help="ablation builds (wrong results by construction): no cross-check, no refusal of a zero loss")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, the driver's contract): every rank runs the configuration's per-GPU shot count; "
+                         "strong: the configuration's shots (--total-shots) are split over the ranks")
+    ap.add_argument("--total-shots", type=int, default=0, help="shots of the whole job with --scaling strong")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the secondary workloads of the default invocation")
     args = ap.parse_args()
@@ -825,7 +900,7 @@ def main():
     primary = args.workload or "elastic_marmousi"
     out = run_workload(primary, args, dev, rank, world, want_cpu)
     if args.workload is None and not args.no_also:
-        keys = ("config", "value", "unit", "steps", "warmup", "ms_per_step", "check", "roofline", "kernels",
+        keys = ("config", "value", "unit", "steps", "warmup", "ms_per_step", "check", "ranks", "roofline", "kernels",
                 "kernels_note", "cpu_baseline", "note")
         also = [run_workload("acoustic_marmousi", args, dev, rank, world, want_cpu)]
         # BASELINE names no elastic grid - the same survey on the 10 m Marmousi-II grid 350x1700, where

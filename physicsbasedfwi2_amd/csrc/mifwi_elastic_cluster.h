@@ -200,7 +200,7 @@ struct EcHandoff {
         }
     }
 
-    // Hand-off receive in two halves, so that the flight of the first pass hides behind an update:
+    // Hand-off receive in two halves:
     //   request(): one pass of loads of ALL of this thread's granules, back to back (one memory round trip per
     //              pass, not one per granule), nothing waits;
     //   complete(): examine that pass; while a tag is missing, nap and sweep again (bounded: a time-out sets
@@ -208,14 +208,6 @@ struct EcHandoff {
     struct Pending {
         const unsigned long long *base;
         unsigned long long v[kEcGr];
-        // Keeps the granule registers reserved for the whole time loop (call once per iteration).  Otherwise the
-        // compiler reuses them for temporaries of the updates and, not knowing across the loop's back edge that the
-        // last sweep has landed, guards each reuse with an s_waitcnt vmcnt - which then waits for the early pass.
-        __device__ __forceinline__ void keep()
-        {
-#pragma unroll
-            for (int k = 0; k < kEcGr; ++k) asm volatile("" : "+v"(v[k]));
-        }
         __device__ __forceinline__ void clear()
         {
             base = nullptr;
@@ -237,7 +229,7 @@ struct EcHandoff {
         sweep(q);
     }
     template <class Dest>
-    __device__ __forceinline__ void complete(Pending &q, unsigned epoch, bool early, Dest dest)
+    __device__ __forceinline__ void complete(Pending &q, unsigned epoch, Dest dest)
     {
         int lo[kEcGr];
         unsigned need[kEcGr];                  // all ones where this thread has a k-th granule
@@ -256,8 +248,7 @@ struct EcHandoff {
                 failed = true;
                 break;
             }
-            // the early pass was requested before the update it hid behind: look again at once, nap from then on
-            if (spins > 0 || !early) mifwi::poll_nap(nap);
+            mifwi::poll_nap(nap);
             sweep(q);
         }
 #pragma unroll
@@ -275,7 +266,7 @@ struct EcHandoff {
     {
         Pending q;
         request(q, kind, parity);
-        complete(q, epoch, false, dest);
+        complete(q, epoch, dest);
     }
 
     // publish the four cells of a boundary-row group (local row lrw, group gq): b = the field a forward
@@ -671,20 +662,12 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     EcHandoff X;
     X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, (kDbg(p) & 4) != 0, p.nap, fsz);
     const bool do_x = p.NW > 1 && !(kDbg(p) & 1);
-    // The first pass of a poll is requested before the wave's last interior update and examined after it (its
-    // flight hides behind the update); q_req = that group slot, -1: this wave has no interior group
     EcHandoff::Pending P;
     P.clear();
-    int q_req = -1;
-#ifdef EC_EARLY_POLL
-#pragma unroll
-    for (int q = 0; q < NG; ++q)
-        if (__any(G[q].cls == 1)) q_req = q;
-#endif
     auto complete = [&](int kind, unsigned epoch) {
         // planes [vx | vz] and [szz | sxz]: the offset already selects the second one for the A field
         float *base = kind == 0 ? c.Lf[F_VX] : c.Lf[F_SZZ];
-        X.complete(P, epoch, q_req >= 0, [&](int off, float v) { base[off] = v; });
+        X.complete(P, epoch, [&](int off, float v) { base[off] = v; });
     };
     // source term of step n for the cells of a group
     auto source_amp = [&](const EcGroup &g, int q, int n) -> float4 {
@@ -764,13 +747,12 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         const bool poll_s = do_x && it > 0 && !(kDbg(p) & 32);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (poll_s && q == q_req) X.request(P, 1, (it - 1) & 1);
             if ((!EC_LATE_INTERIOR || q == 0) && ec_opaque(G[q].cls) == 1) do_v(G[q], n, it, false);
             __builtin_amdgcn_sched_barrier(0);             // one group at a time: bounds the register peak
         }
         EC_STAMP(1);
         if (poll_s) {
-            if (q_req < 0) X.request(P, 1, (it - 1) & 1);
+            X.request(P, 1, (it - 1) & 1);
             complete(1, (unsigned)(2 * it));
         }
         EC_STAMP(2);
@@ -790,13 +772,12 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         const bool poll_v = do_x && !(kDbg(p) & 32);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (poll_v && q == q_req) X.request(P, 0, it & 1);
             if ((!EC_LATE_INTERIOR || q == 0) && ec_opaque(G[q].cls) == 1) do_s(G[q], q, n, it, false);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(6);
         if (poll_v) {
-            if (q_req < 0) X.request(P, 0, it & 1);
+            X.request(P, 0, it & 1);
             complete(0, (unsigned)(2 * it + 1));
         }
         EC_STAMP(7);
@@ -845,9 +826,6 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         } else {
             __syncthreads();                               // D: all stresses of the slab are in LDS
         }
-#ifdef EC_EARLY_POLL
-        P.keep();
-#endif
         EC_STAMP(11);
     }
 
@@ -1133,14 +1111,8 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     EcHandoff X;
     X.init(p.xbuf, s, p.NW, w, R, PL, p.gp, p.ng, t, p.err, false, p.nap, fsz);
     const bool do_x = p.NW > 1 && !(kDbg(p) & 1);
-    EcHandoff::Pending P;                   // first pass requested before the wave's last interior update (forward kernel)
-    int q_req = -1;
-#ifdef EC_EARLY_POLL
-#pragma unroll
-    for (int q = 0; q < NG; ++q)
-        if (__any(G[q].cls == 1)) q_req = q;
-#endif
-    auto complete = [&](unsigned epoch) { X.complete(P, epoch, q_req >= 0, [&](int off, float v) { (pln + fsz)[off] = v; }); };
+    EcHandoff::Pending P;
+    auto complete = [&](unsigned epoch) { X.complete(P, epoch, [&](int off, float v) { (pln + fsz)[off] = v; }); };
     // byte offset of a group inside a [nz][gp] plane (snapshots, materials)
     auto cell_bytes = [&](int jq, int gq) { return 4u * (unsigned)(jq * p.gp + 4 * gq); };
     const float *S_shot = p.S + (long long)s * 5 * ncell;           // step n: S_shot + (n - s_first) * s_step
@@ -1438,13 +1410,12 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         // ---- B ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (do_x && q == q_req) X.request(P, 0, it & 1);
             if ((!EC_LATE_INTERIOR || q == 0) && ec_opaque(G[q].cls) == 1) phase_b(G[q]);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(3);
         if (do_x) {
-            if (q_req < 0) X.request(P, 0, it & 1);
+            X.request(P, 0, it & 1);
             complete((unsigned)(2 * it + 1));
         }
         EC_STAMP(4);
@@ -1542,13 +1513,12 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         // ---- D ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            if (do_x && q == q_req) X.request(P, 1, it & 1);
             if ((!EC_LATE_INTERIOR || q == 0) && ec_opaque(G[q].cls) == 1) phase_d(G[q], false);
             __builtin_amdgcn_sched_barrier(0);
         }
         EC_STAMP(11);
         if (do_x) {
-            if (q_req < 0) X.request(P, 1, it & 1);
+            X.request(P, 1, it & 1);
             complete((unsigned)(2 * it + 2));
         }
         EC_STAMP(12);

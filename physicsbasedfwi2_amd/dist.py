@@ -21,6 +21,15 @@ def shot_partition(nshots, rank, world):
     return lo, hi
 
 
+def shot_partition_balanced(nshots, rank, world):
+    """Contiguous blocks whose sizes differ by at most one (the first S mod R ranks own one more): what a
+    strong-scaled run wants, since the slowest rank sets the time - 29 shots on 8 ranks are 4,4,4,4,4,3,3,3 here
+    and 4,4,4,4,4,4,4,1 with :func:`shot_partition`."""
+    base, extra = divmod(int(nshots), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
 def all_reduce_gradient(grads, loss=None, group=None):
     """Sum per-rank partial gradients (list of tensors, any shapes) and the partial loss with a
     single all_reduce(SUM) on one flat fp32 buffer [sum(numel) + 1].  In place; returns

@@ -25,6 +25,22 @@ def test_shot_partition_covers_all_shots_once():
     assert shot_partition(29, 7, 8) == (28, 29)       # 29 shots / 8 GPUs: last rank gets one
 
 
+def test_balanced_partition_for_strong_scaling():
+    """`bench.py --scaling strong`: contiguous blocks whose sizes differ by at most one - C2's 29 shots on 8 ranks are
+    4,4,4,4,4,3,3,3 - covering every shot once."""
+    from physicsbasedfwi2_amd.dist import shot_partition_balanced
+    sizes = [hi - lo for lo, hi in (shot_partition_balanced(29, r, 8) for r in range(8))]
+    assert sizes == [4, 4, 4, 4, 4, 3, 3, 3]
+    for S in (1, 5, 29, 32, 35, 69, 256):
+        for R in (1, 2, 3, 4, 8):
+            seen, sz = [], []
+            for r in range(R):
+                lo, hi = shot_partition_balanced(S, r, R)
+                seen += list(range(lo, hi))
+                sz.append(hi - lo)
+            assert seen == list(range(S)) and max(sz) - min(sz) <= 1 and sz == sorted(sz, reverse=True)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     from physicsbasedfwi2_amd.dist import all_reduce_gradient, shot_partition
