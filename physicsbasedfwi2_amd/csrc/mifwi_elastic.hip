@@ -1141,7 +1141,7 @@ struct mifwi_elastic_plan {
     long long field_stride, shot_stride, fields_elems, psix_elems, psiz_elems, coef_elems;
     long long psi_elems;  // psix+psiz rounded up to 64
     // cluster path (LDS-resident time loop); 0 when a shot does not fit
-    int cluster, NW, PL, cl_shots, cl_lds, cl_ng;
+    int cluster, NW, PL, adj_PL, cl_shots, cl_lds, cl_ng;
     // adjoint cluster kernel (its own slab count: different LDS footprint)
     int cl_adj, adj_NW, adj_shots, adj_lds, adj_ng, adj_zrows;
     long long xbuf_elems, list_elems, xcc_elems;
@@ -1200,7 +1200,13 @@ void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, int nshot, hipSt
 
 void el_cluster_setup(mifwi_elastic_plan *pl)
 {
-    pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0; pl->xbuf_elems = 0; pl->xcc_elems = 0;
+    pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0;
+    pl->adj_PL = pl->PL;
+    // LDS row pitch: with the dense group -> thread deal (lane v <-> group v of the slab, row-major) a wave's 64 lanes
+    // cross a row break almost always; the 16-byte slot of lane v stays congruent to v (mod 16) across the break - and
+    // every ds_read_b128 lane group conflict-free - iff the pitch in slots is congruent to the groups per row
+    if (env_int("MIFWI_EL_PL_SKEW", 0) & 1) { int P = pl->ng + 2; while ((P - pl->ng) % 16) ++P; pl->PL = 4 * P; }
+    if (env_int("MIFWI_EL_PL_SKEW", 0) & 2) { int P = pl->ng + 2; while ((P - pl->ng) % 16) ++P; pl->adj_PL = 4 * P; } pl->cl_lds = 0; pl->xbuf_elems = 0; pl->xcc_elems = 0;
     pl->cl_adj = 0; pl->adj_NW = 0; pl->adj_shots = 0; pl->adj_lds = 0; pl->adj_ng = 0; pl->adj_zrows = 0; pl->list_elems = 0;
     {   // el_build_tile_taps: start [nshot][ntiles + 1], cursor [nshot][ntiles], list [nshot][nrec * ntap]
         const long long ntiles = (long long)mifwi::ceil_div(pl->ng, AGO) * mifwi::ceil_div(pl->d.nz, ATZ);
@@ -1257,9 +1263,9 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
                 const int nbot = std::max(0, r0 + R - std::max(r0, pl->d.nz - pl->W));
                 zmax = std::max(zmax, ntop + nbot);
             }
-            const long long lds = (4LL * (rows + 4) * pl->PL + 6LL * pl->gp + 8LL * rows +
+            const long long lds = (4LL * (rows + 4) * pl->adj_PL + 6LL * pl->gp + 8LL * rows +
                                    4LL * rows * pl->wx + 4LL * zmax * pl->gp +
-                                   (rows + 4) + 2LL * kEaRcvRows * pl->PL) * sizeof(float);   // + row map, receiver rows
+                                   (rows + 4) + 2LL * kEaRcvRows * pl->adj_PL) * sizeof(float);   // + row map, receiver rows
             if (lds > kEaLdsLimit) continue;
             if ((long long)rows * pl->ng > 2 * kEcThreads || kEcRowFields * pl->gp > kEcGr * kEcThreads) continue;
             const int per_launch = 8 * (ncu / (8 * nw));
@@ -1760,7 +1766,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         memset(&c, 0, sizeof(c));
         c.nz = d.nz; c.nx = d.nx; c.ng = pl->ng; c.gp = pl->gp; c.pitch = pl->pitch;
         c.field_stride = (unsigned)pl->field_stride; c.shot_stride = pl->shot_stride;
-        c.nshot = d.nshot; c.NW = pl->adj_NW; c.PL = pl->PL;
+        c.nshot = d.nshot; c.NW = pl->adj_NW; c.PL = pl->adj_PL;
         c.n_first = n_hi; c.n_last = n_lo; c.nt = d.nt;
         c.W = pl->W; c.wl = pl->wl; c.xr0 = pl->xr0; c.wx = pl->wx; c.fsurf = d.free_surface;
         c.zrows_max = pl->adj_zrows;
