@@ -672,6 +672,8 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
     losses, gsums = [], []
     from physicsbasedfwi2_amd import _lib as _mifwi_lib
     fallbacks0 = int(_mifwi_lib.load().mifwi_fallback_count())
+    agent0 = int(_mifwi_lib.load().mifwi_agent_handoff_count())
+    slow0 = int(_mifwi_lib.load().mifwi_slow_handoff_count())
     t0 = time.perf_counter()
     for _ in range(args.steps):
         grad, loss = one_step(True)
@@ -682,6 +684,10 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
     # single-launch time loops that gave up inside the timed region and were re-run with one launch per step (rank 0's
     # count): must be 0 for `kernel_family` to describe what was timed
     fallbacks = int(_mifwi_lib.load().mifwi_fallback_count()) - fallbacks0
+    # time loops repeated with hand-offs through the fabric (placement check failed), and launches in which a slab waited
+    # long for a neighbour (a GPU shared with another process): both 0 on a healthy, exclusively owned GPU
+    agent_tier = int(_mifwi_lib.load().mifwi_agent_handoff_count()) - agent0
+    slow_handoffs = int(_mifwi_lib.load().mifwi_slow_handoff_count()) - slow0
     # same inputs every step: the gradient pass must reproduce itself bit for bit
     losses = [float(v) for v in losses]
     gsums = [float(v) for v in gsums]
@@ -745,7 +751,8 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
                                          wl.resident_adj_bytes, res_a),
     }
     dom = "adjoint+imaging" if t_b >= t_f else "forward+save"
-    check = {"loss": losses[0], "grad_abs_sum": gsums[0], "bitwise_repeatable": deterministic, "fallbacks": fallbacks}
+    check = {"loss": losses[0], "grad_abs_sum": gsums[0], "bitwise_repeatable": deterministic, "fallbacks": fallbacks,
+             "agent_scope_relaunches": agent_tier, "slow_handoff_launches": slow_handoffs}
     if not (args.no_verify or args.timing_only):
         check.update(cross_check(wl, name, dev, kw))
     out = {

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define MIFWI_VERSION_MAJOR 0
-#define MIFWI_VERSION_MINOR 4   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format; 4: mifwi_fallback_count */
+#define MIFWI_VERSION_MINOR 5   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format; 4: mifwi_fallback_count; 5: mifwi_agent_handoff_count, mifwi_slow_handoff_count */
 
 enum {
     MIFWI_OK = 0,
@@ -46,6 +46,13 @@ int mifwi_version(void);                 /* major*1000 + minor                  
  * were re-run with one launch per step: results are the same, the time is not.  Monitoring and tests read it; the
  * first such call is also noted on stderr (MIFWI_QUIET=1 silences that). */
 int64_t mifwi_fallback_count(void);
+/* Single-launch time loops that were repeated with hand-offs through the fabric (agent-scope publishes) because the
+ * slabs of a shot had not been placed on one XCD: still one launch per time loop, 10-15 % slower per step. */
+int64_t mifwi_agent_handoff_count(void);
+/* Single-launch time loops in which some workgroup needed more than 32 poll passes for a neighbour's rows - what a
+ * GPU shared with another process looks like (the loop then runs many times slower, results unchanged, no fall-back):
+ * one rank must own the GPU while a propagator call runs.  The first such launch is noted on stderr. */
+int64_t mifwi_slow_handoff_count(void);
 int mifwi_device_count(void);            /* number of visible HIP devices, >=0  */
 /* engine / memory clock (kHz) and compute units of a device, for measurement reports; 0 where unknown */
 int mifwi_device_info(int device, int32_t *sclk_khz, int32_t *mclk_khz, int32_t *compute_units);

@@ -61,6 +61,8 @@ SIGNATURES = {
     "mifwi_last_error": (ctypes.c_char_p, []),
     "mifwi_version": (ctypes.c_int, []),
     "mifwi_fallback_count": (ctypes.c_int64, []),
+    "mifwi_agent_handoff_count": (ctypes.c_int64, []),
+    "mifwi_slow_handoff_count": (ctypes.c_int64, []),
     "mifwi_device_count": (ctypes.c_int, []),
     "mifwi_device_info": (ctypes.c_int, [ctypes.c_int, _P, _P, _P]),
     "mifwi_acoustic_plan_create": (ctypes.c_int, [ctypes.POINTER(_P), ctypes.c_int,

@@ -35,16 +35,40 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile_and_link(out, extra_flags, verbose):
+    """One hipcc -c per source (in parallel: the two big kernel files take ten seconds each), then one link."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    flags = [f for f in FLAGS if f != "-shared"] + list(extra_flags)
+    with tempfile.TemporaryDirectory(prefix="mifwi_build_") as tmp:
+        jobs = []
+        for src in sources():
+            obj = os.path.join(tmp, os.path.basename(src) + ".o")
+            jobs.append(([HIPCC] + flags + ["-c", "-o", obj, src], obj))
+        if verbose:
+            for cmd, _ in jobs:
+                print(" ".join(cmd))
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(lambda j: subprocess.check_call(j[0]), jobs))
+        link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [o for _, o in jobs]
+        if verbose:
+            print(" ".join(link))
+        subprocess.check_call(link)
+
+
 def build(force=False, verbose=False, extra_flags=(), out=None):
     """`out`: build another copy (e.g. an ablation build loaded through MIFWI_LIB) instead of the in-tree library."""
     if out is None and not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", out or LIB] + sources()
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
     if out is None and "-DMIFWI_ABLATIONS" not in extra_flags:
-        build(force=True, verbose=verbose, extra_flags=list(extra_flags) + ["-DMIFWI_ABLATIONS"], out=LIB_ABLATIONS)
+        # libmifwi.so and its -DMIFWI_ABLATIONS twin side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=2) as ex:
+            a = ex.submit(_compile_and_link, LIB, list(extra_flags), verbose)
+            b = ex.submit(_compile_and_link, LIB_ABLATIONS, list(extra_flags) + ["-DMIFWI_ABLATIONS"], verbose)
+            a.result(); b.result()
+        return LIB
+    _compile_and_link(out or LIB, list(extra_flags), verbose)
     return out or LIB
 
 

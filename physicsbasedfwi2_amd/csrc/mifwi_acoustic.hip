@@ -355,15 +355,20 @@ constexpr unsigned kClMaxSpin = 400000;
         if (p.trace && tr_on && it >= 64 && it < 128 && (t & 63) == 0)                                     \
             p.trace[((it - 64) * 16 + (t >> 6)) * 16 + (k)] = (long long)__builtin_readcyclecounter();     \
     } while (0)
+// dbg bit 4096 (fault injection): slab 1 of the first shot stalls ~10 ms at every 64th step (see EC_LAGGARD)
+#define CL_LAGGARD()                                                                                       \
+    do {                                                                                                   \
+        if ((kDbg(p) & 4096) && w == 1 && s == p.shot0 && (it & 63) == 1)                                  \
+            for (int z_ = 0; z_ < 3000; ++z_) __builtin_amdgcn_s_sleep(127);                               \
+    } while (0)
 #else
 #define CL_STAMP(k) do { } while (0)
+#define CL_LAGGARD() do { } while (0)
 #endif
-// publishes stay in the XCD's L2 (mifwi::same_xcd in mifwi_common.h); -DMIFWI_HANDOFF_AGENT: written through the fabric
-#ifdef MIFWI_HANDOFF_AGENT
-#define CL_PUBLISH_SCOPE __HIP_MEMORY_SCOPE_AGENT
-#else
-#define CL_PUBLISH_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
-#endif
+// Publishes stay in the XCD's L2 (workgroup-scope stores; mifwi::same_xcd in mifwi_common.h checks the placement that
+// makes this correct).  AG = true (last template argument of ac_cluster): agent-scope stores, through the fabric -
+// correct on any placement; launched by the host after a failed placement check.
+template <bool AG> struct ClScope { static constexpr int value = AG ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP; };
 
 struct ClParams {
     int n0, n1, ng, gp, pitch;
@@ -530,7 +535,7 @@ __device__ __forceinline__ int cl_opaque(int x)
 // SLOW = false: at most one source per shot and at most kClThreads receivers / sources (decided by the
 // host from the sizes): every sparse point has a thread of its own and the rescanning paths are not even
 // compiled in - they cost ~8 % of the C2 gradient pass in SGPR/VGPR spills alone.  SLOW = true: general.
-template <int MODE, bool SLOW>   // MODE 0: forward, 1: forward + snapshots, 2: adjoint + imaging, 3: Born (source G^n dr)
+template <int MODE, bool SLOW, bool AG>   // MODE 0: forward, 1: forward + snapshots, 2: adjoint + imaging, 3: Born (source G^n dr)
 __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     // its neighbours must time out, publish the error word and let the host fall back
     if ((kDbg(p) & 64) && w == 1 && s == p.shot0) return;
     const int t = (int)threadIdx.x;
-    if (!mifwi::same_xcd(p.xcc_tab, s, p.NW, w, t, p.err, kClMaxSpin, kDbg(p) & 128)) return;
+    if (!AG && !mifwi::same_xcd(p.xcc_tab, s, p.NW, w, t, p.err, kClMaxSpin, kDbg(p) & 128)) return;
     constexpr bool adj = (MODE == 2);
     int r0, R;
     slab_rows(p.n0, p.NW, p.rt, w, r0, R);
@@ -783,6 +788,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     for (int it = 0; it < nsteps; ++it) {
         const int n = adj ? (p.n_first - it) : (p.n_first + it);
         const float amp = amp_next;
+        CL_LAGGARD();
         CL_STAMP(0);
         // ---- sampling of the current field (owner slab writes) -------------------------------
         if (kDbg(p) & 8) {
@@ -903,6 +909,8 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
 #pragma unroll
                 for (int kk = 0; kk < kGr; ++kk)
                     if (rcv_lo[kk] >= 0) ok = ok && (unsigned)(v[kk] >> 32) == (unsigned)it;
+                // a wave that waits this long for a neighbour says so at once (rare path, no state carried through the loop)
+                if (spins == mifwi::kSlowPollPasses && (t & 63) == 0) atomicAdd(p.err + mifwi::kErrSlow, 1);
                 if (ok || failed) break;            // once failed: one pass per step, garbage forward until the check
                 if (spins > kClMaxSpin ||
                     ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
@@ -977,7 +985,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 if (rcv_lo[kk] >= 0)
                     __hip_atomic_store(xmine + t + kk * kClThreads,
                                        ((unsigned long long)epoch << 32) | __float_as_uint(prv[pub_off(kk)]),
-                                       __ATOMIC_RELAXED, CL_PUBLISH_SCOPE);
+                                       __ATOMIC_RELAXED, ClScope<AG>::value);
         }
         CL_STAMP(8);
         // global traffic that nobody waits for goes AFTER the hand-off (vector memory operations
@@ -1130,10 +1138,14 @@ void cluster_setup(mifwi_acoustic_plan *pl)
     pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * pl->NW * 8 * pl->gp, 64) +
                      mifwi::round_up64((long long)pl->d.nshot * pl->NW, 64) + 64;
     pl->list_elems = mifwi::round_up64((long long)pl->d.nshot * pl->NW * (1 + (long long)pl->d.nrec), 64);
-    for (const void *fn : {(const void *)ac_cluster<0, false>, (const void *)ac_cluster<1, false>,
-                           (const void *)ac_cluster<2, false>, (const void *)ac_cluster<3, false>,
-                           (const void *)ac_cluster<0, true>, (const void *)ac_cluster<1, true>,
-                           (const void *)ac_cluster<2, true>, (const void *)ac_cluster<3, true>})
+    for (const void *fn : {(const void *)ac_cluster<0, false, false>, (const void *)ac_cluster<1, false, false>,
+                           (const void *)ac_cluster<2, false, false>, (const void *)ac_cluster<3, false, false>,
+                           (const void *)ac_cluster<0, true, false>, (const void *)ac_cluster<1, true, false>,
+                           (const void *)ac_cluster<2, true, false>, (const void *)ac_cluster<3, true, false>,
+                           (const void *)ac_cluster<0, false, true>, (const void *)ac_cluster<1, false, true>,
+                           (const void *)ac_cluster<2, false, true>, (const void *)ac_cluster<3, false, true>,
+                           (const void *)ac_cluster<0, true, true>, (const void *)ac_cluster<1, true, true>,
+                           (const void *)ac_cluster<2, true, true>, (const void *)ac_cluster<3, true, true>})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mifwi::kClusterLdsLimit) != hipSuccess) {
             (void)hipGetLastError();           // not sticky: the plan simply uses one launch per step
             pl->cluster = 0;
@@ -1161,8 +1173,8 @@ ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const flo
     return c;
 }
 
-template <int MODE>
-int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStream_t st)
+template <int MODE, bool AG>
+int cluster_attempt(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStream_t st)
 {
     if (mifwi::fake_timeout() == 1) return mifwi::kClusterTimedOut;
     MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
@@ -1183,13 +1195,13 @@ int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStrea
         const bool general = MODE == 2 ? (c.nrec > kClThreads || c.nsrc > kClThreads)
                                        : (c.nsrc > 1 || c.nrec > kClThreads);
         if (general)
-            hipLaunchKernelGGL((ac_cluster<MODE, true>), dim3(8 * pl->NW * nsl8), dim3(kClThreads), pl->cl_lds, st, c);
+            hipLaunchKernelGGL((ac_cluster<MODE, true, AG>), dim3(8 * pl->NW * nsl8), dim3(kClThreads), pl->cl_lds, st, c);
         else
-            hipLaunchKernelGGL((ac_cluster<MODE, false>), dim3(8 * pl->NW * nsl8), dim3(kClThreads), pl->cl_lds, st, c);
+            hipLaunchKernelGGL((ac_cluster<MODE, false, AG>), dim3(8 * pl->NW * nsl8), dim3(kClThreads), pl->cl_lds, st, c);
     }
     MIFWI_HIP_TRY(hipGetLastError());
-    int err = 0;
-    MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
+    int err[4] = {0, 0, 0, 0};
+    MIFWI_HIP_TRY(hipMemcpyAsync(err, c.err, sizeof(err), hipMemcpyDeviceToHost, st));
     MIFWI_HIP_TRY(hipStreamSynchronize(st));
 #ifdef MIFWI_ABLATIONS
     if (c.trace) {
@@ -1206,7 +1218,26 @@ int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStrea
         }
     }
 #endif
-    return (err != 0 || mifwi::fake_timeout() == 2) ? mifwi::kClusterTimedOut : MIFWI_OK;
+    const int verdict = mifwi::cluster_verdict(err, "acoustic");
+    return mifwi::fake_timeout() == 2 ? mifwi::kClusterTimedOut : verdict;
+}
+
+int cluster_restore(float *work, long long state_elems, const float *backup, int32_t flags, hipStream_t st);
+
+// The single-launch time loop with its middle tier: a failed placement check (the slabs of a shot were not dealt to one
+// XCD) restores the state and repeats the launch with granules published through the fabric; what comes back is OK,
+// an error, or kClusterTimedOut (the caller then restores the state and runs one launch per step).
+template <int MODE>
+int cluster_run(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipStream_t st, float *work, long long state_elems,
+                const float *backup, int32_t flags)
+{
+    int rc = cluster_attempt<MODE, false>(pl, c, xbuf, st);
+    if (rc != mifwi::kClusterMisplaced) return rc;
+    mifwi::note_agent_tier("acoustic");
+    rc = cluster_restore(work, state_elems, backup, flags, st);
+    if (rc) return rc;
+    rc = cluster_attempt<MODE, true>(pl, c, xbuf, st);
+    return rc == mifwi::kClusterMisplaced ? mifwi::kClusterTimedOut : rc;
 }
 
 // A single-launch attempt may time out (some workgroup was not resident in time) after it has advanced the state by
@@ -1233,6 +1264,8 @@ extern "C" {
 const char *mifwi_last_error(void) { return mifwi::err_buf(); }
 int mifwi_version(void) { return MIFWI_VERSION_MAJOR * 1000 + MIFWI_VERSION_MINOR; }
 int64_t mifwi_fallback_count(void) { return (int64_t)mifwi::g_fallbacks.load(std::memory_order_relaxed); }
+int64_t mifwi_agent_handoff_count(void) { return (int64_t)mifwi::g_agent_tier.load(std::memory_order_relaxed); }
+int64_t mifwi_slow_handoff_count(void) { return (int64_t)mifwi::g_slow_handoffs.load(std::memory_order_relaxed); }
 int mifwi_device_count(void)
 {
     int n = 0;
@@ -1399,7 +1432,8 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *pl, const float *r, const float 
         float *backup = xbuf + pl->xbuf_elems + pl->list_elems;
         rc = cluster_backup(work, 2 * pl->field_elems, backup, flags, st);
         if (rc) return rc;
-        rc = snap ? cluster_run<1>(pl, c, xbuf, st) : cluster_run<0>(pl, c, xbuf, st);
+        rc = snap ? cluster_run<1>(pl, c, xbuf, st, work, 2 * pl->field_elems, backup, flags)
+                  : cluster_run<0>(pl, c, xbuf, st, work, 2 * pl->field_elems, backup, flags);
         if (rc != mifwi::kClusterTimedOut) return rc;
         mifwi::note_fallback("acoustic");
         rc = cluster_restore(work, 2 * pl->field_elems, backup, flags, st);
@@ -1456,7 +1490,7 @@ int mifwi_acoustic_born(mifwi_acoustic_plan *pl, const float *r, const float *q0
         float *backup = xbuf + pl->xbuf_elems + pl->list_elems;
         rc = cluster_backup(work, 2 * pl->field_elems, backup, flags, st);
         if (rc) return rc;
-        rc = cluster_run<3>(pl, c, xbuf, st);
+        rc = cluster_run<3>(pl, c, xbuf, st, work, 2 * pl->field_elems, backup, flags);
         if (rc != mifwi::kClusterTimedOut) return rc;
         mifwi::note_fallback("acoustic");
         rc = cluster_restore(work, 2 * pl->field_elems, backup, flags, st);
@@ -1535,7 +1569,7 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
         float *backup = reinterpret_cast<float *>(lists) + pl->list_elems;
         rc = cluster_backup(work, state, backup, flags, st);
         if (rc) return rc;
-        rc = cluster_run<2>(pl, c, xbuf, st);
+        rc = cluster_run<2>(pl, c, xbuf, st, work, state, backup, flags);
         if (rc == mifwi::kClusterTimedOut) {
             mifwi::note_fallback("acoustic");
             rc = cluster_restore(work, state, backup, flags, st);

@@ -40,6 +40,14 @@ inline int fail(int code, const char *fmt, ...)
 // launch per (half) step: from the zero state when it started there, otherwise from the copy of its
 // input state that resumed calls keep (time checkpointing).
 constexpr int kClusterTimedOut = 1;
+// ... or whose placement check failed (the slabs of a shot were not dealt to one XCD): the launch is repeated once with
+// granules published at agent scope (through the fabric: correct on any placement, 10-15 % slower per step) before the
+// per-step kernels are considered.
+constexpr int kClusterMisplaced = 2;
+// The error block of a single-launch kernel (last 64 ints of its hand-off buffer): [0] time-out raised, [1] placement
+// check failed, [2] slow polls: waves x polls that needed more than kSlowPollPasses passes.
+constexpr int kErrTimeout = 0, kErrPlacement = 1, kErrSlow = 2;
+constexpr unsigned kSlowPollPasses = 32;
 // A single-launch time loop gave up (a workgroup was not resident in time, or the slabs of a shot were not placed on
 // one XCD) and the call is re-run with one launch per step: correct, but several times slower on small grids, so it
 // is said once per process on stderr (MIFWI_QUIET=1 silences it) rather than left to be discovered in a profile.
@@ -52,6 +60,37 @@ inline void note_fallback(const char *what)
     said = true;
     fprintf(stderr, "libmifwi: %s: single-launch time loop gave up (hand-off time-out or XCD placement); "
                     "falling back to one launch per step for this call\n", what);
+}
+
+// launches repeated with agent-scope publishes after a failed placement check (mifwi_agent_handoff_count()), and
+// launches in which some workgroup waited more than kSlowPollPasses poll passes for a neighbour - the signature of a
+// GPU shared with another process (mifwi_slow_handoff_count()): results are unaffected, the speed is not
+inline std::atomic<long long> g_agent_tier{0}, g_slow_handoffs{0};
+inline void note_agent_tier(const char *what)
+{
+    g_agent_tier.fetch_add(1, std::memory_order_relaxed);
+    static bool said = false;
+    if (said || getenv("MIFWI_QUIET")) return;
+    said = true;
+    fprintf(stderr, "libmifwi: %s: the slabs of a shot were not placed on one XCD; repeating the single-launch time loop "
+                    "with hand-offs through the fabric\n", what);
+}
+inline void note_slow_handoff(const char *what, int workgroups)
+{
+    g_slow_handoffs.fetch_add(1, std::memory_order_relaxed);
+    static bool said = false;
+    if (said || getenv("MIFWI_QUIET")) return;
+    said = true;
+    fprintf(stderr, "libmifwi: %s: %d time(s) a wave of a single-launch time loop waited more than %u poll passes for a "
+                    "neighbouring slab - is another process using this GPU?  (results are unaffected; "
+                    "mifwi_slow_handoff_count() counts such launches)\n", what, workgroups, kSlowPollPasses);
+}
+// what the host makes of the error block after a launch
+inline int cluster_verdict(const int *e, const char *what)
+{
+    if (e[kErrSlow] > 0) note_slow_handoff(what, e[kErrSlow]);
+    if (e[kErrPlacement] != 0) return kClusterMisplaced;
+    return e[kErrTimeout] != 0 ? kClusterTimedOut : MIFWI_OK;
 }
 
 // test hook, read per call: MIFWI_TEST_FAKE_TIMEOUT=1 treats every single-launch attempt as timed out before it
@@ -109,14 +148,16 @@ __device__ __forceinline__ void poll_nap(int units)
 // them on blocks b, b + 8, b + 16, ..., which the dispatcher deals to one XCD - observed, not promised by HIP - so it
 // is checked, not assumed: before its time loop every workgroup writes its XCC_ID to xcc_tab[shot][slab] (agent
 // scope) and reads its two neighbours' entries; a mismatch or a neighbour that never shows up makes the launch bail
-// out through the same error word as a hand-off time-out, and the host re-runs the range with one launch per step.
+// out through the error block (a mismatch also raises its placement word), and the host repeats the launch with
+// agent-scope publishes - the AG variants of the kernels, which skip this check - or, after a no-show, re-runs the range
+// with one launch per step.
 // (A stale granule can never be taken for a fresh one - its tag is an older epoch - so a wrong placement could only
 // ever end in that time-out, not in wrong numbers; the check just gets there in microseconds.)
 // Returns true when this workgroup may run; collective over the workgroup (__syncthreads_or inside).
 __device__ __forceinline__ bool same_xcd(int *xcc_tab, int s, int NW, int w, int t, int *err, unsigned max_spin, int fake)
 {
     if (NW == 1) return true;
-    bool bad = false;
+    bool bad = false, misplaced = false;
     if (t == 0) {
         // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, 4 bits)
         const int me = fake ? w + 1 : (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) + 1;
@@ -131,7 +172,9 @@ __device__ __forceinline__ bool same_xcd(int *xcc_tab, int s, int NW, int w, int
                 __builtin_amdgcn_s_sleep(4);
             }
             if (v != me) bad = true;                     // 0: the neighbour never showed up
+            if (v != me && v != 0) misplaced = true;
         }
+        if (misplaced) __hip_atomic_store(err + kErrPlacement, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (bad) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return __syncthreads_or(bad ? 1 : 0) == 0;

@@ -1238,8 +1238,10 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
         }
     }
     if (pl->cluster) {
-        for (const void *fn : {(const void *)el_cluster_fwd<false, 1>, (const void *)el_cluster_fwd<true, 1>,
-                               (const void *)el_cluster_fwd<false, 2>, (const void *)el_cluster_fwd<true, 2>})
+        for (const void *fn : {(const void *)el_cluster_fwd<false, 1, false>, (const void *)el_cluster_fwd<true, 1, false>,
+                               (const void *)el_cluster_fwd<false, 2, false>, (const void *)el_cluster_fwd<true, 2, false>,
+                               (const void *)el_cluster_fwd<false, 1, true>, (const void *)el_cluster_fwd<true, 1, true>,
+                               (const void *)el_cluster_fwd<false, 2, true>, (const void *)el_cluster_fwd<true, 2, true>})
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mifwi::kClusterLdsLimit) != hipSuccess) {
                 (void)hipGetLastError();       // not sticky: fall back to one launch per half step
                 pl->cluster = 0;
@@ -1278,7 +1280,8 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
             }
         }
         if (pl->cl_adj)
-            for (const void *fn : {(const void *)el_cluster_adj<1>, (const void *)el_cluster_adj<2>})
+            for (const void *fn : {(const void *)el_cluster_adj<1, false>, (const void *)el_cluster_adj<2, false>,
+                                   (const void *)el_cluster_adj<1, true>, (const void *)el_cluster_adj<2, true>})
                 if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kEaLdsLimit) != hipSuccess) {
                     (void)hipGetLastError();
                     pl->cl_adj = 0;
@@ -1293,7 +1296,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
         pl->list_elems = mifwi::round_up64((long long)pl->d.nshot * pl->adj_NW * (1 + pl->d.nrec), 64);
 }
 
-template <bool SAVE>
+template <bool SAVE, bool AG>
 int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStream_t st)
 {
     if (mifwi::fake_timeout() == 1) return mifwi::kClusterTimedOut;
@@ -1315,13 +1318,13 @@ int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStr
         c.shot1 = std::min(pl->d.nshot, s0 + pl->cl_shots);
         const int nsl8 = mifwi::ceil_div(c.shot1 - s0, 8);
         if (pl->cl_ng == 1)
-            hipLaunchKernelGGL((el_cluster_fwd<SAVE, 1>), dim3(8 * pl->NW * nsl8), dim3(kEcThreads), pl->cl_lds, st, c);
+            hipLaunchKernelGGL((el_cluster_fwd<SAVE, 1, AG>), dim3(8 * pl->NW * nsl8), dim3(kEcThreads), pl->cl_lds, st, c);
         else
-            hipLaunchKernelGGL((el_cluster_fwd<SAVE, 2>), dim3(8 * pl->NW * nsl8), dim3(kEcThreads), pl->cl_lds, st, c);
+            hipLaunchKernelGGL((el_cluster_fwd<SAVE, 2, AG>), dim3(8 * pl->NW * nsl8), dim3(kEcThreads), pl->cl_lds, st, c);
     }
     MIFWI_HIP_TRY(hipGetLastError());
-    int err = 0;
-    MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
+    int err[4] = {0, 0, 0, 0};
+    MIFWI_HIP_TRY(hipMemcpyAsync(err, c.err, sizeof(err), hipMemcpyDeviceToHost, st));
     MIFWI_HIP_TRY(hipStreamSynchronize(st));
 #ifdef MIFWI_ABLATIONS
     if (c.trace) {
@@ -1338,7 +1341,8 @@ int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStr
         }
     }
 #endif
-    return (err != 0 || mifwi::fake_timeout() == 2) ? mifwi::kClusterTimedOut : MIFWI_OK;
+    const int verdict = mifwi::cluster_verdict(err, "elastic forward");
+    return mifwi::fake_timeout() == 2 ? mifwi::kClusterTimedOut : verdict;
 }
 
 // A timed-out single-launch attempt has advanced the state by an unknown number of steps: a call that started from
@@ -1598,8 +1602,14 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
         float *backup = xbuf + pl->xbuf_elems;
         rc = el_cluster_backup(work, pl->fields_elems + psi, backup, flags, st);
         if (rc) return rc;
-        rc = snap ? el_cluster_run<true>(pl, c, xbuf, st) : el_cluster_run<false>(pl, c, xbuf, st);
-        if (rc != mifwi::kClusterTimedOut) return rc;
+        rc = snap ? el_cluster_run<true, false>(pl, c, xbuf, st) : el_cluster_run<false, false>(pl, c, xbuf, st);
+        if (rc == mifwi::kClusterMisplaced) {          // not on one XCD: once more with hand-offs through the fabric
+            mifwi::note_agent_tier("elastic forward");
+            rc = el_cluster_restore(work, pl->fields_elems + psi, backup, flags, st);
+            if (rc) return rc;
+            rc = snap ? el_cluster_run<true, true>(pl, c, xbuf, st) : el_cluster_run<false, true>(pl, c, xbuf, st);
+        }
+        if (rc != mifwi::kClusterTimedOut && rc != mifwi::kClusterMisplaced) return rc;
         mifwi::note_fallback("elastic");
         rc = el_cluster_restore(work, pl->fields_elems + psi, backup, flags, st);
         if (rc) return rc;
@@ -1783,7 +1793,6 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         c.dbg = env_int("MIFWI_EL_CL_DBG", 0);
         c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(d.nz, c.NW) >= 8 ? 48 : 1);   // mifwi::poll_nap
         c.K = fd_weights(d.fd_order);
-        MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
         c.xbuf = reinterpret_cast<unsigned long long *>(xbuf);
         c.err = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64);
         c.xcc_tab = reinterpret_cast<int *>(xbuf + pl->xbuf_elems - 64 - pl->xcc_elems);
@@ -1791,46 +1800,62 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
         float *backup = reinterpret_cast<float *>(lists) + pl->list_elems;
         rc = el_cluster_backup(work, adj_state, backup, flags, st);
         if (rc) return rc;
+        // one attempt on the single-launch kernel; agent: granules published through the fabric (after a failed placement check)
+        auto attempt = [&](bool agent) -> int {
+            MIFWI_HIP_TRY(hipMemsetAsync(xbuf, 0, sizeof(float) * pl->xbuf_elems, st));
 #ifdef MIFWI_ABLATIONS
-        const char *trace_path = getenv("MIFWI_EL_CL_TRACE");
-        const size_t trace_n = 64 * 8 * 16;
-        if (trace_path && *trace_path) {
-            MIFWI_HIP_TRY(hipMalloc(&c.trace, trace_n * sizeof(long long)));
-            MIFWI_HIP_TRY(hipMemsetAsync(c.trace, 0, trace_n * sizeof(long long), st));
-        }
-#endif
-        for (int s0 = 0; s0 < d.nshot && mifwi::fake_timeout() != 1; s0 += pl->adj_shots) {
-            c.shot0 = s0;
-            c.shot1 = std::min(d.nshot, s0 + pl->adj_shots);
-            const int nsl8 = mifwi::ceil_div(c.shot1 - s0, 8);
-            if (pl->adj_ng == 1)
-                hipLaunchKernelGGL((el_cluster_adj<1>), dim3(8 * pl->adj_NW * nsl8), dim3(kEcThreads), pl->adj_lds, st, c);
-            else
-                hipLaunchKernelGGL((el_cluster_adj<2>), dim3(8 * pl->adj_NW * nsl8), dim3(kEcThreads), pl->adj_lds, st, c);
-        }
-        MIFWI_HIP_TRY(hipGetLastError());
-        int err = 0;
-        MIFWI_HIP_TRY(hipMemcpyAsync(&err, c.err, sizeof(int), hipMemcpyDeviceToHost, st));
-        MIFWI_HIP_TRY(hipStreamSynchronize(st));
-#ifdef MIFWI_ABLATIONS
-        if (c.trace) {
-            std::vector<long long> h(trace_n);
-            MIFWI_HIP_TRY(hipMemcpy(h.data(), c.trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost));
-            MIFWI_HIP_TRY(hipFree(c.trace));
-            if (FILE *fp = fopen(trace_path, "a")) {
-                fprintf(fp, "# el_cluster_adj steps=%d\n", n_hi - n_lo + 1);
-                for (size_t i = 0; i < trace_n; i += 16) {
-                    for (int k = 0; k < 16; ++k) fprintf(fp, "%lld ", h[i + k]);
-                    fprintf(fp, "\n");
-                }
-                fclose(fp);
+            const char *trace_path = getenv("MIFWI_EL_CL_TRACE");
+            const size_t trace_n = 64 * 8 * 16;
+            c.trace = nullptr;
+            if (trace_path && *trace_path) {
+                MIFWI_HIP_TRY(hipMalloc(&c.trace, trace_n * sizeof(long long)));
+                MIFWI_HIP_TRY(hipMemsetAsync(c.trace, 0, trace_n * sizeof(long long), st));
             }
-        }
 #endif
-        if (err != 0 || mifwi::fake_timeout()) {
+            for (int s0 = 0; s0 < d.nshot && mifwi::fake_timeout() != 1; s0 += pl->adj_shots) {
+                c.shot0 = s0;
+                c.shot1 = std::min(d.nshot, s0 + pl->adj_shots);
+                const dim3 grid(8 * pl->adj_NW * mifwi::ceil_div(c.shot1 - s0, 8));
+                if (pl->adj_ng == 1 && !agent) hipLaunchKernelGGL((el_cluster_adj<1, false>), grid, dim3(kEcThreads), pl->adj_lds, st, c);
+                else if (pl->adj_ng == 1) hipLaunchKernelGGL((el_cluster_adj<1, true>), grid, dim3(kEcThreads), pl->adj_lds, st, c);
+                else if (!agent) hipLaunchKernelGGL((el_cluster_adj<2, false>), grid, dim3(kEcThreads), pl->adj_lds, st, c);
+                else hipLaunchKernelGGL((el_cluster_adj<2, true>), grid, dim3(kEcThreads), pl->adj_lds, st, c);
+            }
+            MIFWI_HIP_TRY(hipGetLastError());
+            int err[4] = {0, 0, 0, 0};
+            MIFWI_HIP_TRY(hipMemcpyAsync(err, c.err, sizeof(err), hipMemcpyDeviceToHost, st));
+            MIFWI_HIP_TRY(hipStreamSynchronize(st));
+#ifdef MIFWI_ABLATIONS
+            if (c.trace) {
+                std::vector<long long> h(trace_n);
+                MIFWI_HIP_TRY(hipMemcpy(h.data(), c.trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost));
+                MIFWI_HIP_TRY(hipFree(c.trace));
+                if (FILE *fp = fopen(trace_path, "a")) {
+                    fprintf(fp, "# el_cluster_adj steps=%d\n", n_hi - n_lo + 1);
+                    for (size_t i = 0; i < trace_n; i += 16) {
+                        for (int k = 0; k < 16; ++k) fprintf(fp, "%lld ", h[i + k]);
+                        fprintf(fp, "\n");
+                    }
+                    fclose(fp);
+                }
+            }
+#endif
+            const int verdict = mifwi::cluster_verdict(err, "elastic adjoint");
+            return mifwi::fake_timeout() ? mifwi::kClusterTimedOut : verdict;
+        };
+        rc = attempt(false);
+        if (rc == mifwi::kClusterMisplaced) {
+            mifwi::note_agent_tier("elastic adjoint");
+            rc = el_cluster_restore(work, adj_state, backup, flags, st);
+            if (rc) return rc;
+            rc = attempt(true);
+        }
+        if (rc == mifwi::kClusterTimedOut || rc == mifwi::kClusterMisplaced) {
             mifwi::note_fallback("elastic adjoint");
             rc = el_cluster_restore(work, adj_state, backup, flags, st);
             if (rc) return rc;
+        } else if (rc != MIFWI_OK) {
+            return rc;
         } else {
             per_step = false;
         }

@@ -55,8 +55,17 @@ struct EcParams {
         if (p.trace && tr_on && it >= 64 && it < 128 && (t & 63) == 0)                                     \
             p.trace[((it - 64) * 8 + (t >> 6)) * 16 + (k)] = (long long)__builtin_readcyclecounter();      \
     } while (0)
+// dbg bit 4096 (fault injection): slab 1 of the first shot stalls ~10 ms at every 64th step - a neighbour that is late
+// but not absent, what a GPU shared with another process looks like; the others must wait (no time-out), finish with
+// the same results, and the launch must be counted by mifwi_slow_handoff_count()
+#define EC_LAGGARD()                                                                                       \
+    do {                                                                                                   \
+        if ((kDbg(p) & 4096) && w == 1 && s == p.shot0 && (it & 63) == 1)                                  \
+            for (int z_ = 0; z_ < 3000; ++z_) __builtin_amdgcn_s_sleep(127);                               \
+    } while (0)
 #else
 #define EC_STAMP(k) do { } while (0)
+#define EC_LAGGARD() do { } while (0)
 #endif
 
 __device__ __forceinline__ void ec_slab_rows(int nz, int NW, int w, int &r0, int &rows)
@@ -155,12 +164,10 @@ __device__ __forceinline__ void ec_drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0
 // caller knows the queue has drained): its later use no longer waits for whatever was requested in between.
 __device__ __forceinline__ void ec_settle(float &x) { asm volatile("" : "+v"(x)); }
 
-// publishes stay in the XCD's L2 (mifwi::same_xcd in mifwi_common.h); -DMIFWI_HANDOFF_AGENT: written through the fabric
-#ifdef MIFWI_HANDOFF_AGENT
-#define EC_PUBLISH_SCOPE __HIP_MEMORY_SCOPE_AGENT
-#else
-#define EC_PUBLISH_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
-#endif
+// Publishes stay in the XCD's L2 (workgroup-scope stores; mifwi::same_xcd in mifwi_common.h checks the placement that
+// makes this correct).  AG = true (the kernels' last template argument): agent-scope stores, written through the
+// fabric - correct on any placement; the host launches these variants after a failed placement check.
+template <bool AG> struct EcScope { static constexpr int value = AG ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP; };
 
 // The granule hand-off of one slab, shared by the forward and the adjoint kernel.  `kind` selects one
 // of the two exchanges of a step, `parity` the double buffer, `epoch` the tag a complete granule
@@ -239,6 +246,8 @@ struct EcHandoff {
             unsigned bad = 0;
 #pragma unroll
             for (int k = 0; k < kEcGr; ++k) bad |= ((unsigned)(q.v[k] >> 32) ^ epoch) & need[k];
+            // a wave that waits this long for a neighbour says so at once (rare path, no state carried through the loop)
+            if (spins == mifwi::kSlowPollPasses && (t & 63) == 0) atomicAdd(err + mifwi::kErrSlow, 1);
             if (bad == 0 || no_wait || failed) break;   // once failed: one pass per hand-off, garbage forward until the check
             if (spins > kEcMaxSpin ||
                 ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
@@ -271,6 +280,7 @@ struct EcHandoff {
 
     // publish the four cells of a boundary-row group (local row lrw, group gq): b = the field a forward
     // difference reads (vx, szz; E2, D2), a = the one a backward difference reads (vz, sxz; E3, D4)
+    template <bool AG>
     __device__ __forceinline__ void publish(int lrw, int gq, int kind, unsigned epoch, int parity, const float4 &b,
                                             const float4 &a) const
     {
@@ -282,7 +292,7 @@ struct EcHandoff {
             unsigned o = rf * gp8 + gq8;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                __hip_atomic_store(ec_at(x, o), tag | __float_as_uint(v[k]), __ATOMIC_RELAXED, EC_PUBLISH_SCOPE);
+                __hip_atomic_store(ec_at(x, o), tag | __float_as_uint(v[k]), __ATOMIC_RELAXED, EcScope<AG>::value);
                 o = ec_opaque(o + ng8);                            // a chain of adds, not 24 hoisted constants
             }
         };
@@ -543,7 +553,7 @@ __device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const in
     st4(c.Lf[F_SXZ] + lo, o1);
 }
 
-template <bool SAVE, int NG>
+template <bool SAVE, int NG, bool AG>
 __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     // ablation builds only: slab 1 of the first shot never shows up (a workgroup that was not resident in time)
     if ((kDbg(p) & 64) && w == 1 && s == p.shot0) return;
     const int t = (int)threadIdx.x;
-    if (!mifwi::same_xcd(p.xcc_tab, s, p.NW, w, t, p.err, kEcMaxSpin, kDbg(p) & 128)) return;
+    if (!AG && !mifwi::same_xcd(p.xcc_tab, s, p.NW, w, t, p.err, kEcMaxSpin, kDbg(p) & 128)) return;
     int r0, R;
     ec_slab_rows(p.nz, p.NW, w, r0, R);
     const int PL = p.PL, LR = R + 4;
@@ -708,7 +718,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         if (edge) {
             const int jq = ec_opaque(g.j);
             ec_update_v<true>(g, c, lo, jq, S4, S5, o0, o1);
-            if (do_x && !(kDbg(p) & 16)) X.publish(jq - r0, ec_opaque(g.g), 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
+            if (do_x && !(kDbg(p) & 16)) X.template publish<AG>(jq - r0, ec_opaque(g.g), 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
         } else {
             ec_update_v<false>(g, c, lo, 2, S4, S5, o0, o1);
         }
@@ -725,7 +735,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         if (edge) {
             const int jq = ec_opaque(g.j);
             ec_update_s<true>(g, c, lo, jq, amp, S1, S2, S3, o0, o1);
-            if (do_x && !(kDbg(p) & 16)) X.publish(jq - r0, ec_opaque(g.g), 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
+            if (do_x && !(kDbg(p) & 16)) X.template publish<AG>(jq - r0, ec_opaque(g.g), 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
         } else {
             ec_update_s<false>(g, c, lo, 2, amp, S1, S2, S3, o0, o1);
         }
@@ -742,6 +752,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
     ec_drain_vmem();
     for (int it = 0; it < nsteps; ++it) {
         const int n = p.n_first + it;
+        EC_LAGGARD();
         EC_STAMP(0);
         // ---- V: interior rows first, then receive the stress halo, then the boundary rows --------
         const bool poll_s = do_x && it > 0 && !(kDbg(p) & 32);
@@ -954,7 +965,7 @@ struct EaGroup {
     float src_wt;
 };
 
-template <int NG>
+template <int NG, bool AG>
 __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -966,7 +977,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     // ablation builds only: slab 1 of the first shot never shows up (a workgroup that was not resident in time)
     if ((kDbg(p) & 64) && w == 1 && s == p.shot0) return;
     const int t = (int)threadIdx.x;
-    if (!mifwi::same_xcd(p.xcc_tab, s, p.NW, w, t, p.err, kEcMaxSpin, kDbg(p) & 128)) return;
+    if (!AG && !mifwi::same_xcd(p.xcc_tab, s, p.NW, w, t, p.err, kEcMaxSpin, kDbg(p) & 128)) return;
     int r0, R;
     ec_slab_rows(p.nz, p.NW, w, r0, R);
     const int PL = p.PL, LR = R + 4;
@@ -1222,7 +1233,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         st4(pln + fsz + lo, E2);
         st4(pln + 2 * fsz + lo, E3);
         st4(pln + 3 * fsz + lo, make_float4(e4[0], e4[1], e4[2], e4[3]));
-        if (do_x && cls == 2) X.publish(jq - r0, gq, 0, (unsigned)(2 * it + 1), it & 1, E2, E3);
+        if (do_x && cls == 2) X.template publish<AG>(jq - r0, gq, 0, (unsigned)(2 * it + 1), it & 1, E2, E3);
     };
     // B: v_bar -= stencils(E)
     auto phase_b = [&](EaGroup &g) {
@@ -1293,7 +1304,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         st4(pln + fsz + lo, D2);
         st4(pln + 2 * fsz + lo, D4);
         st4(pln + 3 * fsz + lo, make_float4(d3[0], d3[1], d3[2], d3[3]));
-        if (do_x && cls == 2) X.publish(jq - r0, gq, 1, (unsigned)(2 * it + 2), it & 1, D2, D4);
+        if (do_x && cls == 2) X.template publish<AG>(jq - r0, gq, 1, (unsigned)(2 * it + 2), it & 1, D2, D4);
         // gradients (oracle order): Ms, Ls, mus from the old sigma_bar; bxs, bzs from the new v_bar
         const bool top = p.fsurf && jq == 0;
         const float4 bzz = make_float4(top ? 0.f : g.bzz.x, top ? 0.f : g.bzz.y, top ? 0.f : g.bzz.z,
@@ -1366,6 +1377,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
     request_amp(p.n_first);
     for (int it = 0; it < nsteps; ++it) {
         const int n = p.n_first - it;
+        EC_LAGGARD();
         EC_STAMP(0);
         // ---- A ----------------------------------------------------------------------------------------
         float4 mL[NG], mM[NG], mMu[NG];

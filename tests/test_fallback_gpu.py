@@ -134,12 +134,15 @@ mat = torch.tensor(ce["mat"], dtype=torch.float32, device=dev, requires_grad=Tru
 ef = torch.tensor(ce["f"], dtype=torch.float32, device=dev)
 vx, vz = elastic.propagate(mat, ef, *t(ce, "pz", "px", "sc", "sw", "rc", "rw"), ce["fw"])
 torch.autograd.backward([vx, vz], [torch.sign(vx.detach()), torch.sign(vz.detach())])
+from physicsbasedfwi2_amd import _lib
+lib = _lib.load()
 np.savez(sys.argv[1], rec=rec.detach().cpu().numpy(), gr=r.grad.cpu().numpy(), vx=vx.detach().cpu().numpy(),
-         vz=vz.detach().cpu().numpy(), gm=mat.grad.cpu().numpy())
+         vz=vz.detach().cpu().numpy(), gm=mat.grad.cpu().numpy(),
+         counts=np.array([lib.mifwi_fallback_count(), lib.mifwi_agent_handoff_count(), lib.mifwi_slow_handoff_count()]))
 """
 
 
-@pytest.mark.parametrize("bit", ["64", "128"])
+@pytest.mark.parametrize("bit", ["64", "128", "4096"])
 def test_a_workgroup_that_never_shows_up_times_out_on_the_device_and_the_call_falls_back(tmp_path, bit):
     """The device side of the time-out, once: in the ablation build (libmifwi_ablations.so, built by
     __graft_entry__.build() with -DMIFWI_ABLATIONS) debug bit 64 makes slab 1 of the first shot of every
@@ -148,7 +151,11 @@ def test_a_workgroup_that_never_shows_up_times_out_on_the_device_and_the_call_fa
     traces bit for bit, gradients to summation order.
     Bit 128: every workgroup reports a different XCD.  The hand-off granules are published with stores that stay in
     the XCD's L2, so the slabs of a shot must share an XCD; the placement check at the head of the kernels
-    (mifwi::same_xcd) sees the mismatch, the launch bails out at once and the call falls back the same way."""
+    (mifwi::same_xcd) sees the mismatch and the launch bails out at once; the host then repeats it with granules published
+    through the fabric (the AG kernel variants: correct on any placement) - still ONE launch per time loop, no fall-back
+    to the per-step kernels, the same bits (mifwi_agent_handoff_count() > 0, mifwi_fallback_count() == 0).
+    Bit 4096: slab 1 of the first shot stalls ~10 ms at every 64th step - late, not absent, as on a GPU shared with another
+    process.  Nobody times out, results are the same, and mifwi_slow_handoff_count() says what happened."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "physicsbasedfwi2_amd", "libmifwi_ablations.so")
     if not os.path.exists(lib):
@@ -163,6 +170,14 @@ def test_a_workgroup_that_never_shows_up_times_out_on_the_device_and_the_call_fa
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(dict(np.load(out)))
     ref, abl = outs
+    fb, ag, slow = (int(v) for v in abl["counts"])
+    assert [int(v) for v in ref["counts"]] == [0, 0, 0]
+    if bit == "64":
+        assert fb >= 4 and ag == 0                  # acoustic + elastic, forward + adjoint
+    elif bit == "128":
+        assert fb == 0 and ag >= 4 and slow == 0
+    else:
+        assert fb == 0 and ag == 0 and slow >= 4
     assert np.abs(ref["rec"]).max() > 0 and np.array_equal(ref["rec"], abl["rec"])
     assert np.array_equal(ref["vx"], abl["vx"]) and np.array_equal(ref["vz"], abl["vz"])
     assert rel_l2(abl["gr"], ref["gr"]) <= 2e-5 and rel_l2(abl["gm"], ref["gm"]) <= 2e-5
