@@ -669,6 +669,7 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
     for _ in range(args.warmup):
         one_step(False)
     barrier()
+    torch.cuda.reset_peak_memory_stats(dev)
     losses, gsums = [], []
     from physicsbasedfwi2_amd import _lib as _mifwi_lib
     fallbacks0 = int(_mifwi_lib.load().mifwi_fallback_count())
@@ -769,6 +770,9 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
                    "kernel_family": wl.kernel_family(),
                    "snapshots": getattr(wl, "elastic", None) and wl.elastic.snapshot_mode() or "f32"},
         "check": check,
+        "memory": {"peak_allocated_GiB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                   "peak_reserved_GiB": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
+                   "note": "torch allocator, timed passes only (snapshots or checkpoints + work buffers + data)"},
         "ranks": ranks,
         "roofline": roofline_of(kern, dom, interior),
         "kernels": kern,
@@ -907,7 +911,7 @@ def main():
     primary = args.workload or "elastic_marmousi"
     out = run_workload(primary, args, dev, rank, world, want_cpu)
     if args.workload is None and not args.no_also:
-        keys = ("config", "value", "unit", "steps", "warmup", "ms_per_step", "check", "ranks", "roofline", "kernels",
+        keys = ("config", "value", "unit", "steps", "warmup", "ms_per_step", "check", "memory", "ranks", "roofline", "kernels",
                 "kernels_note", "cpu_baseline", "note")
         also = [run_workload("acoustic_marmousi", args, dev, rank, world, want_cpu)]
         # BASELINE names no elastic grid - the same survey on the 10 m Marmousi-II grid 350x1700, where

@@ -172,6 +172,48 @@ def _acoustic_gradient_devito(self, r, q0, q1, rec_cell, rec_w, res, U_dev, s, h
     return grad
 
 
+def _acoustic_cpml_forward(self, r, ab0, ab1, f, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0, save=False):
+    """oracle/acoustic_cpml.c: the scalar scheme with a second-order C-PML.  ab0 [2,n0], ab1 [2,n1] = the a and b
+    profiles of the layer along each axis (zero outside it); everything else as :meth:`acoustic_forward`."""
+    r = self._r(r); ab0 = self._r(ab0); ab1 = self._r(ab1); f = self._r(f)
+    src_cell = self._i(src_cell); rec_cell = self._i(rec_cell)
+    src_w = self._r(src_w); rec_w = self._r(rec_w)
+    n0, n1 = r.shape
+    nt, ns, nsrc = f.shape
+    nrec, ntap = rec_cell.shape[1], rec_cell.shape[2]
+    assert ab0.shape == (2, n0) and ab1.shape == (2, n1)
+    cfg = self.AcCfg(n0, n1, nt, ns, nsrc, nrec, ntap, c0, c1)
+    rec = np.zeros((nt, ns, nrec), dtype=self.dtype)
+    G = np.zeros((nt, ns, n0, n1), dtype=self.dtype) if save else None
+    st = self.lib.oracle_acoustic_cpml_forward(ctypes.byref(cfg), self._p(r), self._p(ab0), self._p(ab1), self._p(f),
+                                               self._p(src_cell), self._p(src_w), self._p(rec_cell), self._p(rec_w),
+                                               self._p(rec), self._p(G))
+    if st != 0:
+        raise MemoryError("oracle_acoustic_cpml_forward failed")
+    return (rec, G) if save else rec
+
+
+def _acoustic_cpml_backward(self, r, ab0, ab1, src_cell, src_w, rec_cell, rec_w, g, G, c0=1.0, c1=1.0,
+                            want_grad_f=True):
+    r = self._r(r); ab0 = self._r(ab0); ab1 = self._r(ab1); g = self._r(g); G = self._r(G)
+    src_cell = self._i(src_cell); rec_cell = self._i(rec_cell)
+    src_w = self._r(src_w); rec_w = self._r(rec_w)
+    n0, n1 = r.shape
+    nt, ns, nrec = g.shape
+    nsrc, ntap = src_cell.shape[1], src_cell.shape[2]
+    cfg = self.AcCfg(n0, n1, nt, ns, nsrc, nrec, ntap, c0, c1)
+    grad_r = np.zeros((n0, n1), dtype=self.dtype)
+    grad_f = np.zeros((nt, ns, nsrc), dtype=self.dtype) if want_grad_f else None
+    st = self.lib.oracle_acoustic_cpml_backward(ctypes.byref(cfg), self._p(r), self._p(ab0), self._p(ab1),
+                                                self._p(src_cell), self._p(src_w), self._p(rec_cell), self._p(rec_w),
+                                                self._p(g), self._p(G), self._p(grad_r), self._p(grad_f))
+    if st != 0:
+        raise MemoryError("oracle_acoustic_cpml_backward failed")
+    return grad_r, grad_f
+
+
+Oracle.acoustic_cpml_forward = _acoustic_cpml_forward
+Oracle.acoustic_cpml_backward = _acoustic_cpml_backward
 Oracle.acoustic_forward_order = _acoustic_forward_order
 Oracle.acoustic_gradient_devito = _acoustic_gradient_devito
 
