@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define MIFWI_VERSION_MAJOR 0
-#define MIFWI_VERSION_MINOR 5   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format; 4: mifwi_fallback_count; 5: mifwi_agent_handoff_count, mifwi_slow_handoff_count */
+#define MIFWI_VERSION_MINOR 5   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format; 4: mifwi_fallback_count; 5: mifwi_agent_handoff_count, mifwi_slow_handoff_count; acoustic desc gained cpml_width, layout state_elems */
 
 enum {
     MIFWI_OK = 0,
@@ -81,6 +81,17 @@ typedef struct {
     int32_t edge_rows;     /* optional hint: rows of absorbing layer at the top and at the bottom
                               (0 = unknown); lets the single-launch kernels give the layer slabs
                               of its own.  Results do not depend on it.                       */
+    int32_t cpml_width;    /* 0: absorbing layer = the sponge q0, q1.  W > 0: second-order convolutional
+                              PML, W cells wide on all four sides (what deepwave.scalar.Propagator's
+                              pml_width is, models/networks.py:5408-5411):
+                                psi_d <- b psi_d + a d_d u;  zeta_d <- b zeta_d + a (d_d^2 u + d_d psi_d)
+                                u_tt = vp^2 sum_d [d_d^2 u + d_d psi_d + zeta_d]
+                              with its exact transposed adjoint (DESIGN.md section 3,
+                              oracle/acoustic_cpml.c).  The q0 / q1 arguments of the calls then carry the
+                              layer's profiles instead of the sponge: q0 = [2][n0] (a, b along axis 0),
+                              q1 = [2][gp] (a, b along axis 1), zero outside the layer.  One launch per
+                              step family; the wavefield state grows by the memory variables
+                              (layout.state_elems).                                              */
 } mifwi_acoustic_desc;
 
 typedef struct mifwi_acoustic_plan mifwi_acoustic_plan;
@@ -99,6 +110,8 @@ typedef struct {
     int64_t coef_elems;           /* n0*gp                                                   */
     int64_t work_forward_elems;   /* size of `work` for mifwi_acoustic_forward               */
     int64_t work_backward_elems;  /* size of `work` for mifwi_acoustic_backward              */
+    int64_t state_elems;          /* head of `work` that is the forward state a checkpoint must keep:
+                                     2*field_elems (+ the C-PML memory variables)             */
 } mifwi_acoustic_layout;
 
 int mifwi_acoustic_plan_layout(const mifwi_acoustic_plan *plan, mifwi_acoustic_layout *out);

@@ -24,14 +24,15 @@ class AcousticDesc(ctypes.Structure):
     _fields_ = [("n0", ctypes.c_int32), ("n1", ctypes.c_int32), ("nt", ctypes.c_int32),
                 ("nshot", ctypes.c_int32), ("nsrc", ctypes.c_int32), ("nrec", ctypes.c_int32),
                 ("ntap", ctypes.c_int32), ("c0", ctypes.c_float), ("c1", ctypes.c_float),
-                ("shots_per_group", ctypes.c_int32), ("edge_rows", ctypes.c_int32)]
+                ("shots_per_group", ctypes.c_int32), ("edge_rows", ctypes.c_int32),
+                ("cpml_width", ctypes.c_int32)]
 
 
 class AcousticLayout(ctypes.Structure):
     _fields_ = [("gp", ctypes.c_int32), ("pitch", ctypes.c_int32), ("ngroups", ctypes.c_int32),
                 ("shots_per_group", ctypes.c_int32), ("field_elems", ctypes.c_int64),
                 ("coef_elems", ctypes.c_int64), ("work_forward_elems", ctypes.c_int64),
-                ("work_backward_elems", ctypes.c_int64)]
+                ("work_backward_elems", ctypes.c_int64), ("state_elems", ctypes.c_int64)]
 
 
 class ElasticDesc(ctypes.Structure):

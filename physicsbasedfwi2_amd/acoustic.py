@@ -21,10 +21,10 @@ class AcousticPlan:
     """RAII wrapper of ``mifwi_acoustic_plan`` (include/mifwi.h)."""
 
     def __init__(self, n0, n1, nt, nshot, nsrc, nrec, ntap, c0, c1, device_index,
-                 shots_per_group=0, edge_rows=0):
+                 shots_per_group=0, edge_rows=0, cpml_width=0):
         self._lib = _lib.load()
         self.desc = _lib.AcousticDesc(n0, n1, nt, nshot, nsrc, nrec, ntap, c0, c1,
-                                      shots_per_group, int(edge_rows))
+                                      shots_per_group, int(edge_rows), int(cpml_width))
         self._h = ctypes.c_void_p()
         _lib.check(self._lib.mifwi_acoustic_plan_create(ctypes.byref(self._h), device_index,
                                                         ctypes.byref(self.desc)))
@@ -88,7 +88,7 @@ class _Geometry:
 
 class _AcousticFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, r, f, q0, q1, geom, c0, c1, shots_per_group, snapshot_budget, edge_rows):
+    def forward(ctx, r, f, q0, q1, geom, c0, c1, shots_per_group, snapshot_budget, edge_rows, cpml_width=0):
         _require_cuda(r, "r")
         dev = r.device
         lib = _lib.load()
@@ -105,14 +105,20 @@ class _AcousticFn(torch.autograd.Function):
             raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (n0, n1))
         with torch.cuda.device(dev):
             plan = AcousticPlan(n0, n1, nt, ns, nsrc, nrec, ntap, c0, c1, dev.index,
-                                shots_per_group, edge_rows)
+                                shots_per_group, edge_rows, cpml_width)
             lay = plan.layout
             gp = lay.gp
             r_p = torch.zeros((n0, gp), device=dev, dtype=torch.float32)
             r_p[:, :n1] = r.detach()
             q0_d = q0.to(device=dev, dtype=torch.float32).contiguous()
-            q1_p = torch.zeros(gp, device=dev, dtype=torch.float32)
-            q1_p[:n1] = q1.to(device=dev, dtype=torch.float32)
+            if cpml_width > 0:                   # q0 / q1 carry the layer's a, b profiles: [2, n0], [2, n1] -> [2, gp]
+                if tuple(q0.shape) != (2, n0) or tuple(q1.shape) != (2, n1):
+                    raise MifwiError("cpml_width > 0: q0 / q1 must be the [2, n0] / [2, n1] C-PML profiles (a, b)")
+                q1_p = torch.zeros((2, gp), device=dev, dtype=torch.float32)
+                q1_p[:, :n1] = q1.to(device=dev, dtype=torch.float32)
+            else:
+                q1_p = torch.zeros(gp, device=dev, dtype=torch.float32)
+                q1_p[:n1] = q1.to(device=dev, dtype=torch.float32)
             f_d = f.detach().to(dtype=torch.float32).contiguous()
             rec = torch.empty((nt, ns, nrec), device=dev, dtype=torch.float32)
             work = torch.empty(lay.work_forward_elems, device=dev, dtype=torch.float32)
@@ -137,9 +143,9 @@ class _AcousticFn(torch.autograd.Function):
                 _lib.check(lib.mifwi_acoustic_forward(*args, _lib.ptr(snap), _lib.ptr(work), 0, nt,
                                                       _lib.ZERO_STATE, _stream()))
             else:
-                # checkpoint the two-level state at every segment start, no snapshots yet
+                # checkpoint the state (two time levels + C-PML memory variables) at every segment start, no snapshots yet
                 ckpt = []
-                state_elems = 2 * lay.field_elems
+                state_elems = lay.state_elems
                 for b in range(0, nt, seg):
                     flags = _lib.ZERO_STATE if b == 0 else 0
                     if b > 0:
@@ -189,7 +195,7 @@ class _AcousticFn(torch.autograd.Function):
                 seg = ctx.seg
                 fwork = torch.empty(lay.work_forward_elems, device=dev, dtype=torch.float32)
                 snap = torch.empty((seg, ns, n0, lay.gp), device=dev, dtype=torch.float32)
-                state_elems = 2 * lay.field_elems
+                state_elems = lay.state_elems
                 starts = list(range(0, nt, seg))
                 first = True
                 for si in reversed(range(len(starts))):
@@ -217,12 +223,16 @@ class _AcousticFn(torch.autograd.Function):
             ctx.plan = None
             ctx.snap = None
             ctx.ckpt = None
-        return (grad_r[:, :n1].contiguous(), grad_f, None, None, None, None, None, None, None, None)
+        return (grad_r[:, :n1].contiguous(), grad_f, None, None, None, None, None, None, None, None, None)
 
 
 def propagate(r, f, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
-              shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET, edge_rows=0):
+              shots_per_group=0, snapshot_budget=DEFAULT_SNAPSHOT_BUDGET, edge_rows=0, cpml_width=0):
     """Run the acoustic propagator (differentiable w.r.t. ``r`` and ``f``).
+
+    cpml_width = W > 0: the absorbing layer is a second-order convolutional PML of W cells on every side instead of
+    the sponge; q0 [2, n0] and q1 [2, n1] then hold its a and b profiles (``profiles.cpml_tables(...)[:2]``), zero
+    outside the layer.  Same call otherwise; runs on the one-launch-per-step kernels.
 
     r   [n0,n1]  = vp^2 dt^2 / h^2 on the computational (already padded) grid
     f   [nt,nshot,nsrc] source amplitudes (the injected term is  w * f[n] * r[cell])
@@ -235,7 +245,7 @@ def propagate(r, f, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
     geom = _Geometry(src_cell, src_w, rec_cell, rec_w, r.device)
     f = f.to(device=r.device)
     ntap = geom.src_cell.shape[2]
-    if ntap > 1 and _flatten_taps_pays(r, f, geom, c0, c1, edge_rows):
+    if ntap > 1 and not cpml_width and _flatten_taps_pays(r, f, geom, c0, c1, edge_rows):
         # Bilinear taps (the Devito-shaped protocol) as independent single-cell points: every tap becomes
         # a source / receiver of its own, which makes the single-launch time loop eligible; the taps of a
         # point are recombined by differentiable torch ops (sum over the tap axis, repeat of f).
@@ -248,7 +258,7 @@ def propagate(r, f, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
                                 int(shots_per_group), int(snapshot_budget), int(edge_rows))
         return rec.reshape(rec.shape[0], ns, nrec, ntap).sum(dim=3)
     return _AcousticFn.apply(r, f, q0, q1, geom, float(c0), float(c1), int(shots_per_group),
-                             int(snapshot_budget), int(edge_rows))
+                             int(snapshot_budget), int(edge_rows), int(cpml_width))
 
 
 def _flatten_taps_pays(r, f, geom, c0, c1, edge_rows):
@@ -270,7 +280,7 @@ def _flatten_taps_pays(r, f, geom, c0, c1, edge_rows):
 
 
 def born(r, f, dr, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
-         snapshot_budget=DEFAULT_SNAPSHOT_BUDGET):
+         snapshot_budget=DEFAULT_SNAPSHOT_BUDGET, cpml_width=0):
     """Born / linearised modelling (``AcousticWaveSolver.born``, wavesolver.py:174-209;
     ``BornOperator``, operators.py:168-207): returns ``(rec, drec)`` where ``rec`` are the seismograms
     of the background model ``r`` and ``drec = J dr`` their first-order change for the perturbation
@@ -289,7 +299,7 @@ def born(r, f, dr, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
     if tops and int(torch.stack(tops).max()) >= n0 * n1:
         raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (n0, n1))
     with torch.cuda.device(dev), torch.no_grad():
-        plan = AcousticPlan(n0, n1, nt, ns, nsrc, nrec, ntap, float(c0), float(c1), dev.index, 0)
+        plan = AcousticPlan(n0, n1, nt, ns, nsrc, nrec, ntap, float(c0), float(c1), dev.index, 0, 0, int(cpml_width))
         lay = plan.layout
         gp = lay.gp
         if 4 * nt * ns * lay.coef_elems > snapshot_budget:
@@ -300,8 +310,12 @@ def born(r, f, dr, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
         dr_p = torch.zeros((n0, gp), device=dev, dtype=torch.float32)
         dr_p[:, :n1] = dr.detach().to(dev)
         q0_d = q0.to(device=dev, dtype=torch.float32).contiguous()
-        q1_p = torch.zeros(gp, device=dev, dtype=torch.float32)
-        q1_p[:n1] = q1.to(device=dev, dtype=torch.float32)
+        if cpml_width:
+            q1_p = torch.zeros((2, gp), device=dev, dtype=torch.float32)
+            q1_p[:, :n1] = q1.to(device=dev, dtype=torch.float32)
+        else:
+            q1_p = torch.zeros(gp, device=dev, dtype=torch.float32)
+            q1_p[:n1] = q1.to(device=dev, dtype=torch.float32)
         f_d = f.detach().to(device=dev, dtype=torch.float32).contiguous()
         rec = torch.empty((nt, ns, nrec), device=dev, dtype=torch.float32)
         drec = torch.empty((nt, ns, nrec), device=dev, dtype=torch.float32)

@@ -60,7 +60,12 @@ struct AcParams {
     int tiles_z;                 // grid.y rows that are stencil tiles; the rest sample
     int xcd;                     // 1: XCD-contiguous tile order (xcd_tile)
     int g0;                      // first shot group of this pass over the time range (blockIdx.z counts from it)
+    // second-order C-PML (ac_step<..., PML = true>, mifwi_acoustic_cpml.h): the layer's term, region-compact
+    int pmlW, pml_adj;           // layer width; 0: forward combination fma(c0, e0, c1 e1), 1: adjoint e0 + e1
+    const float *pe0, *pe1;      // [nshot][2][W+2][gp], [nshot][n0][2][W+2]
 };
+
+#include "mifwi_acoustic_cpml.h"
 
 __device__ __forceinline__ float comp(const float4 &v, int c)
 {
@@ -111,7 +116,7 @@ __device__ void sample_points(const AcParams &p, int bx, int by)
     }
 }
 
-template <int LX, int RZ, bool SAVE, bool IMAGE>
+template <int LX, int RZ, bool SAVE, bool IMAGE, bool PML = false>
 __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
 {
     constexpr int LZ = kThreads / LX;
@@ -214,6 +219,25 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
                         drv = *reinterpret_cast<const float4 *>(p.born_dr + (long long)j * p.gp + 4 * g);
                     const float xs[8] = {L.x, L.y, w2.x, w2.y, w2.z, w2.w, R.x, R.y};
                     float un[4], gk[4];
+                    float pe[4] = {0.f, 0.f, 0.f, 0.f};        // C-PML: the layer's term of the four cells
+                    if (PML) {
+                        const int W2 = p.pmlW + 2;
+                        float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float *pe0 = p.pe0 + (long long)s * 2 * W2 * p.gp;
+                        if (j < W2) e0 = *reinterpret_cast<const float4 *>(pe0 + (long long)j * p.gp + 4 * g);
+                        else if (j >= p.n0 - W2)
+                            e0 = *reinterpret_cast<const float4 *>(pe0 + (long long)(W2 + j - (p.n0 - W2)) * p.gp + 4 * g);
+                        const float *pe1 = p.pe1 + ((long long)s * p.n0 + j) * 2 * W2;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int i1 = 4 * g + c;
+                            float e1 = 0.f;
+                            if (i1 < W2) e1 = pe1[i1];
+                            else if (i1 >= p.n1 - W2 && i1 < p.n1) e1 = pe1[W2 + i1 - (p.n1 - W2)];
+                            const float e0c = comp(e0, c);
+                            pe[c] = p.pml_adj ? e0c + e1 : fmaf(p.c0, e0c, p.c1 * e1);
+                        }
+                    }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float uc = xs[c + 2];
@@ -223,7 +247,8 @@ __global__ __launch_bounds__(kThreads) void ac_step(const AcParams p)
                         const float s12 = xs[c] + xs[c + 4];
                         const float l0 = fmaf(K1, s01, fmaf(K2, s02, K0 * uc));
                         const float l1 = fmaf(K1, s11, fmaf(K2, s12, K0 * uc));
-                        const float lap = fmaf(p.c0, l0, p.c1 * l1);
+                        float lap = fmaf(p.c0, l0, p.c1 * l1);
+                        if (PML) lap += pe[c];
                         const float rv = comp(rr[rz], c);
                         const float q = q0v[rz] + comp(q1v, c);
                         const float qr = q * rv;
@@ -1038,6 +1063,9 @@ struct mifwi_acoustic_plan {
     // cluster path (LDS-resident time loop), 0 when the shot does not fit
     int cluster, NW, PL, cl_shots, cl_lds, rt;
     long long xbuf_elems, list_elems;      // in floats
+    // second-order C-PML (desc.cpml_width > 0; one launch per step family only)
+    int pmlW;
+    long long pml_persist, pml_scratch, zq_elems;      // floats, all shots: memory variables | scratch + e | zero q0, q1
 };
 
 namespace {
@@ -1046,6 +1074,10 @@ template <int LX, bool SAVE, bool IMAGE>
 void launch_rz(const mifwi_acoustic_plan *pl, dim3 grid, const AcParams &q, hipStream_t st)
 {
     dim3 block(kThreads);
+    if (q.pmlW > 0) {                  // C-PML plans march two rows per thread (plan_create pins rz)
+        hipLaunchKernelGGL((ac_step<LX, 2, SAVE, IMAGE, true>), grid, block, 0, st, q);
+        return;
+    }
     switch (pl->rz) {
         case 8: hipLaunchKernelGGL((ac_step<LX, 8, SAVE, IMAGE>), grid, block, 0, st, q); break;
         case 2: hipLaunchKernelGGL((ac_step<LX, 2, SAVE, IMAGE>), grid, block, 0, st, q); break;
@@ -1091,12 +1123,46 @@ AcParams base_params(const mifwi_acoustic_plan *pl, const float *r, const float 
     return p;
 }
 
+// ---- C-PML helpers -------------------------------------------------------------------------------------
+// persist: [A0 | B0 | A1 | B1], scratch: [P0 | Q0 | P1 | Q1 | e0 | e1], every array shot-major
+AcPml pml_params(const mifwi_acoustic_plan *pl, const float *ab0, const float *ab1, float *persist, float *scratch)
+{
+    AcPml m;
+    memset(&m, 0, sizeof(m));
+    const mifwi_acoustic_desc &d = pl->d;
+    const long long ns = d.nshot;
+    m.W = pl->pmlW; m.n0 = d.n0; m.n1 = d.n1; m.gp = pl->gp; m.pitch = pl->pitch; m.shot_stride = pl->shot_stride;
+    m.ab0 = ab0; m.ab1 = ab1; m.c0 = d.c0; m.c1 = d.c1; m.nshot = d.nshot;
+    m.s0 = 2LL * m.W * pl->gp; m.s1 = 2LL * m.W * d.n0;
+    m.r0 = 2LL * (m.W + 2) * pl->gp; m.r1 = 2LL * (m.W + 2) * d.n0;
+    m.A0 = persist; m.B0 = m.A0 + ns * m.s0; m.A1 = m.B0 + ns * m.s0; m.B1 = m.A1 + ns * m.s1;
+    m.P0 = scratch; m.Q0 = m.P0 + ns * m.s0; m.P1 = m.Q0 + ns * m.s0; m.Q1 = m.P1 + ns * m.s1;
+    m.e0 = m.Q1 + ns * m.s1; m.e1 = m.e0 + ns * m.r0;
+    return m;
+}
+// the thin launches of one step for shots [shot0, shot0 + count): forward (Psi, Z, e) or adjoint (P/Zb, Q/Pb, e)
+void pml_step(const AcPml &m0, const float *cur, int shot0, int count, bool adjoint, hipStream_t st)
+{
+    AcPml m = m0;
+    m.shot0 = shot0;
+    const long long cells = 2LL * (m.W + 2) * ((long long)m.n1 + m.n0);
+    const dim3 grid((unsigned)((cells + kThreads - 1) / kThreads), (unsigned)count), block(kThreads);
+    if (!adjoint) {
+        hipLaunchKernelGGL(ac_pml_fwd_psi, grid, block, 0, st, m, cur);
+        hipLaunchKernelGGL(ac_pml_fwd_zeta, grid, block, 0, st, m, cur);
+    } else {
+        hipLaunchKernelGGL(ac_pml_adj_a, grid, block, 0, st, m, cur);
+        hipLaunchKernelGGL(ac_pml_adj_b, grid, block, 0, st, m, cur);
+        hipLaunchKernelGGL(ac_pml_adj_c, grid, block, 0, st, m, cur);
+    }
+}
+
 // ---- cluster path helpers --------------------------------------------------------------------------
 void cluster_setup(mifwi_acoustic_plan *pl)
 {
     pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0; pl->rt = 0;
     pl->xbuf_elems = 0; pl->list_elems = 0;
-    if (env_int("MIFWI_AC_CLUSTER", 1) == 0 || pl->d.ntap != 1) return;
+    if (env_int("MIFWI_AC_CLUSTER", 1) == 0 || pl->d.ntap != 1 || pl->pmlW > 0) return;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device) != hipSuccess) return;
     const int forced = env_int("MIFWI_AC_NW", 0);
@@ -1294,6 +1360,8 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
         return mifwi::fail(MIFWI_EINVAL, "bad sizes n0=%d n1=%d nt=%d nshot=%d", d->n0, d->n1,
                            d->nt, d->nshot);
     if (d->ntap != 1 && d->ntap != 4) return mifwi::fail(MIFWI_EINVAL, "ntap must be 1 or 4");
+    if (d->cpml_width < 0 || (d->cpml_width > 0 && (d->n0 < 2 * d->cpml_width + 4 || d->n1 < 2 * d->cpml_width + 4)))
+        return mifwi::fail(MIFWI_EINVAL, "grid %dx%d cannot hold a %d-cell C-PML on every side", d->n0, d->n1, d->cpml_width);
     int rc = mifwi::check_device(device);
     if (rc) return rc;
     // function attributes and CU counts queried during set-up belong to THIS device (one process per
@@ -1304,6 +1372,10 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
     pl->device = device;
     pl->ng = mifwi::ceil_div(d->n1, 4);
     pl->gp = 4 * pl->ng;
+    pl->pmlW = d->cpml_width;
+    pl->pml_persist = pl->pmlW > 0 ? d->nshot * pml_persist_per_shot(pl->pmlW, d->n0, pl->gp) : 0;
+    pl->pml_scratch = pl->pmlW > 0 ? d->nshot * pml_scratch_per_shot(pl->pmlW, d->n0, pl->gp) : 0;
+    pl->zq_elems = pl->pmlW > 0 ? mifwi::round_up64((long long)d->n0 + pl->gp, 64) : 0;
     // one halo group left, interior, two spare groups right, rounded to 128-B lines
     pl->pitch = (int)mifwi::round_up64(4 * (pl->ng + 3), 32);
     pl->shot_stride = (long long)(d->n0 + 4) * pl->pitch;
@@ -1320,6 +1392,7 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
     // tuning overrides (benchmarks only)
     { const int v = env_int("MIFWI_AC_LX", 0); if (v == 16 || v == 32 || v == 64) pl->lx = v; }
     { const int v = env_int("MIFWI_AC_RZ", 0); if (v == 1 || v == 2 || v == 4 || v == 8) pl->rz = v; }
+    if (pl->pmlW > 0) pl->rz = 2;       // the C-PML variant of ac_step is built for two rows per thread
     int gs = d->shots_per_group;
     if (gs <= 0) gs = env_int("MIFWI_AC_GS", 2);
     if (gs <= 0) gs = 2;
@@ -1385,9 +1458,11 @@ int mifwi_acoustic_plan_layout(const mifwi_acoustic_plan *pl, mifwi_acoustic_lay
     const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
     const long long cl = pl->cluster ? pl->xbuf_elems + pl->list_elems : 0;
     // single-launch plans: room for a copy of the input state of a resumed call (cluster_backup)
-    out->work_forward_elems = 2 * pl->field_elems + bbox + cl + (pl->cluster ? 2 * pl->field_elems : 0);
-    out->work_backward_elems = 2 * pl->field_elems + pl->ngroups * pl->coef_elems + bbox + cl +
+    const long long pml = pl->pml_persist + pl->pml_scratch + pl->zq_elems;
+    out->work_forward_elems = 2 * pl->field_elems + pml + bbox + cl + (pl->cluster ? 2 * pl->field_elems : 0);
+    out->work_backward_elems = 2 * pl->field_elems + pl->ngroups * pl->coef_elems + pml + bbox + cl +
                                (pl->cluster ? 2 * pl->field_elems + pl->ngroups * pl->coef_elems : 0);
+    out->state_elems = 2 * pl->field_elems + pl->pml_persist;
     return MIFWI_OK;
 }
 
@@ -1410,20 +1485,31 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *pl, const float *r, const float 
     MIFWI_HIP_TRY(hipSetDevice(pl->device));
     hipStream_t st = (hipStream_t)stream;
     float *ua = work, *ub = work + pl->field_elems;
-    int *bbox = reinterpret_cast<int *>(work + 2 * pl->field_elems);
+    // C-PML plans: [ua | ub | memory variables | scratch + e | zero q0, q1 | bbox]; q0 / q1 carry the a, b profiles
+    float *pml_persist = work + 2 * pl->field_elems, *pml_scratch = pml_persist + pl->pml_persist;
+    float *zq = pml_scratch + pl->pml_scratch;
+    int *bbox = reinterpret_cast<int *>(zq + pl->zq_elems);
     if (flags & MIFWI_ZERO_STATE)
-        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * 2 * pl->field_elems, st));
+        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (2 * pl->field_elems + pl->pml_persist), st));
+    AcPml pm;
+    memset(&pm, 0, sizeof(pm));
+    if (pl->pmlW > 0) {
+        MIFWI_HIP_TRY(hipMemsetAsync(zq, 0, sizeof(float) * pl->zq_elems, st));
+        pm = pml_params(pl, q0, q1, pml_persist, pml_scratch);
+        q0 = zq; q1 = zq + d.n0;
+    }
     if (d.nsrc > 0)
         hipLaunchKernelGGL(points_bbox, dim3(d.nshot), dim3(kThreads), 0, st, src_cell,
                            d.nsrc * d.ntap, d.n1, bbox);
     AcParams p = base_params(pl, r, q0, q1);
+    p.pmlW = pl->pmlW; p.pml_adj = 0; p.pe0 = pm.e0; p.pe1 = pm.e1;
     p.ninj = d.nsrc; p.ntap_inj = d.ntap; p.inj_mode = 0;
     p.inj_cell = src_cell; p.inj_w = src_w; p.inj_bbox = bbox;
     p.nsmp = rec_out ? d.nrec : 0; p.ntap_smp = d.ntap; p.smp_mode = 0;
     p.smp_cell = rec_cell; p.smp_w = rec_w;
     const long long snap_step = (long long)d.nshot * pl->coef_elems;
     if (pl->cluster && n_end > n_begin) {
-        float *xbuf = work + 2 * pl->field_elems + mifwi::round_up64(4LL * d.nshot, 64);
+        float *xbuf = reinterpret_cast<float *>(bbox) + mifwi::round_up64(4LL * d.nshot, 64);
         ClParams c = cluster_params(pl, r, q0, q1, ua, ub, xbuf);
         c.n_first = n_begin; c.n_last = n_end;
         c.src_cell = src_cell; c.src_w = src_w; c.f = f;
@@ -1448,6 +1534,7 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *pl, const float *r, const float 
         p.prev = (n & 1) ? ua : ub;
         p.inj_amp = f ? f + (long long)n * d.nshot * d.nsrc : nullptr;
         p.smp_out = (rec_out && d.nrec > 0) ? rec_out + (long long)n * d.nshot * d.nrec : nullptr;
+        if (pl->pmlW > 0) pml_step(pm, p.cur, g0 * pl->gs, std::min(cg * pl->gs, d.nshot - g0 * pl->gs), false, st);
         if (snap) {
             p.G = snap + (long long)(n - n_begin) * snap_step;
             launch_step<true, false>(pl, p, st, cg);
@@ -1476,11 +1563,20 @@ int mifwi_acoustic_born(mifwi_acoustic_plan *pl, const float *r, const float *q0
     MIFWI_HIP_TRY(hipSetDevice(pl->device));
     hipStream_t st = (hipStream_t)stream;
     float *ua = work, *ub = work + pl->field_elems;
+    float *pml_persist = work + 2 * pl->field_elems, *pml_scratch = pml_persist + pl->pml_persist;
+    float *zq = pml_scratch + pl->pml_scratch;
     if (flags & MIFWI_ZERO_STATE)
-        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * 2 * pl->field_elems, st));
+        MIFWI_HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (2 * pl->field_elems + pl->pml_persist), st));
+    AcPml pm;
+    memset(&pm, 0, sizeof(pm));
+    if (pl->pmlW > 0) {
+        MIFWI_HIP_TRY(hipMemsetAsync(zq, 0, sizeof(float) * pl->zq_elems, st));
+        pm = pml_params(pl, q0, q1, pml_persist, pml_scratch);
+        q0 = zq; q1 = zq + d.n0;
+    }
     const long long snap_step = (long long)d.nshot * pl->coef_elems;
     if (pl->cluster && n_end > n_begin) {
-        float *xbuf = work + 2 * pl->field_elems + mifwi::round_up64(4LL * d.nshot, 64);
+        float *xbuf = zq + pl->zq_elems + mifwi::round_up64(4LL * d.nshot, 64);
         ClParams c = cluster_params(pl, r, q0, q1, ua, ub, xbuf);
         c.n_first = n_begin; c.n_last = n_end;
         c.nsrc = 0; c.src_cell = nullptr; c.src_w = nullptr; c.f = nullptr;      // no point source
@@ -1500,11 +1596,13 @@ int mifwi_acoustic_born(mifwi_acoustic_plan *pl, const float *r, const float *q0
     p.ninj = 0;
     p.nsmp = d.nrec; p.ntap_smp = d.ntap; p.smp_mode = 0; p.smp_cell = rec_cell; p.smp_w = rec_w;
     p.born_dr = dr;
+    p.pmlW = pl->pmlW; p.pml_adj = 0; p.pe0 = pm.e0; p.pe1 = pm.e1;
     for (int n = n_begin; n < n_end; ++n) {
         p.cur = (n & 1) ? ub : ua;
         p.prev = (n & 1) ? ua : ub;
         p.smp_out = d.nrec > 0 ? drec_out + (long long)n * d.nshot * d.nrec : nullptr;
         p.G = const_cast<float *>(snap) + (long long)(n - snap_first) * snap_step;
+        if (pl->pmlW > 0) pml_step(pm, p.cur, 0, d.nshot, false, st);
         launch_step<false, true>(pl, p, st);
     }
     MIFWI_HIP_TRY(hipGetLastError());
@@ -1534,14 +1632,26 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
     MIFWI_HIP_TRY(hipSetDevice(pl->device));
     hipStream_t st = (hipStream_t)stream;
     float *za = work, *zb = work + pl->field_elems;
-    float *acc = work + 2 * pl->field_elems;
-    int *bbox = reinterpret_cast<int *>(acc + (long long)pl->ngroups * pl->coef_elems);
+    // C-PML plans: [za | zb | adjoint memory variables | acc | scratch + e | zero q0, q1 | bbox]
+    float *pml_persist = work + 2 * pl->field_elems;
+    float *acc = pml_persist + pl->pml_persist;
+    float *pml_scratch = acc + (long long)pl->ngroups * pl->coef_elems;
+    float *zq = pml_scratch + pl->pml_scratch;
+    int *bbox = reinterpret_cast<int *>(zq + pl->zq_elems);
     if (flags & MIFWI_ZERO_STATE)
         MIFWI_HIP_TRY(hipMemsetAsync(
-            work, 0, sizeof(float) * (2 * pl->field_elems + pl->ngroups * pl->coef_elems), st));
+            work, 0, sizeof(float) * (2 * pl->field_elems + pl->pml_persist + pl->ngroups * pl->coef_elems), st));
+    AcPml pm;
+    memset(&pm, 0, sizeof(pm));
+    if (pl->pmlW > 0) {
+        MIFWI_HIP_TRY(hipMemsetAsync(zq, 0, sizeof(float) * pl->zq_elems, st));
+        pm = pml_params(pl, q0, q1, pml_persist, pml_scratch);
+        q0 = zq; q1 = zq + d.n0;
+    }
     hipLaunchKernelGGL(points_bbox, dim3(d.nshot), dim3(kThreads), 0, st, rec_cell,
                        d.nrec * d.ntap, d.n1, bbox);
     AcParams p = base_params(pl, r, q0, q1);
+    p.pmlW = pl->pmlW; p.pml_adj = 1; p.pe0 = pm.e0; p.pe1 = pm.e1;
     p.acc = acc;
     p.ninj = d.nrec; p.ntap_inj = d.ntap; p.inj_mode = 1;
     p.inj_cell = rec_cell; p.inj_w = rec_w; p.inj_bbox = bbox;
@@ -1588,7 +1698,9 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
         p.inj_amp = grad_rec + (long long)k * d.nshot * d.nrec;
         p.G = const_cast<float *>(snap) + (long long)(k - 1 - snap_first) * snap_step;
         p.smp_out = want_f ? grad_f + (long long)k * d.nshot * d.nsrc : nullptr;
-        launch_step<false, true>(pl, p, st, std::min(pl->pass_adj, pl->ngroups - g0));
+        const int cg = std::min(pl->pass_adj, pl->ngroups - g0);
+        if (pl->pmlW > 0) pml_step(pm, p.cur, g0 * pl->gs, std::min(cg * pl->gs, d.nshot - g0 * pl->gs), true, st);
+        launch_step<false, true>(pl, p, st, cg);
     }
     p.g0 = 0;
     if (flags & MIFWI_FINALIZE) {
@@ -1603,6 +1715,7 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
             const int extra =
                 mifwi::ceil_div(mifwi::ceil_div(pl->gs * s.nsmp, kThreads), tiles_x);
             dim3 grid(tiles_x, extra, pl->ngroups), block(kThreads);
+            s.pmlW = 0;                                         // sampling workgroups only: no stencil, no layer term
             hipLaunchKernelGGL((ac_step<16, 4, false, false>), grid, block, 0, st, s);
         }
         const long long ncoef = pl->coef_elems;

@@ -307,3 +307,103 @@ def test_deepwave_shim_substeps_when_dt_exceeds_the_stability_limit(oracle32):
     assert np.abs(rec_o).max() > 0 and rel_l2(rec.detach().cpu().numpy(), rec_o) <= 1e-5
     rec.square().sum().backward()
     assert torch.isfinite(vp.grad).all() and float(vp.grad.abs().max()) > 0
+
+
+def _cpml_case(seed=5, n0=70, n1=90, w=10, nt=150, ns=3, nrec=24, ntap=1, h=(10.0, 10.0)):
+    """acoustic_case with the sponge replaced by a W-cell C-PML: ab [2, n] = the a and b profiles of each axis."""
+    from oracle import helpers as H
+    c = acoustic_case(seed=seed, n0=n0, n1=n1, nb=w, nt=nt, ns=ns, nrec=nrec, ntap=ntap, h=h)
+    N0, N1 = c["shape"]
+    vmax = float(c["vp"].max())
+    c["ab0"] = H.cpml_profiles(N0, w, h[0], c["s"], vmax, 0.02)[:2]
+    c["ab1"] = H.cpml_profiles(N1, w, h[1], c["s"], vmax, 0.02)[:2]
+    c["w"] = w
+    # a source and a receiver INSIDE the layer as well (the reference puts both on the top row of the model)
+    if ntap == 1:
+        c["sc"][0, 0, 0] = 3 * N1 + N1 // 3
+        c["rc"][0, 0, 0] = 2 * N1 + 4
+    return c
+
+
+def _run_cpml(c, budget=None, need_f=True):
+    from physicsbasedfwi2_amd import acoustic
+    dev = torch.device("cuda:0")
+    r = torch.tensor(c["r"], dtype=torch.float32, device=dev, requires_grad=True)
+    f = torch.tensor(c["f"], dtype=torch.float32, device=dev, requires_grad=need_f)
+    kw = {} if budget is None else {"snapshot_budget": budget}
+    rec = acoustic.propagate(r, f, torch.tensor(c["ab0"]), torch.tensor(c["ab1"]), torch.tensor(c["sc"]),
+                             torch.tensor(c["sw"]), torch.tensor(c["rc"]), torch.tensor(c["rw"]), c["c0"], c["c1"],
+                             cpml_width=c["w"], **kw)
+    return r, f, rec
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(n0=41, n1=53, w=6, ns=2, nrec=9),                 # ragged sizes
+    dict(n0=60, n1=300, w=20, ns=2, nrec=40, nt=90),       # the reference's layer width, several tiles
+    dict(ntap=4, nrec=9),                                  # bilinear taps
+    dict(h=(10.0, 15.0)),                                  # anisotropic spacing: c0 != c1 in the layer's term
+])
+def test_cpml_forward_backward_parity(oracle32, kw):
+    """Second-order C-PML (desc.cpml_width; what deepwave's pml_width is, networks.py:5408-5411) through the per-step
+    kernels and their thin layer launches against oracle/acoustic_cpml.c: traces bit for bit, gradients <= 2e-5."""
+    c = _cpml_case(**kw)
+    o = oracle32
+    geo = (c["sc"], c["sw"], c["rc"], c["rw"])
+    rec_o, G_o = o.acoustic_cpml_forward(c["r"], c["ab0"], c["ab1"], c["f"], *geo, c["c0"], c["c1"], save=True)
+    r, f, rec = _run_cpml(c)
+    rec_h = rec.detach().cpu().numpy()
+    assert np.abs(rec_o).max() > 0 and np.isfinite(rec_h).all()
+    if c["sc"].shape[2] == 1:
+        assert np.abs(rec_h - rec_o).max() == 0.0
+    else:
+        assert rel_l2(rec_h, rec_o) <= TOL_TRACE
+    # the layer does something: the sponge-free scheme gives other traces
+    z0, z1 = np.zeros(c["shape"][0]), np.zeros(c["shape"][1])
+    plain = o.acoustic_forward(c["r"], z0, z1, c["f"], *geo, c["c0"], c["c1"])
+    assert rel_l2(plain, rec_o) > 1e-6
+    rng = np.random.default_rng(13)
+    g = (rng.standard_normal(rec_o.shape) * np.abs(rec_o).max()).astype(np.float32)
+    rec.backward(torch.tensor(g, device=rec.device))
+    gr_o, gf_o = o.acoustic_cpml_backward(c["r"], c["ab0"], c["ab1"], *geo, g, G_o, c["c0"], c["c1"])
+    assert rel_l2(r.grad.cpu().numpy(), gr_o) <= TOL_GRAD
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= TOL_GRAD
+
+
+def test_cpml_time_checkpointing_carries_the_memory_variables():
+    """The state a checkpoint keeps includes the layer's memory variables (layout.state_elems): a run cut into
+    segments equals the resident one bit for bit."""
+    c = _cpml_case(seed=9, nt=160)
+    r1, f1, rec1 = _run_cpml(c)
+    g = torch.sign(rec1.detach())
+    rec1.backward(g)
+    r2, f2, rec2 = _run_cpml(c, budget=1 << 20)
+    rec2.backward(g)
+    assert float(rec1.abs().max()) > 0 and torch.equal(rec1, rec2)
+    assert torch.equal(r1.grad, r2.grad) and torch.equal(f1.grad, f2.grad)
+
+
+def test_cpml_born_is_the_transpose_partner_of_the_gradient(oracle32):
+    from physicsbasedfwi2_amd import acoustic
+    c = _cpml_case(seed=21, ns=2, nt=120)
+    dev = torch.device("cuda:0")
+    t = lambda k: torch.tensor(c[k])
+    r = torch.tensor(c["r"], dtype=torch.float32, device=dev)
+    f = torch.tensor(c["f"], dtype=torch.float32, device=dev)
+    rng = np.random.default_rng(2)
+    dr = torch.tensor(c["r"] * 0.05 * rng.standard_normal(c["r"].shape), dtype=torch.float32, device=dev)
+    rec, drec = acoustic.born(r, f, dr, t("ab0"), t("ab1"), t("sc"), t("sw"), t("rc"), t("rw"), c["c0"], c["c1"],
+                              cpml_width=c["w"])
+    rr, ff, rec2 = _run_cpml(c, need_f=False)
+    assert torch.equal(rec, rec2.detach())
+    g = torch.tensor(rng.standard_normal(tuple(rec.shape)).astype(np.float32), device=dev)
+    rec2.backward(g)
+    lhs, rhs = float((drec.double() * g.double()).sum()), float((rr.grad.double() * dr.double()).sum())
+    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs))
+    # and J dr is the derivative of the forward map
+    eps = 1e-2
+    with torch.no_grad():
+        kw = dict(cpml_width=c["w"])
+        a = acoustic.propagate(r + eps * dr, f, t("ab0"), t("ab1"), t("sc"), t("sw"), t("rc"), t("rw"), c["c0"], c["c1"], **kw)
+        b = acoustic.propagate(r - eps * dr, f, t("ab0"), t("ab1"), t("sc"), t("sw"), t("rc"), t("rw"), c["c0"], c["c1"], **kw)
+    assert rel_l2(drec.cpu().numpy(), ((a - b) / (2 * eps)).cpu().numpy()) < 2e-2
