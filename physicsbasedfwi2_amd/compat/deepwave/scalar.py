@@ -12,15 +12,24 @@ pin against): the absorbing layer is the reference's in-tree spon
 (seisgan/fwi/pde/seismic/model.py:6-29), `pml_width` cells wide (default 20), the model is
 edge-replicated into it, and rec[n] samples the field before step n.
 
-``Propagator(..., absorbing="cpml")`` swaps the sponge for a convolutional PML of the same width: the scalar
-equation u_tt = vp^2 (lap u + f) is then advanced as the first-order pressure-velocity system on the staggered
-grid - the P-SV solver of this library in a fluid (Vs = 0, rho = 1), which carries the C-PML with memory variables
-on every derivative and its exact transposed adjoint (csrc/mifwi_elastic.hip; DENISE's PHYSICS = 2 runs the same
-way).  u is the pressure -(sxx + szz)/2; the source enters as the stress increment -vp^2 dt^2 cumsum(f) at the
-source cell, which makes the second time difference of u receive vp^2 dt^2 f exactly as in the sponge scheme.  Same
-orders of accuracy (2 in time, 4 in space), a different discretisation: inside the model the two modes agree to the
-discretisation error (tests/test_compat_gpu.py), at the edges the C-PML reflects an order of magnitude less.  Such
-runs use the one-launch-per-half-step kernels (pressure receivers).
+``Propagator(..., absorbing="cpml")`` makes ``pml_width`` what it is in deepwave - the width of a PML: a second-order
+convolutional PML inside the same scalar scheme (memory variables psi, zeta on the layer's cells only; exact
+transposed adjoint; csrc/mifwi_acoustic_cpml.h, oracle/acoustic_cpml.c).  The 20-cell layer returns 1.6e-4 of the
+direct wave where the 20-cell sponge returns 4e-2 (tests/test_acoustic_cpml_oracle.py); inside the model the two
+modes are the same scheme bit for bit.  It runs on the one-launch-per-step kernels; the sponge stays the default
+because it is what the single-launch time loops carry.  ``pml_freq`` (Hz) sets the frequency
+shift of the layer (default: a fifth of the source band's upper end, 0.25 / dt / 5).
+
+``absorbing="cpml-staggered"`` (round 2's C-PML) advances the scalar equation as the first-order pressure-velocity
+system on the staggered grid - the P-SV solver of this library in a fluid (Vs = 0, rho = 1) with its C-PML on every
+derivative (csrc/mifwi_elastic.hip; DENISE's PHYSICS = 2 runs the same way): u = -(sxx + szz)/2, source = the
+stress increment -vp^2 dt^2 cumsum(f).  Same orders of accuracy, a different discretisation (the two agree to the
+discretisation error inside the model); several times slower.
+
+``cfl``: the internal time step is dt / ceil(dt / dt_max).  "stability" (default): dt_max = 0.9 x the stability limit
+of the fourth-order stencil; "deepwave": deepwave's own bound dt_max = 0.6 / (vp_max sqrt(sum 1/dx_i^2)) (SURVEY.md
+appendix C) - 1.4x tighter, so a caller that wants deepwave's sub-step ratio (2 above 4243 m/s at dx = 10 m,
+dt = 1 ms) gets it; a number = that fraction of the stability limit.
 """
 import functools
 import math
@@ -94,12 +103,22 @@ def _sponge(n, width, d, h, dt, device):
     return torch.from_numpy(profiles.sponge_q(n, width, d, h, dt)).float().to(device)
 
 
+@functools.lru_cache(maxsize=32)
+def _cpml_ab(n, width, d, dt, vmax, fpml):
+    """a and b profiles of one axis of the second-order C-PML: [2, n], zero outside the layer."""
+    return torch.from_numpy(profiles.cpml_tables(n, width, d, dt, vmax, fpml)[:2].copy()).float()
+
+
 class Propagator(torch.nn.Module):
-    def __init__(self, model, dx, pml_width=None, survey_pad=None, vpmax=None, absorbing="sponge", pml_freq=None):
+    def __init__(self, model, dx, pml_width=None, survey_pad=None, vpmax=None, absorbing="sponge", pml_freq=None,
+                 cfl="stability"):
         super().__init__()
-        if absorbing not in ("sponge", "cpml"):
-            raise MifwiError("absorbing must be 'sponge' or 'cpml'")
+        if absorbing not in ("sponge", "cpml", "cpml-staggered"):
+            raise MifwiError("absorbing must be 'sponge', 'cpml' or 'cpml-staggered'")
+        if not (cfl in ("stability", "deepwave") or (isinstance(cfl, (int, float)) and 0 < cfl <= 1)):
+            raise MifwiError("cfl must be 'stability', 'deepwave' or a fraction of the stability limit in (0, 1]")
         self.absorbing = absorbing
+        self.cfl = cfl
         self.pml_freq = pml_freq                 # C-PML only: dominant frequency (Hz) of the frequency shift
         if not isinstance(model, dict) or "vp" not in model:
             raise MifwiError("model must be a dict holding 'vp'")
@@ -112,6 +131,12 @@ class Propagator(torch.nn.Module):
         self.vpmax = vpmax
         self.shots_per_group = 0
 
+    def _dt_max(self, limit, vmax):
+        """Largest internal time step for the given stability limit of the scheme in use."""
+        if self.cfl == "deepwave":
+            return min(limit, 0.6 / (vmax * math.sqrt(sum(1.0 / (h * h) for h in self.spacing))))
+        return (CFL_SAFETY if self.cfl == "stability" else float(self.cfl)) * limit
+
     def _forward_cpml(self, source_amplitudes, source_locations, receiver_locations, dt):
         vp = self.vp
         dev = vp.device
@@ -121,7 +146,7 @@ class Propagator(torch.nn.Module):
             raise MifwiError("absorbing='cpml' needs square cells (dz == dx)")
         h = dz
         vmax = float(self.vpmax) if self.vpmax is not None else float(vp.detach().max())
-        dt_max = CFL_SAFETY * profiles.elastic_cfl_limit(h, vmax, 4)
+        dt_max = self._dt_max(profiles.elastic_cfl_limit(h, vmax, 4), vmax)
         ratio = max(1, int(math.ceil(abs(dt) / dt_max - 1e-9)))
         dti = dt / ratio
         vp_pad = _EdgePad.apply(vp.float(), P)
@@ -146,7 +171,7 @@ class Propagator(torch.nn.Module):
         vp = self.vp
         if not vp.is_cuda:
             raise MifwiError("model must live on a HIP device: libmifwi has no CPU fallback")
-        if self.absorbing == "cpml":
+        if self.absorbing == "cpml-staggered":
             return self._forward_cpml(source_amplitudes, source_locations, receiver_locations, dt)
         dev = vp.device
         P = self.pml_width
@@ -154,7 +179,7 @@ class Propagator(torch.nn.Module):
         h = min(dz, dx)
         nt = source_amplitudes.shape[0]
         vmax = float(self.vpmax) if self.vpmax is not None else float(vp.detach().max())
-        dt_max = CFL_SAFETY * profiles.scalar_cfl_limit(self.spacing, vmax)
+        dt_max = self._dt_max(profiles.scalar_cfl_limit(self.spacing, vmax), vmax)
         ratio = max(1, int(math.ceil(abs(dt) / dt_max - 1e-9)))
         dti = dt / ratio
 
@@ -163,10 +188,16 @@ class Propagator(torch.nn.Module):
         r = (vp_pad * (dti / h)) ** 2
         f = source_amplitudes.to(device=dev, dtype=torch.float32) * (h * h)
         f = _upsample(f, ratio)
-        q0, q1 = _sponge(n0, P, dz, h, dti, str(dev)), _sponge(n1, P, dx, h, dti, str(dev))
         # coordinates -> cells where the coordinates live (no host round trip when they are on the GPU)
         sc, sw = profiles.cells_truncate(source_locations.detach(), self.spacing, P, n1)
         rc, rw = profiles.cells_truncate(receiver_locations.detach(), self.spacing, P, n1)
+        if self.absorbing == "cpml" and P > 0:
+            fpml = float(self.pml_freq) if self.pml_freq is not None else 0.25 / abs(dt) / 5.0
+            ab0, ab1 = _cpml_ab(n0, P, dz, dti, vmax, fpml), _cpml_ab(n1, P, dx, dti, vmax, fpml)
+            rec = acoustic.propagate(r, f, ab0, ab1, sc, sw, rc, rw, (h / dz) ** 2, (h / dx) ** 2,
+                                     shots_per_group=self.shots_per_group, cpml_width=P)
+            return rec[::ratio] if ratio > 1 else rec
+        q0, q1 = _sponge(n0, P, dz, h, dti, str(dev)), _sponge(n1, P, dx, h, dti, str(dev))
         rec = acoustic.propagate(r, f, q0, q1, sc, sw, rc, rw, (h / dz) ** 2, (h / dx) ** 2,
                                  shots_per_group=self.shots_per_group, edge_rows=P)
         return rec[::ratio] if ratio > 1 else rec

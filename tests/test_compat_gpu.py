@@ -300,7 +300,7 @@ def _deepwave_run(vp, dx, dt, wav, x_s, x_r, P, **kw):
 
 
 def test_deepwave_cpml_mode_agrees_inside_the_model_and_reflects_less_than_the_sponge():
-    """`Propagator(..., absorbing="cpml")` advances the same scalar equation as the first-order pressure-velocity
+    """`Propagator(..., absorbing="cpml-staggered")` advances the same scalar equation as the first-order pressure-velocity
     system (the P-SV kernels in a fluid) with a convolutional PML.  (1) Without boundaries in reach the two modes are
     two discretisations of one equation: traces agree to the discretisation error.  (2) At equal width (10 cells) the
     C-PML's boundary reflection - the difference to a run on a domain so large that nothing returns - is several
@@ -318,7 +318,7 @@ def test_deepwave_cpml_mode_agrees_inside_the_model_and_reflects_less_than_the_s
             return _deepwave_run(vp, dx, dt, wav, mid, ring + mid, P, **kw).cpu().numpy()
 
     small_s, big_s = pair(121), pair(421)
-    small_c, big_c = pair(121, absorbing="cpml", pml_freq=f0), pair(421, absorbing="cpml", pml_freq=f0)
+    small_c, big_c = pair(121, absorbing="cpml-staggered", pml_freq=f0), pair(421, absorbing="cpml-staggered", pml_freq=f0)
     assert np.abs(big_s).max() > 0
     # (1) same equation, two discretisations (2nd-order 5-point Laplacian vs staggered first-order system)
     assert rel_l2(big_c, big_s) <= 0.03
@@ -333,9 +333,12 @@ def test_deepwave_cpml_mode_agrees_inside_the_model_and_reflects_less_than_the_s
     assert np.sqrt(np.mean((small_c - big_c)[:480] ** 2)) <= 1e-4 * peak      # nothing before the edge is reached
 
 
-def test_deepwave_cpml_mode_gradient_is_the_derivative_of_its_own_forward_map():
-    """vp.grad through the C-PML mode (staggered materials, source scaling by vp^2 at the source cell, exact
-    transposed adjoint of the P-SV kernels) against a central difference of the loss along a smooth direction."""
+@pytest.mark.parametrize("mode", ["cpml", "cpml-staggered"])
+def test_deepwave_cpml_mode_gradient_is_the_derivative_of_its_own_forward_map(mode):
+    """vp.grad through the C-PML modes - "cpml": the second-order C-PML inside the scalar scheme (edge-replicated pad,
+    r = vp^2 dt^2 / h^2, exact transposed adjoint of the layer's recursion); "cpml-staggered": staggered materials,
+    source scaling by vp^2 at the source cell, exact transposed adjoint of the P-SV kernels - against a central
+    difference of the loss along a smooth direction."""
     import physicsbasedfwi2_amd.compat.deepwave as deepwave
     from scipy.ndimage import gaussian_filter
     rng = np.random.default_rng(5)
@@ -350,7 +353,7 @@ def test_deepwave_cpml_mode_gradient_is_the_derivative_of_its_own_forward_map():
 
     def loss_of(v, grad):
         vp = torch.tensor(v.astype(np.float32), device=DEV, requires_grad=grad)
-        rec = _deepwave_run(vp, dx, dt, wav, x_s, x_r, P, absorbing="cpml", pml_freq=12.0)
+        rec = _deepwave_run(vp, dx, dt, wav, x_s, x_r, P, absorbing=mode, pml_freq=12.0)
         loss = 0.5 * (rec.double() ** 2).sum()
         if grad:
             loss.backward()
@@ -365,6 +368,60 @@ def test_deepwave_cpml_mode_gradient_is_the_derivative_of_its_own_forward_map():
     fd = (lp - lm) / (2 * eps)
     an = float((g * dv).sum())
     assert abs(fd - an) <= 0.03 * abs(an), (fd, an)
+
+
+def test_deepwave_pml_width_is_a_pml_with_absorbing_cpml():
+    """`Propagator(..., pml_width=W, absorbing="cpml")`: the second-order C-PML inside the scalar scheme.  Inside the
+    model it IS the sponge mode's scheme (same traces until anything has come back from an edge, to round-off); what
+    the edge returns, measured as in the staggered test above, is 1e-3 of the direct wave's peak or less at 20 cells
+    and far below the sponge's at 10 and 20 (recorded in DESIGN.md section 3)."""
+    import physicsbasedfwi2_amd.compat.deepwave as deepwave
+    dx, dt, nt, c, f0 = 10.0, 0.001, 900, 2000.0, 15.0
+    wav = deepwave.wavelets.ricker(f0, nt, dt, 1.0 / f0).reshape(-1, 1, 1)
+    ang = torch.arange(8, dtype=torch.float32) * (2 * np.pi / 8)
+    ring = torch.stack([200.0 * torch.cos(ang), 200.0 * torch.sin(ang)], dim=-1)[None]
+
+    def pair(n, P, **kw):
+        vp = torch.full((n, n), c, device=DEV)
+        mid = torch.tensor([[[(n // 2) * dx, (n // 2) * dx]]])
+        with torch.no_grad():
+            return _deepwave_run(vp, dx, dt, wav, mid, ring + mid, P, **kw).cpu().numpy()
+
+    big = pair(421, 20)
+    peak = np.abs(big).max()
+    late = slice(520, nt)
+    out = {}
+    for P in (10, 20):
+        for mode in ("sponge", "cpml"):
+            small = pair(121, P, absorbing=mode, pml_freq=f0)
+            assert np.sqrt(np.mean((small - big)[:480] ** 2)) <= 1e-5 * peak          # the same scheme inside the model
+            out[(mode, P)] = np.abs((small - big)[late]).max() / peak
+    print("edge return / peak:", {k: "%.2e" % v for k, v in out.items()})
+    assert out[("cpml", 20)] <= 1e-3 and out[("cpml", 10)] <= 0.2 * out[("sponge", 10)]
+    assert out[("cpml", 20)] <= 0.1 * out[("sponge", 20)]
+
+
+def test_deepwave_cfl_option_reproduces_deepwaves_substep_ratio():
+    """cfl="deepwave": dt_max = 0.6 / (vp_max sqrt(sum 1/dx^2)) - at dx = 10 m, dt = 1 ms the internal step halves above
+    4243 m/s, where the default (0.9 x the stability limit) still takes whole steps up to
+    4.9 km/s.  Both are stable and agree to the time-discretisation error; the option changes what is computed, so
+    it is asserted through the traces."""
+    import physicsbasedfwi2_amd.compat.deepwave as deepwave
+    dx, dt, nt = 10.0, 0.001, 300
+    wav = deepwave.wavelets.ricker(10.0, nt, dt, 0.1).reshape(-1, 1, 1)
+    vp = torch.full((80, 80), 4500.0, device=DEV)
+    x_s = torch.tensor([[[400.0, 400.0]]])
+    x_r = torch.tensor([[[400.0, 600.0], [200.0, 300.0]]])
+    with torch.no_grad():
+        a = _deepwave_run(vp, dx, dt, wav, x_s, x_r, 10)
+        b = _deepwave_run(vp, dx, dt, wav, x_s, x_r, 10, cfl="deepwave")
+        c2 = _deepwave_run(vp, dx, dt, wav, x_s, x_r, 10, cfl=0.45)          # also two sub-steps
+    assert a.shape == b.shape == (nt, 1, 2) and float(a.abs().max()) > 0
+    e_ab = rel_l2(b.cpu().numpy(), a.cpu().numpy())
+    assert 1e-4 < e_ab < 0.1                       # another inner step: different numbers, same wave
+    assert torch.equal(b, c2)                      # ratio 2 either way
+    with pytest.raises(Exception):
+        deepwave.scalar.Propagator({"vp": vp}, dx, cfl="fastest")
 
 
 def _wavesolver_setup(shape=(60, 50), spacing=(15.0, 15.0), nbpml=10, tn=600.0):
