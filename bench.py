@@ -136,6 +136,8 @@ class AcousticMarmousi:
         import physicsbasedfwi2_amd.compat.deepwave as deepwave
         from physicsbasedfwi2_amd import misfit
         self.torch, self.deepwave, self.dev, self.misfit = torch, deepwave, dev, misfit
+        # BENCH_ABSORBING=cpml: the deepwave-shaped shim's second-order C-PML instead of the sponge (measurement runs)
+        self.absorbing = os.environ.get("BENCH_ABSORBING", "sponge")
         self.full_nt = type(self).nt
         if nt:
             self.nt = nt
@@ -161,7 +163,7 @@ class AcousticMarmousi:
         self.vp = torch.tensor(synth_vp(self.nz, self.nx, 0), device=dev, requires_grad=True)
         vp_true = torch.tensor(synth_vp(self.nz, self.nx, 1), device=dev)
         with torch.no_grad():
-            obs = deepwave.scalar.Propagator({"vp": vp_true}, self.h, pml_width=self.pml)(
+            obs = deepwave.scalar.Propagator({"vp": vp_true}, self.h, pml_width=self.pml, absorbing=self.absorbing)(
                 self.wav, self.x_s, self.x_r, self.dt)
             omax, _ = obs.abs().max(dim=0, keepdim=True)
             self.obs = obs / (omax + 1e-10)
@@ -184,7 +186,7 @@ class AcousticMarmousi:
         torch = self.torch
         self.vp.grad = None
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        prop = self.deepwave.scalar.Propagator({"vp": self.vp}, self.h, pml_width=self.pml)
+        prop = self.deepwave.scalar.Propagator({"vp": self.vp}, self.h, pml_width=self.pml, absorbing=self.absorbing)
         ev[0].record()
         rec = prop(self.wav, self.x_s, self.x_r, self.dt)
         ev[1].record()
@@ -202,7 +204,7 @@ class AcousticMarmousi:
         from physicsbasedfwi2_amd.acoustic import AcousticPlan
         P = self.pml
         pl = AcousticPlan(self.nz + 2 * P, self.nx + 2 * P, self.nt, self.ns, 1, self.nx, 1, 1.0, 1.0,
-                          self.dev.index or 0)
+                          self.dev.index or 0, 0, P, P if self.absorbing == "cpml" else 0)
         nw = pl.cluster_slabs()
         pl.close()
         return nw, nw

@@ -65,12 +65,12 @@ struct AcParams {
     const float *pe0, *pe1;      // [nshot][2][W+2][gp], [nshot][n0][2][W+2]
 };
 
-#include "mifwi_acoustic_cpml.h"
-
 __device__ __forceinline__ float comp(const float4 &v, int c)
 {
     return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
 }
+
+#include "mifwi_acoustic_cpml.h"
 
 // Workgroups go to the 8 XCDs round-robin in launch order and every XCD has its own L2: remap so that
 // each XCD walks one contiguous row-major run of the (x, y) tiles of its z slice and halo rows of
@@ -1145,8 +1145,8 @@ void pml_step(const AcPml &m0, const float *cur, int shot0, int count, bool adjo
 {
     AcPml m = m0;
     m.shot0 = shot0;
-    const long long cells = 2LL * (m.W + 2) * ((long long)m.n1 + m.n0);
-    const dim3 grid((unsigned)((cells + kThreads - 1) / kThreads), (unsigned)count), block(kThreads);
+    const long long cells = 2LL * (m.W + 2) * std::max(m.gp / 4, m.n0);      // threads per axis (blockIdx.z): groups of four cells on axis 0
+    const dim3 grid((unsigned)((cells + kThreads - 1) / kThreads), (unsigned)count, 2), block(kThreads);
     if (!adjoint) {
         hipLaunchKernelGGL(ac_pml_fwd_psi, grid, block, 0, st, m, cur);
         hipLaunchKernelGGL(ac_pml_fwd_zeta, grid, block, 0, st, m, cur);

@@ -35,13 +35,6 @@ __host__ __device__ inline long long pml_scratch_per_shot(int W, int n0, int gp)
 }
 
 // strip-shaped array of axis 0 / axis 1, zero outside the strip (and outside the grid)
-__device__ __forceinline__ float pml_get0(const AcPml &p, const float *a, int i0, int i1)
-{
-    if (i0 < 0 || i0 >= p.n0) return 0.f;
-    if (i0 < p.W) return a[(long long)i0 * p.gp + i1];
-    if (i0 >= p.n0 - p.W) return a[(long long)(p.W + i0 - (p.n0 - p.W)) * p.gp + i1];
-    return 0.f;
-}
 __device__ __forceinline__ float pml_get1(const AcPml &p, const float *a, int i0, int i1)
 {
     if (i1 < 0 || i1 >= p.n1) return 0.f;
@@ -55,51 +48,63 @@ __device__ __forceinline__ float pml_d2(float m2, float m1, float c, float p1, f
     return fmaf(K1, m1 + p1, fmaf(K2, m2 + p2, K0 * c));
 }
 
-// One thread per region cell: ids [0, 2 (W+2) n1) walk region 0 (side, l, i1), the rest region 1 (i0, side, l).
+// Thread maps.  blockIdx.z = axis, blockIdx.y = shot.
+//   axis 0 (the layer's rows, whole rows of the grid): one thread per GROUP of four cells, id = (side (W+2) + l) ng + g
+//           - 16-byte accesses along i1, four cells of arithmetic per thread;
+//   axis 1 (the layer's columns, two short runs per row): one thread per cell, id = i0 2 (W+2) + side (W+2) + l.
 struct PmlCell {
-    int axis, i0, i1;            // axis < 0: no cell
-    bool strip;
-    long long sidx, ridx;        // index inside the strip / region array of the axis
+    int i0, i1;                  // axis 0: i1 = first cell of the group
+    bool ok, strip;
+    int sidx, ridx;              // index inside the strip / region array of the axis
 };
-__device__ __forceinline__ PmlCell pml_cell(const AcPml &p, long long id)
+__device__ __forceinline__ PmlCell pml_cell(const AcPml &p, unsigned id, int axis)
 {
     PmlCell c;
-    c.axis = -1; c.i0 = c.i1 = 0; c.strip = false; c.sidx = c.ridx = 0;
-    const int W2 = p.W + 2;
-    const long long n0c = 2LL * W2 * p.n1, n1c = 2LL * W2 * p.n0;
-    if (id < n0c) {
-        const int side = (int)(id / ((long long)W2 * p.n1));
-        const long long rem = id - (long long)side * W2 * p.n1;
-        const int l = (int)(rem / p.n1);
-        c.axis = 0; c.i1 = (int)(rem - (long long)l * p.n1);
-        c.i0 = side == 0 ? l : p.n0 - W2 + l;
-        c.strip = side == 0 ? l < p.W : l >= 2;
-        const int ls = side == 0 ? l : l - 2;
-        c.sidx = ((long long)side * p.W + ls) * p.gp + c.i1;
-        c.ridx = ((long long)side * W2 + l) * p.gp + c.i1;
-    } else if (id < n0c + n1c) {
-        const long long q = id - n0c;
-        c.i0 = (int)(q / (2 * W2));
-        const int rem = (int)(q - (long long)c.i0 * 2 * W2);
-        const int side = rem / W2, l = rem - side * W2;
-        c.axis = 1;
-        c.i1 = side == 0 ? l : p.n1 - W2 + l;
-        c.strip = side == 0 ? l < p.W : l >= 2;
-        const int ls = side == 0 ? l : l - 2;
-        c.sidx = ((long long)c.i0 * 2 + side) * p.W + ls;
-        c.ridx = ((long long)c.i0 * 2 + side) * W2 + l;
+    c.ok = false; c.i0 = c.i1 = 0; c.strip = false; c.sidx = c.ridx = 0;
+    const unsigned W2 = (unsigned)p.W + 2u;
+    if (axis == 0) {
+        const unsigned ng = (unsigned)p.gp / 4u;
+        if (id >= 2u * W2 * ng) return c;
+        const unsigned row = id / ng;                                // side * W2 + l
+        const unsigned side = row >= W2 ? 1u : 0u, l = row - side * W2;
+        c.ok = true; c.i1 = 4 * (int)(id - row * ng);
+        c.i0 = side == 0 ? (int)l : p.n0 - (int)W2 + (int)l;
+        c.strip = side == 0 ? l < (unsigned)p.W : l >= 2u;
+        const int ls = side == 0 ? (int)l : (int)l - 2;
+        c.sidx = ((int)side * p.W + ls) * p.gp + c.i1;
+        c.ridx = (int)row * p.gp + c.i1;
+    } else {
+        if (id >= 2u * W2 * (unsigned)p.n0) return c;
+        const unsigned i0 = id / (2u * W2), rem = id - i0 * 2u * W2;
+        const unsigned side = rem >= W2 ? 1u : 0u, l = rem - side * W2;
+        c.ok = true; c.i0 = (int)i0;
+        c.i1 = side == 0 ? (int)l : p.n1 - (int)W2 + (int)l;
+        c.strip = side == 0 ? l < (unsigned)p.W : l >= 2u;
+        const int ls = side == 0 ? (int)l : (int)l - 2;
+        c.sidx = ((int)i0 * 2 + (int)side) * p.W + ls;
+        c.ridx = (int)id;
     }
     return c;
+}
+__device__ __forceinline__ float4 pml_ld4(const float *q) { return *reinterpret_cast<const float4 *>(q); }
+__device__ __forceinline__ void pml_st4(float *q, const float (&v)[4]) { *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]); }
+// four cells of a strip-shaped axis-0 array at row i0 (zero outside the strip / the grid)
+__device__ __forceinline__ float4 pml_get0v(const AcPml &p, const float *a, int i0, int i1)
+{
+    if (i0 >= 0 && i0 < p.W) return pml_ld4(a + i0 * p.gp + i1);
+    if (i0 >= p.n0 - p.W && i0 < p.n0) return pml_ld4(a + (p.W + i0 - (p.n0 - p.W)) * p.gp + i1);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 #define PML_PROLOGUE                                                                              \
     const int s = p.shot0 + (int)blockIdx.y;                                                      \
     if (s >= p.nshot) return;                                                                     \
-    const PmlCell c = pml_cell(p, (long long)blockIdx.x * blockDim.x + threadIdx.x);              \
-    if (c.axis < 0) return;                                                                       \
+    const int axis = (int)blockIdx.z;                                                             \
+    const PmlCell c = pml_cell(p, blockIdx.x * blockDim.x + threadIdx.x, axis);                   \
+    if (!c.ok) return;                                                                            \
     const float *u = cur + (long long)s * p.shot_stride + 2LL * p.pitch + 4;                      \
-    const long long pt = p.pitch;                                                                 \
-    const long long k = (long long)c.i0 * pt + c.i1;                                              \
+    const int pt = p.pitch;                                                                       \
+    const int k = c.i0 * pt + c.i1;                                                               \
     (void)u; (void)k; (void)pt
 
 // forward 1: Psi_d = fma(b, Psi_d, a * D1_d u) on the strips
@@ -107,10 +112,15 @@ __global__ __launch_bounds__(kThreads) void ac_pml_fwd_psi(const AcPml p, const 
 {
     PML_PROLOGUE;
     if (!c.strip) return;
-    if (c.axis == 0) {
-        float *A = p.A0 + (long long)s * p.s0;
-        const float d = pml_d1(u[k - 2 * pt], u[k - pt], u[k + pt], u[k + 2 * pt]);
-        A[c.sidx] = fmaf(p.ab0[p.n0 + c.i0], A[c.sidx], p.ab0[c.i0] * d);
+    if (axis == 0) {
+        float *A = p.A0 + (long long)s * p.s0 + c.sidx;
+        const float4 m2 = pml_ld4(u + k - 2 * pt), m1 = pml_ld4(u + k - pt), p1 = pml_ld4(u + k + pt), p2 = pml_ld4(u + k + 2 * pt);
+        const float4 a4 = pml_ld4(A);
+        const float a = p.ab0[c.i0], b = p.ab0[p.n0 + c.i0];
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = fmaf(b, comp(a4, q), a * pml_d1(comp(m2, q), comp(m1, q), comp(p1, q), comp(p2, q)));
+        pml_st4(A, o);
     } else {
         float *A = p.A1 + (long long)s * p.s1;
         const float d = pml_d1(u[k - 2], u[k - 1], u[k + 1], u[k + 2]);
@@ -122,18 +132,26 @@ __global__ __launch_bounds__(kThreads) void ac_pml_fwd_psi(const AcPml p, const 
 __global__ __launch_bounds__(kThreads) void ac_pml_fwd_zeta(const AcPml p, const float *cur)
 {
     PML_PROLOGUE;
-    if (c.axis == 0) {
+    if (axis == 0) {
         const float *A = p.A0 + (long long)s * p.s0;
-        float *B = p.B0 + (long long)s * p.s0;
-        const float dp = pml_d1(pml_get0(p, A, c.i0 - 2, c.i1), pml_get0(p, A, c.i0 - 1, c.i1),
-                                pml_get0(p, A, c.i0 + 1, c.i1), pml_get0(p, A, c.i0 + 2, c.i1));
-        float z = 0.f;
+        float *B = p.B0 + (long long)s * p.s0 + c.sidx;
+        const float4 am2 = pml_get0v(p, A, c.i0 - 2, c.i1), am1 = pml_get0v(p, A, c.i0 - 1, c.i1);
+        const float4 ap1 = pml_get0v(p, A, c.i0 + 1, c.i1), ap2 = pml_get0v(p, A, c.i0 + 2, c.i1);
+        float dp[4], z[4] = {0.f, 0.f, 0.f, 0.f}, e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dp[q] = pml_d1(comp(am2, q), comp(am1, q), comp(ap1, q), comp(ap2, q));
         if (c.strip) {
-            const float d2 = pml_d2(u[k - 2 * pt], u[k - pt], u[k], u[k + pt], u[k + 2 * pt]);
-            z = fmaf(p.ab0[p.n0 + c.i0], B[c.sidx], p.ab0[c.i0] * (d2 + dp));
-            B[c.sidx] = z;
+            const float4 m2 = pml_ld4(u + k - 2 * pt), m1 = pml_ld4(u + k - pt), uc = pml_ld4(u + k);
+            const float4 p1 = pml_ld4(u + k + pt), p2 = pml_ld4(u + k + 2 * pt), b4 = pml_ld4(B);
+            const float a = p.ab0[c.i0], b = p.ab0[p.n0 + c.i0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                z[q] = fmaf(b, comp(b4, q), a * (pml_d2(comp(m2, q), comp(m1, q), comp(uc, q), comp(p1, q), comp(p2, q)) + dp[q]));
+            pml_st4(B, z);
         }
-        (p.e0 + (long long)s * p.r0)[c.ridx] = dp + z;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = dp[q] + z[q];
+        pml_st4(p.e0 + (long long)s * p.r0 + c.ridx, e);
     } else {
         const float *A = p.A1 + (long long)s * p.s1;
         float *B = p.B1 + (long long)s * p.s1;
@@ -154,11 +172,18 @@ __global__ __launch_bounds__(kThreads) void ac_pml_adj_a(const AcPml p, const fl
 {
     PML_PROLOGUE;
     if (!c.strip) return;
-    if (c.axis == 0) {
-        float *B = p.B0 + (long long)s * p.s0;
-        const float a = fmaf(p.c0, u[k], B[c.sidx]);
-        (p.P0 + (long long)s * p.s0)[c.sidx] = p.ab0[c.i0] * a;
-        B[c.sidx] = p.ab0[p.n0 + c.i0] * a;
+    if (axis == 0) {
+        float *B = p.B0 + (long long)s * p.s0 + c.sidx;
+        const float4 w4 = pml_ld4(u + k), b4 = pml_ld4(B);
+        const float a = p.ab0[c.i0], b = p.ab0[p.n0 + c.i0];
+        float P[4], Z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float t = fmaf(p.c0, comp(w4, q), comp(b4, q));
+            P[q] = a * t; Z[q] = b * t;
+        }
+        pml_st4(p.P0 + (long long)s * p.s0 + c.sidx, P);
+        pml_st4(B, Z);
     } else {
         float *B = p.B1 + (long long)s * p.s1;
         const float a = fmaf(p.c1, u[k], B[c.sidx]);
@@ -172,13 +197,25 @@ __global__ __launch_bounds__(kThreads) void ac_pml_adj_b(const AcPml p, const fl
 {
     PML_PROLOGUE;
     if (!c.strip) return;
-    if (c.axis == 0) {
+    if (axis == 0) {
         const float *P = p.P0 + (long long)s * p.s0;
-        float *A = p.A0 + (long long)s * p.s0;
-        auto V = [&](int o) { return fmaf(p.c0, u[k + o * pt], pml_get0(p, P, c.i0 + o, c.i1)); };
-        const float t = A[c.sidx] - pml_d1(V(-2), V(-1), V(1), V(2));
-        (p.Q0 + (long long)s * p.s0)[c.sidx] = p.ab0[c.i0] * t;
-        A[c.sidx] = p.ab0[p.n0 + c.i0] * t;
+        float *A = p.A0 + (long long)s * p.s0 + c.sidx;
+        float4 w[4], pp[4];
+        const int off[4] = {-2, -1, 1, 2};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { w[o] = pml_ld4(u + k + off[o] * pt); pp[o] = pml_get0v(p, P, c.i0 + off[o], c.i1); }
+        const float4 a4 = pml_ld4(A);
+        const float a = p.ab0[c.i0], b = p.ab0[p.n0 + c.i0];
+        float Q[4], T[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v0 = fmaf(p.c0, comp(w[0], q), comp(pp[0], q)), v1 = fmaf(p.c0, comp(w[1], q), comp(pp[1], q));
+            const float v2 = fmaf(p.c0, comp(w[2], q), comp(pp[2], q)), v3 = fmaf(p.c0, comp(w[3], q), comp(pp[3], q));
+            const float t = comp(a4, q) - pml_d1(v0, v1, v2, v3);
+            Q[q] = a * t; T[q] = b * t;
+        }
+        pml_st4(p.Q0 + (long long)s * p.s0 + c.sidx, Q);
+        pml_st4(A, T);
     } else {
         const float *P = p.P1 + (long long)s * p.s1;
         float *A = p.A1 + (long long)s * p.s1;
@@ -193,12 +230,17 @@ __global__ __launch_bounds__(kThreads) void ac_pml_adj_b(const AcPml p, const fl
 __global__ __launch_bounds__(kThreads) void ac_pml_adj_c(const AcPml p, const float *cur)
 {
     PML_PROLOGUE;
-    if (c.axis == 0) {
+    if (axis == 0) {
         const float *P = p.P0 + (long long)s * p.s0, *Q = p.Q0 + (long long)s * p.s0;
-        auto gp_ = [&](int o) { return pml_get0(p, P, c.i0 + o, c.i1); };
-        auto gq_ = [&](int o) { return pml_get0(p, Q, c.i0 + o, c.i1); };
-        (p.e0 + (long long)s * p.r0)[c.ridx] =
-            pml_d2(gp_(-2), gp_(-1), gp_(0), gp_(1), gp_(2)) - pml_d1(gq_(-2), gq_(-1), gq_(1), gq_(2));
+        float4 pv[5], qv[5];
+#pragma unroll
+        for (int o = 0; o < 5; ++o) { pv[o] = pml_get0v(p, P, c.i0 + o - 2, c.i1); qv[o] = pml_get0v(p, Q, c.i0 + o - 2, c.i1); }
+        float e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            e[q] = pml_d2(comp(pv[0], q), comp(pv[1], q), comp(pv[2], q), comp(pv[3], q), comp(pv[4], q)) -
+                   pml_d1(comp(qv[0], q), comp(qv[1], q), comp(qv[3], q), comp(qv[4], q));
+        pml_st4(p.e0 + (long long)s * p.r0 + c.ridx, e);
     } else {
         const float *P = p.P1 + (long long)s * p.s1, *Q = p.Q1 + (long long)s * p.s1;
         auto gp_ = [&](int o) { return pml_get1(p, P, c.i0, c.i1 + o); };
