@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r02"      # profiles/<round>_pmc_traffic.json, profiles/<round>_latency_floor.json
+PROFILE_ROUND = "r03"      # profiles/<round>_pmc_traffic.json, profiles/<round>_latency_floor.json
 
 
 def sized_cpu_sample(run, nt0, nt_full, budget_s, bytes_per_step, mem_cap=6e9):
@@ -92,6 +92,27 @@ def latency_floor(workload, kernel):
     the chain of barrier-separated LDS phases, the bound of an LDS-resident time loop."""
     rec, tag = _profile_record(PROFILE_ROUND + "_latency_floor.json", workload, kernel)
     return (rec["floor_s_per_step"], tag) if rec else (None, tag)
+
+
+def issue_bound(workload, kernel, t_step, sclk_hz=2.4e9):
+    """The bound quoted for an LDS-resident time loop: issue cycles of the SHIPPED kernel over the cycles of a step.
+    Instruction counts per wave and step come from the committed SQ counters (profiles/<round>_issue_counters.json,
+    tools/issue_counters.py); a wave's vector, scalar or LDS instruction costs 4 issue cycles (MI355X_MICROARCH.md,
+    "vector-instruction ISSUE cost").  frac_wave = how much of a step one wave spends issuing (the rest it waits: LDS
+    and memory latency, barriers, hand-off polls); frac_simd_valu = how busy the SIMD's vector pipe is with the
+    waves_per_simd waves that share it - 1.0 would be the vector-issue roofline of this instruction stream."""
+    rec, tag = _profile_record(PROFILE_ROUND + "_issue_counters.json", workload, kernel)
+    if not rec:
+        return {"bound": "issue", "frac_wave": None, "note": tag}
+    cyc = t_step * sclk_hz
+    wps = 2 if workload.startswith("elastic") else 4             # 512 threads x 256 VGPRs / 1024 threads x 128 VGPRs
+    per = rec["valu_per_wave_step"] + rec["salu_per_wave_step"] + rec["lds_per_wave_step"]
+    return {"bound": "issue", "valu_per_wave_step": round(rec["valu_per_wave_step"], 1),
+            "salu_per_wave_step": round(rec["salu_per_wave_step"], 1), "lds_per_wave_step": round(rec["lds_per_wave_step"], 1),
+            "cycles_per_step": round(cyc), "issue_cycles_per_wave_step": round(4 * per),
+            "frac_wave": 4 * per / cyc, "waves_per_simd": wps,
+            "frac_simd_valu": wps * 4 * rec["valu_per_wave_step"] / cyc, "counters_profiled_at": tag,
+            "note": "4 issue cycles per instruction; cycles at %.1f GHz" % (sclk_hz / 1e9)}
 
 
 def synth_vp(nz, nx, seed, water_rows=26):
@@ -556,16 +577,21 @@ def kernel_report(wl_key, label, t_step, interior, streaming_bytes, resident_byt
          "Mcells_steps_per_s": interior / t_step / 1e6,
          "hbm_bytes_per_cell_step_measured": hbm,
          "hbm_GBs_measured": None if hbm is None else hbm * interior / t_step / 1e9,
-         "traffic_profiled_at": tag if hbm is not None else None}
+         "traffic_profiled_at": tag if hbm is not None else None,
+         "traffic_counter_note": "2 x FETCH_SIZE + WRITE_SIZE at the L2's fabric side: traffic served by the Infinity "
+                                 "Cache counts as well, so on cache-resident passes this is an upper bound of the HBM bytes"}
     if hbm is None:
         k["traffic_note"] = tag
     if is_resident:
+        # the bound that applies to an LDS-resident loop, measured on the shipped kernel: issue cycles / step cycles
+        k["issue"] = issue_bound(wl_key, label, t_step)
         floor, ftag = latency_floor(wl_key, label)
         if floor is not None:
             k["latency"] = {"bound": "latency", "floor_us_per_step": floor * 1e6,
                             "achieved_us_per_step": t_step * 1e6, "frac": min(1.0, floor / t_step),
                             "floor_profiled_at": ftag,
-                            "note": "floor = the same kernel with hand-off waits and the snapshot stream ablated"}
+                            "note": "diagnostic, not a roofline: the same kernel with hand-off waits and the snapshot "
+                                    "stream ablated (what the waits cost); the bound is `issue`"}
         else:
             k["latency"] = {"bound": "latency", "floor_us_per_step": None, "note": ftag}
     return k
@@ -584,12 +610,13 @@ def roofline_of(kern, dom, interior):
          "alg_bytes_per_launch_step": k["alg_bytes_per_cell_step"] * interior,
          "cells": "interior",
          "formulation": ("LDS-resident time loop in one launch: only the snapshot stream must cross HBM "
-                         "(%.0f B/cell-step); its bound is the latency chain, see `latency`"
+                         "(%.0f B/cell-step); the bound that applies is instruction issue, see `issue`"
                          % k["alg_bytes_per_cell_step"]) if k["lds_resident"] else
                         "one launch per (half) step: SURVEY 8d streaming bytes (%.0f B/cell-step)"
                         % k["alg_bytes_per_cell_step"]}
     if k["lds_resident"]:
         r["streaming_equivalent_GBs"] = k["streaming_equivalent_GBs"]
+        r["issue"] = k.get("issue")
         r["latency"] = k.get("latency")
     assert r["frac"] <= 1.0 + 1e-9, "a roofline fraction above 1 means the byte count does not describe the kernel"
     return r

@@ -1141,7 +1141,7 @@ struct mifwi_elastic_plan {
     long long field_stride, shot_stride, fields_elems, psix_elems, psiz_elems, coef_elems;
     long long psi_elems;  // psix+psiz rounded up to 64
     // cluster path (LDS-resident time loop); 0 when a shot does not fit
-    int cluster, NW, PL, adj_PL, cl_shots, cl_lds, cl_ng;
+    int cluster, NW, PL, fwd_PL, adj_PL, cl_shots, cl_lds, cl_ng;
     // adjoint cluster kernel (its own slab count: different LDS footprint)
     int cl_adj, adj_NW, adj_shots, adj_lds, adj_ng, adj_zrows;
     long long xbuf_elems, list_elems, xcc_elems;
@@ -1201,12 +1201,18 @@ void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, int nshot, hipSt
 void el_cluster_setup(mifwi_elastic_plan *pl)
 {
     pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0;
-    pl->adj_PL = pl->PL;
+    pl->adj_PL = pl->PL; pl->fwd_PL = pl->PL;
     // LDS row pitch: with the dense group -> thread deal (lane v <-> group v of the slab, row-major) a wave's 64 lanes
     // cross a row break almost always; the 16-byte slot of lane v stays congruent to v (mod 16) across the break - and
     // every ds_read_b128 lane group conflict-free - iff the pitch in slots is congruent to the groups per row
-    if (env_int("MIFWI_EL_PL_SKEW", 0) & 1) { int P = pl->ng + 2; while ((P - pl->ng) % 16) ++P; pl->PL = 4 * P; }
-    if (env_int("MIFWI_EL_PL_SKEW", 0) & 2) { int P = pl->ng + 2; while ((P - pl->ng) % 16) ++P; pl->adj_PL = 4 * P; } pl->cl_lds = 0; pl->xbuf_elems = 0; pl->xcc_elems = 0;
+    // (measured on 100x300: SQ_LDS_BANK_CONFLICT of the forward loop -22 %, step 6.20 -> 6.07 us; the adjoint's LDS
+    // has no room for the wider rows at 8 slabs).  MIFWI_EL_PL_SKEW: bit 0 forward (default on), bit 1 adjoint.
+    const int skew = env_int("MIFWI_EL_PL_SKEW", 1);
+    int Pskew = pl->ng + 2;
+    while ((Pskew - pl->ng) % 16) ++Pskew;
+    const int PL_plain = pl->PL;
+    if (skew & 1) pl->PL = 4 * Pskew;
+    if (skew & 2) pl->adj_PL = 4 * Pskew; pl->cl_lds = 0; pl->xbuf_elems = 0; pl->xcc_elems = 0;
     pl->cl_adj = 0; pl->adj_NW = 0; pl->adj_shots = 0; pl->adj_lds = 0; pl->adj_ng = 0; pl->adj_zrows = 0; pl->list_elems = 0;
     {   // el_build_tile_taps: start [nshot][ntiles + 1], cursor [nshot][ntiles], list [nshot][nrec * ntap]
         const long long ntiles = (long long)mifwi::ceil_div(pl->ng, AGO) * mifwi::ceil_div(pl->d.nz, ATZ);
@@ -1225,7 +1231,12 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
         if (forced > 0 && nw != forced) continue;
         const int rows = mifwi::ceil_div(pl->d.nz, nw);
         if (pl->d.nz / nw < 4) break;
-        const long long lds = (5LL * (rows + 4) * pl->PL + 6LL * pl->gp + 8LL * rows + 8) * sizeof(float);
+        long long lds = (5LL * (rows + 4) * pl->PL + 6LL * pl->gp + 8LL * rows + 8) * sizeof(float);
+        int PLq = pl->PL;
+        if (lds > 150 * 1024 && pl->PL != PL_plain) {          // the wider rows do not fit this slab height: plain pitch
+            PLq = PL_plain;
+            lds = (5LL * (rows + 4) * PLq + 6LL * pl->gp + 8LL * rows + 8) * sizeof(float);
+        }
         if (lds > 150 * 1024) continue;
         if ((long long)rows * pl->ng > 2 * kEcThreads || kEcRowFields * pl->gp > kEcGr * kEcThreads) continue;
         const int per_launch = 8 * (ncu / (8 * nw));
@@ -1235,6 +1246,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
             best = cost;
             pl->cluster = 1; pl->NW = nw; pl->cl_shots = per_launch; pl->cl_lds = (int)lds;
             pl->cl_ng = mifwi::ceil_div(rows * pl->ng, kEcThreads);
+            pl->fwd_PL = PLq;
         }
     }
     if (pl->cluster) {
@@ -1429,6 +1441,9 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     if (gs <= 0) gs = env_int("MIFWI_EL_GS", 4);
     if (gs <= 0) gs = 1;
     if (gs > d->nshot) gs = d->nshot;
+    // groups of equal size where a slightly smaller one gives them (a 6-shot chunk of a shot-chunked gradient pass: 3 + 3
+    // instead of 4 + 2 - the workgroups of the short group would idle while the others finish their fourth shot)
+    if (d->shots_per_group <= 0 && env_int("MIFWI_EL_GS", 0) <= 0 && gs == 4 && d->nshot % 4 != 0 && d->nshot % 3 == 0) gs = 3;
     pl->gs = gs;
     pl->ngroups = mifwi::ceil_div(d->nshot, gs);
     pl->psi_elems = mifwi::round_up64(pl->psix_elems + pl->psiz_elems, 64);
@@ -1586,7 +1601,7 @@ int mifwi_elastic_forward(mifwi_elastic_plan *pl, const float *mat, const float 
         memset(&c, 0, sizeof(c));
         c.nz = d.nz; c.nx = d.nx; c.ng = pl->ng; c.gp = pl->gp; c.pitch = pl->pitch;
         c.field_stride = (unsigned)pl->field_stride; c.shot_stride = pl->shot_stride;
-        c.nshot = d.nshot; c.NW = pl->NW; c.PL = pl->PL;
+        c.nshot = d.nshot; c.NW = pl->NW; c.PL = pl->fwd_PL;
         c.n_first = n_begin; c.n_last = n_end;
         c.W = pl->W; c.wl = pl->wl; c.xr0 = pl->xr0; c.wx = pl->wx; c.fsurf = d.free_surface;
         c.psix_shot = 4LL * d.nz * pl->wx; c.psiz_shot = 4LL * 2 * pl->W * pl->gp;

@@ -1,7 +1,7 @@
 """Copy the round's summaries from gpurun_out/ (scratch, merged back from the GPU box) into profiles/ (tracked) and stamp
 the commit they were measured at: the GPU box has no .git, so its `commit` fields arrive empty.  The kernel-source
 fingerprint (`csrc_sha16`) inside each file is what bench.py trusts; the commit is for the reader.
-usage: python tools/adopt_profiles.py [r02] [commit]"""
+usage: python tools/adopt_profiles.py [r03] [commit]"""
 import json
 import os
 import shutil
@@ -9,10 +9,11 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 COMMIT = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(
     ["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 NAMES = ["bench_default_output.json", "bench_default_kernel_stats.csv", "pmc_traffic.json", "latency_floor.json",
+         "issue_counters.json",
          "seam_bench_output.json", "seam_kernel_stats.csv"]
 
 for n in NAMES:
@@ -21,7 +22,7 @@ for n in NAMES:
     if not os.path.exists(src):
         print("missing", src)
         continue
-    if n in ("pmc_traffic.json", "latency_floor.json"):
+    if n in ("pmc_traffic.json", "latency_floor.json", "issue_counters.json"):
         doc = json.load(open(src))
         if not doc.get("commit"):
             doc["commit"] = COMMIT

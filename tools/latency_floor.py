@@ -4,7 +4,7 @@
 wrong results, timing only).  What remains is the chain of barrier-separated LDS phases of a step - the
 bound these kernels can be measured against (bench.py `latency`).  Run on the GPU box:
 
-    python tools/latency_floor.py            ->  profiles/r02_latency_floor.json
+    python tools/latency_floor.py            ->  profiles/<round>_latency_floor.json
 """
 import json
 import os

@@ -1,12 +1,13 @@
 #!/bin/bash
-# Round profile set, run on the GPU box (gpurun -- bash tools/profile_round.sh [r02]); results under gpurun_out/,
+# Round profile set, run on the GPU box (gpurun -- bash tools/profile_round.sh [r03]); results under gpurun_out/,
 # to be copied into profiles/:
 #   <R>_bench_default_output.json        python bench.py
 #   <R>_bench_default_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command (no CPU baseline)
 #   <R>_pmc_traffic.json                 FETCH_SIZE / WRITE_SIZE passes of the four bench workloads (tools/pmc_traffic.py)
 #   <R>_latency_floor.json               tools/latency_floor.py (ablation build)
+#   <R>_issue_counters.json              SQ instruction counts of the single-launch kernels (tools/issue_counters.py)
 #   <R>_seam_kernel_stats.csv            rocprofv3 stats of the SEAM-sized sample
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python tools/latency_floor.py $O/${R}_latency_floor.json > $O/latency_floor.log 2>&1 || { tail -5 $O/latency_floor.log; exit 1; }
@@ -21,6 +22,14 @@ pmc() {  # name, bench args..., -- pmc_traffic args
     python tools/pmc_traffic.py $O/pmc_${name}_FETCH_SIZE $O/pmc_${name}_WRITE_SIZE $O/${R}_pmc_traffic.json "$@" > /dev/null || return 1
     find $O/pmc_${name}_FETCH_SIZE $O/pmc_${name}_WRITE_SIZE -name "*.csv" -size +200k -delete
 }
+issue() {  # workload: one --pmc pass of the SQ instruction counters
+    rm -rf $O/pmc_issue_$1
+    timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/pmc_issue_$1 -- python bench.py --workload $1 --steps 1 --warmup 0 --no-cpu-baseline --no-also --no-verify > $O/pmc.log 2>&1 || { tail -5 $O/pmc.log; return 1; }
+    python tools/issue_counters.py $O/pmc_issue_$1 $O/${R}_issue_counters.json --workload $1 > /dev/null || return 1
+    find $O/pmc_issue_$1 -name "*.csv" -size +200k -delete
+}
+issue elastic_marmousi && issue acoustic_marmousi || exit 1
+cp $O/${R}_issue_counters.json profiles/${R}_issue_counters.json
 pmc el100 --workload elastic_marmousi -- --workload elastic_marmousi &&
 pmc ac174 --workload acoustic_marmousi -- --workload acoustic_marmousi &&
 pmc el350 --workload elastic_marmousi --grid 350x1700 --nt 60 -- --workload elastic_marmousi --grid 350x1700 --nt 60 &&
