@@ -649,7 +649,7 @@ def cross_check(wl, name, dev, kw):
             "gradient_rel_l2": gr}
 
 
-def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, warmup=None):
+def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, warmup=None, nt=None):
     import copy
     import torch
     import torch.distributed as dist
@@ -659,6 +659,9 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
     if steps is not None:                   # secondary workloads may time fewer passes (stated in their entry)
         args = copy.copy(args)
         args.steps, args.warmup = steps, warmup
+    if nt is not None:                      # ... or a sample of the time axis (kernel rates of a grid whose full run takes minutes)
+        args = copy.copy(args)
+        args.nt = nt
     strong = getattr(args, "scaling", "weak") == "strong"
     total_shots = 0
     if strong:
@@ -947,8 +950,14 @@ def main():
         # the per-step kernels run HBM-bound and the 3000 snapshots do not fit (time checkpointing); fewer passes
         also.append(run_workload("elastic_marmousi", args, dev, rank, world, want_cpu, grid=(350, 1700),
                                  steps=min(args.steps, 3), warmup=1))
+        # BASELINE config 5's per-GPU share (1000x3000, free surface, 16 shots): a 90-step sample with resident
+        # snapshots - the kernel rates of the SEAM-sized grid; the full 5000 steps take 10.5 s per gradient pass
+        # (time-checkpointed; profiles/r03_c5_full_length.json)
+        also.append(run_workload("elastic_seam", args, dev, rank, world, False, steps=min(args.steps, 3), warmup=1, nt=90))
         if rank == 0:
             also[1]["note"] = "snapshots of all shots do not fit at full length: see kernels_note for how the pass is cut"
+            also[2]["note"] = ("90-step sample of the 5000-step configuration (snapshots resident): kernel rates of the "
+                               "1000x3000 grid; the full-length pass is in profiles/r03_c5_full_length.json")
             out["also"] = [{k: a[k] for k in keys if k in a} for a in also]
     if rank == 0:
         print(json.dumps(out))
