@@ -430,6 +430,7 @@ struct ClParams {
     unsigned long long *xbuf;    // granules [nshot][NW][2 epoch slots][2 sides][2 rows][gp]
     int *err;
     int *xcc_tab;                        // [nshot][NW] XCC_ID + 1 of each slab's workgroup (mifwi::same_xcd)
+    AcPml pml;                           // second-order C-PML (PML = true variants): strip / region arrays in global memory
 #ifdef MIFWI_ABLATIONS
     long long *trace;                    // phase time stamps of one workgroup (MIFWI_AC_CL_TRACE), see CL_STAMP
 #endif
@@ -492,10 +493,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <bool WANT_G>
+template <bool WANT_G, bool PML = false>
 __device__ __forceinline__ void cl_update(const float *c, const float *pp, int PL, const float4 &rv4,
                                           float q0, const float4 &q1, bool damped, float c0, float c1,
-                                          int ncol_valid, float (&un)[4], float (&gk)[4])
+                                          int ncol_valid, float (&un)[4], float (&gk)[4],
+                                          const float4 &pe = make_float4(0.f, 0.f, 0.f, 0.f))
 {
     const float4 w2 = *reinterpret_cast<const float4 *>(c);
     const float4 w0 = *reinterpret_cast<const float4 *>(c - 2 * PL);
@@ -524,7 +526,8 @@ __device__ __forceinline__ void cl_update(const float *c, const float *pp, int P
         const f2 s01 = zm1 + zp1, s02 = zm2 + zp2, s11 = xm1 + xp1, s12 = xm2 + xp2;
         const f2 l0 = pk_fma(k1, s01, pk_fma(k2, s02, k0 * uc));
         const f2 l1 = pk_fma(k1, s11, pk_fma(k2, s12, k0 * uc));
-        const f2 lap = pk_fma(vc0, l0, vc1 * l1);
+        f2 lap = pk_fma(vc0, l0, vc1 * l1);
+        if (PML) lap = lap + (h == 0 ? f2{pe.x, pe.y} : f2{pe.z, pe.w});       // the layer's term (exact zero outside it)
         f2 v, g;
         if (damped) {
             const f2 q = f2{q0, q0} + (h == 0 ? f2{q1.x, q1.y} : f2{q1.z, q1.w});
@@ -560,7 +563,31 @@ __device__ __forceinline__ int cl_opaque(int x)
 // SLOW = false: at most one source per shot and at most kClThreads receivers / sources (decided by the
 // host from the sizes): every sparse point has a thread of its own and the rescanning paths are not even
 // compiled in - they cost ~8 % of the C2 gradient pass in SGPR/VGPR spills alone.  SLOW = true: general.
-template <int MODE, bool SLOW, bool AG>   // MODE 0: forward, 1: forward + snapshots, 2: adjoint + imaging, 3: Born (source G^n dr)
+// The layer's phases of one step inside a slab (PML variants): exactly the thin launches of the per-step family
+// (mifwi_acoustic_cpml.h: same cell functions, same bits), run by the slab's threads over the slab's own strip / region
+// cells with the wavefield read from LDS.  Memory variables, exchanged values (psi', P, Q) and the layer's term e
+// travel through global memory (the XCD's L2): a phase's stores are released, a barrier, the next phase acquires.
+// Edge slabs hold W + 2 rows (plan), so everything a phase reads of u lies in the slab's own rows - the phases run
+// before the hand-off poll.
+__device__ __forceinline__ void cl_pml_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+template <class F>
+__device__ __forceinline__ void cl_pml_cells(const AcPml &m, int w, int NW, int r0, int R, int t, F f)
+{
+    const unsigned W2 = (unsigned)m.W + 2u, ng = (unsigned)m.gp / 4u;
+    if (w == 0 || w == NW - 1) {                       // axis 0: the W + 2 rows of this end of the grid, groups of four cells
+        const unsigned base = w == 0 ? 0u : W2 * ng;
+        for (unsigned e = (unsigned)t; e < W2 * ng; e += kClThreads) f(pml_cell(m, base + e, 0), 0);
+    }
+    for (unsigned e = (unsigned)t; e < 2u * W2 * (unsigned)R; e += kClThreads)       // axis 1: two runs per own row
+        f(pml_cell(m, (unsigned)r0 * 2u * W2 + e, 1), 1);
+}
+
+template <int MODE, bool SLOW, bool AG, bool PML = false>   // MODE 0: forward, 1: forward + snapshots, 2: adjoint + imaging, 3: Born (source G^n dr)
 __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -852,6 +879,22 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             }
         }
         CL_STAMP(1);
+        if (PML) {
+            const AcPml &m = p.pml;
+            const float *ul = cur + (2 - r0) * PL + 4;             // ul[i0 * PL + i1] = the current field at grid cell (i0, i1)
+            if (!adj) {
+                cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_fwd_psi_cell(m, s, ax, c, ul, PL); });
+                cl_pml_sync();
+                cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_fwd_zeta_cell(m, s, ax, c, ul, PL); });
+            } else {
+                cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_adj_a_cell(m, s, ax, c, ul, PL); });
+                cl_pml_sync();
+                cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_adj_b_cell(m, s, ax, c, ul, PL); });
+                cl_pml_sync();
+                cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_adj_c_cell(m, s, ax, c, ul, PL); });
+            }
+            cl_pml_sync();
+        }
         // ---- stencil: new field overwrites prv in place (prv is only read at the own cell) --
         float *Gn = (MODE == 1) ? p.G + (long long)(n - p.g_first) * p.g_step + plane : nullptr;
         const unsigned epoch = (unsigned)(it + 1);
@@ -870,8 +913,29 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                     q1 = *reinterpret_cast<const float4 *>(ldq1 + 4 * (jg_i & 4095));
                     q0 = ldq0[(jg_i >> 12) - r0];
                 }
-                cl_update<MODE == 1>(cur + lo_i, prv + lo_i, PL, rr[i], q0, q1, damped, p.c0, p.c1,
-                                     p.n1 - 4 * (jg_i & 4095), un, gk);
+                float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (PML) {                               // the layer's term of the group's four cells, as ac_step<PML> reads it
+                    const AcPml &m = p.pml;
+                    const int W2 = m.W + 2, j = jg_i >> 12, g = jg_i & 4095;
+                    float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float *pe0 = m.e0 + (long long)s * m.r0;
+                    if (j < W2) e0 = *reinterpret_cast<const float4 *>(pe0 + j * m.gp + 4 * g);
+                    else if (j >= m.n0 - W2) e0 = *reinterpret_cast<const float4 *>(pe0 + (W2 + j - (m.n0 - W2)) * m.gp + 4 * g);
+                    const float *pe1 = m.e1 + (long long)s * m.r1 + j * 2 * W2;
+                    float ev[4];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int i1 = 4 * g + cc;
+                        float e1 = 0.f;
+                        if (i1 < W2) e1 = pe1[i1];
+                        else if (i1 >= m.n1 - W2 && i1 < m.n1) e1 = pe1[W2 + i1 - (m.n1 - W2)];
+                        const float e0c = comp(e0, cc);
+                        ev[cc] = adj ? e0c + e1 : fmaf(p.c0, e0c, p.c1 * e1);
+                    }
+                    pe = make_float4(ev[0], ev[1], ev[2], ev[3]);
+                }
+                cl_update<MODE == 1, PML>(cur + lo_i, prv + lo_i, PL, rr[i], q0, q1, damped, p.c0, p.c1,
+                                          p.n1 - 4 * (jg_i & 4095), un, gk, pe);
                 if (!adj && !slow_sparse && i == src_slot) {
                     const float a = src_wt * amp;
 #pragma unroll
@@ -1162,11 +1226,14 @@ void cluster_setup(mifwi_acoustic_plan *pl)
 {
     pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0; pl->cl_lds = 0; pl->rt = 0;
     pl->xbuf_elems = 0; pl->list_elems = 0;
-    if (env_int("MIFWI_AC_CLUSTER", 1) == 0 || pl->d.ntap != 1 || pl->pmlW > 0) return;
+    if (env_int("MIFWI_AC_CLUSTER", 1) == 0 || pl->d.ntap != 1) return;
+    if (pl->pmlW > 0 && env_int("MIFWI_AC_CLUSTER_PML", 1) == 0) return;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device) != hipSuccess) return;
     const int forced = env_int("MIFWI_AC_NW", 0);
-    const int hint = env_int("MIFWI_AC_EDGE_ROWS", pl->d.edge_rows);
+    // C-PML plans: the first and the last slab hold exactly the layer's rows and the two beyond them (W + 2), so that
+    // everything the layer's phases read and write along z stays inside one slab
+    const int hint = pl->pmlW > 0 ? pl->pmlW + 2 : env_int("MIFWI_AC_EDGE_ROWS", pl->d.edge_rows);
     // Slab count: a step costs a fixed part (barriers, one hand-off flight) plus the groups a thread
     // updates, times the launches the shot batch needs (measured: ~(4.7 + groups/thread) per launch on
     // C1/C2).  Few shots -> many thin slabs use the idle CUs; a full batch -> the fewest slabs that fit.
@@ -1178,7 +1245,7 @@ void cluster_setup(mifwi_acoustic_plan *pl)
         const int per_launch = 8 * (ncu / (8 * nw));       // shots per launch (multiple of 8)
         if (per_launch < 8) break;
         // both splits are priced: the absorbing layer in slabs of its own (hint = its width), or even
-        for (int uneven = 1; uneven >= 0; --uneven) {
+        for (int uneven = 1; uneven >= (pl->pmlW > 0 ? 1 : 0); --uneven) {
             int rt = 0, rows = mifwi::ceil_div(pl->d.n0, nw);
             if (uneven) {
                 if (hint < 4 || nw < 3 || pl->d.n0 - 2 * hint < 4 * (nw - 2)) continue;
@@ -1211,7 +1278,13 @@ void cluster_setup(mifwi_acoustic_plan *pl)
                            (const void *)ac_cluster<0, false, true>, (const void *)ac_cluster<1, false, true>,
                            (const void *)ac_cluster<2, false, true>, (const void *)ac_cluster<3, false, true>,
                            (const void *)ac_cluster<0, true, true>, (const void *)ac_cluster<1, true, true>,
-                           (const void *)ac_cluster<2, true, true>, (const void *)ac_cluster<3, true, true>})
+                           (const void *)ac_cluster<2, true, true>, (const void *)ac_cluster<3, true, true>,
+                           (const void *)ac_cluster<0, false, false, true>, (const void *)ac_cluster<1, false, false, true>,
+                           (const void *)ac_cluster<2, false, false, true>, (const void *)ac_cluster<0, true, false, true>,
+                           (const void *)ac_cluster<1, true, false, true>, (const void *)ac_cluster<2, true, false, true>,
+                           (const void *)ac_cluster<0, false, true, true>, (const void *)ac_cluster<1, false, true, true>,
+                           (const void *)ac_cluster<2, false, true, true>, (const void *)ac_cluster<0, true, true, true>,
+                           (const void *)ac_cluster<1, true, true, true>, (const void *)ac_cluster<2, true, true, true>})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mifwi::kClusterLdsLimit) != hipSuccess) {
             (void)hipGetLastError();           // not sticky: the plan simply uses one launch per step
             pl->cluster = 0;
@@ -1260,10 +1333,16 @@ int cluster_attempt(const mifwi_acoustic_plan *pl, ClParams c, float *xbuf, hipS
         // general (rescanning) variant only when a thread may own several sparse points
         const bool general = MODE == 2 ? (c.nrec > kClThreads || c.nsrc > kClThreads)
                                        : (c.nsrc > 1 || c.nrec > kClThreads);
-        if (general)
-            hipLaunchKernelGGL((ac_cluster<MODE, true, AG>), dim3(8 * pl->NW * nsl8), dim3(kClThreads), pl->cl_lds, st, c);
-        else
-            hipLaunchKernelGGL((ac_cluster<MODE, false, AG>), dim3(8 * pl->NW * nsl8), dim3(kClThreads), pl->cl_lds, st, c);
+        const dim3 grid(8 * pl->NW * nsl8), block(kClThreads);
+        if constexpr (MODE != 3) {
+            if (pl->pmlW > 0) {
+                if (general) hipLaunchKernelGGL((ac_cluster<MODE, true, AG, true>), grid, block, pl->cl_lds, st, c);
+                else hipLaunchKernelGGL((ac_cluster<MODE, false, AG, true>), grid, block, pl->cl_lds, st, c);
+                continue;
+            }
+        }
+        if (general) hipLaunchKernelGGL((ac_cluster<MODE, true, AG>), grid, block, pl->cl_lds, st, c);
+        else hipLaunchKernelGGL((ac_cluster<MODE, false, AG>), grid, block, pl->cl_lds, st, c);
     }
     MIFWI_HIP_TRY(hipGetLastError());
     int err[4] = {0, 0, 0, 0};
@@ -1459,9 +1538,9 @@ int mifwi_acoustic_plan_layout(const mifwi_acoustic_plan *pl, mifwi_acoustic_lay
     const long long cl = pl->cluster ? pl->xbuf_elems + pl->list_elems : 0;
     // single-launch plans: room for a copy of the input state of a resumed call (cluster_backup)
     const long long pml = pl->pml_persist + pl->pml_scratch + pl->zq_elems;
-    out->work_forward_elems = 2 * pl->field_elems + pml + bbox + cl + (pl->cluster ? 2 * pl->field_elems : 0);
+    out->work_forward_elems = 2 * pl->field_elems + pml + bbox + cl + (pl->cluster ? 2 * pl->field_elems + pl->pml_persist : 0);
     out->work_backward_elems = 2 * pl->field_elems + pl->ngroups * pl->coef_elems + pml + bbox + cl +
-                               (pl->cluster ? 2 * pl->field_elems + pl->ngroups * pl->coef_elems : 0);
+                               (pl->cluster ? 2 * pl->field_elems + pl->pml_persist + pl->ngroups * pl->coef_elems : 0);
     out->state_elems = 2 * pl->field_elems + pl->pml_persist;
     return MIFWI_OK;
 }
@@ -1515,14 +1594,16 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *pl, const float *r, const float 
         c.src_cell = src_cell; c.src_w = src_w; c.f = f;
         c.rec_cell = rec_cell; c.rec_w = rec_w; c.rec_out = (rec_out && d.nrec > 0) ? rec_out : nullptr;
         c.G = snap; c.g_first = n_begin; c.g_step = snap_step;
+        c.pml = pm;
+        const long long fstate = 2 * pl->field_elems + pl->pml_persist;       // fields + the layer's memory variables
         float *backup = xbuf + pl->xbuf_elems + pl->list_elems;
-        rc = cluster_backup(work, 2 * pl->field_elems, backup, flags, st);
+        rc = cluster_backup(work, fstate, backup, flags, st);
         if (rc) return rc;
-        rc = snap ? cluster_run<1>(pl, c, xbuf, st, work, 2 * pl->field_elems, backup, flags)
-                  : cluster_run<0>(pl, c, xbuf, st, work, 2 * pl->field_elems, backup, flags);
+        rc = snap ? cluster_run<1>(pl, c, xbuf, st, work, fstate, backup, flags)
+                  : cluster_run<0>(pl, c, xbuf, st, work, fstate, backup, flags);
         if (rc != mifwi::kClusterTimedOut) return rc;
         mifwi::note_fallback("acoustic");
-        rc = cluster_restore(work, 2 * pl->field_elems, backup, flags, st);
+        rc = cluster_restore(work, fstate, backup, flags, st);
         if (rc) return rc;
     }
     // shot groups are independent: a few at a time keep wavefields and model inside the Infinity Cache
@@ -1575,7 +1656,7 @@ int mifwi_acoustic_born(mifwi_acoustic_plan *pl, const float *r, const float *q0
         q0 = zq; q1 = zq + d.n0;
     }
     const long long snap_step = (long long)d.nshot * pl->coef_elems;
-    if (pl->cluster && n_end > n_begin) {
+    if (pl->cluster && pl->pmlW == 0 && n_end > n_begin) {          // (the Born pass of a C-PML plan runs one launch per step)
         float *xbuf = zq + pl->zq_elems + mifwi::round_up64(4LL * d.nshot, 64);
         ClParams c = cluster_params(pl, r, q0, q1, ua, ub, xbuf);
         c.n_first = n_begin; c.n_last = n_end;
@@ -1675,7 +1756,8 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
         c.G = const_cast<float *>(snap); c.g_first = snap_first; c.g_step = snap_step;
         c.acc = acc;
         c.slab_cnt = lists; c.slab_list = lists + (long long)d.nshot * pl->NW;
-        const long long state = 2 * pl->field_elems + pl->ngroups * pl->coef_elems;     // adjoint fields + accumulators
+        c.pml = pm;
+        const long long state = 2 * pl->field_elems + pl->pml_persist + pl->ngroups * pl->coef_elems;     // adjoint fields (+ layer) + accumulators
         float *backup = reinterpret_cast<float *>(lists) + pl->list_elems;
         rc = cluster_backup(work, state, backup, flags, st);
         if (rc) return rc;

@@ -96,21 +96,11 @@ __device__ __forceinline__ float4 pml_get0v(const AcPml &p, const float *a, int 
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-#define PML_PROLOGUE                                                                              \
-    const int s = p.shot0 + (int)blockIdx.y;                                                      \
-    if (s >= p.nshot) return;                                                                     \
-    const int axis = (int)blockIdx.z;                                                             \
-    const PmlCell c = pml_cell(p, blockIdx.x * blockDim.x + threadIdx.x, axis);                   \
-    if (!c.ok) return;                                                                            \
-    const float *u = cur + (long long)s * p.shot_stride + 2LL * p.pitch + 4;                      \
-    const int pt = p.pitch;                                                                       \
-    const int k = c.i0 * pt + c.i1;                                                               \
-    (void)u; (void)k; (void)pt
-
 // forward 1: Psi_d = fma(b, Psi_d, a * D1_d u) on the strips
-__global__ __launch_bounds__(kThreads) void ac_pml_fwd_psi(const AcPml p, const float *cur)
+__device__ __forceinline__ void ac_pml_fwd_psi_cell(const AcPml &p, const int s, const int axis, const PmlCell &c, const float *u, const int pt)
 {
-    PML_PROLOGUE;
+    const int k = c.i0 * pt + c.i1;
+    (void)k;
     if (!c.strip) return;
     if (axis == 0) {
         float *A = p.A0 + (long long)s * p.s0 + c.sidx;
@@ -129,9 +119,10 @@ __global__ __launch_bounds__(kThreads) void ac_pml_fwd_psi(const AcPml p, const 
 }
 
 // forward 2: Z_d = fma(b, Z_d, a * (D2_d u + D1_d Psi_d)) on the strips; e_d = D1_d Psi_d + Z_d on the regions
-__global__ __launch_bounds__(kThreads) void ac_pml_fwd_zeta(const AcPml p, const float *cur)
+__device__ __forceinline__ void ac_pml_fwd_zeta_cell(const AcPml &p, const int s, const int axis, const PmlCell &c, const float *u, const int pt)
 {
-    PML_PROLOGUE;
+    const int k = c.i0 * pt + c.i1;
+    (void)k;
     if (axis == 0) {
         const float *A = p.A0 + (long long)s * p.s0;
         float *B = p.B0 + (long long)s * p.s0 + c.sidx;
@@ -168,9 +159,10 @@ __global__ __launch_bounds__(kThreads) void ac_pml_fwd_zeta(const AcPml p, const
 }
 
 // adjoint 1 (w = z^{k+1} = cur): A = fma(c_d, w, Zb);  P = a A;  Zb = b A   on the strips
-__global__ __launch_bounds__(kThreads) void ac_pml_adj_a(const AcPml p, const float *cur)
+__device__ __forceinline__ void ac_pml_adj_a_cell(const AcPml &p, const int s, const int axis, const PmlCell &c, const float *u, const int pt)
 {
-    PML_PROLOGUE;
+    const int k = c.i0 * pt + c.i1;
+    (void)k;
     if (!c.strip) return;
     if (axis == 0) {
         float *B = p.B0 + (long long)s * p.s0 + c.sidx;
@@ -193,9 +185,10 @@ __global__ __launch_bounds__(kThreads) void ac_pml_adj_a(const AcPml p, const fl
 }
 
 // adjoint 2: T = Pb - D1_d(fma(c_d, w, P));  Q = a T;  Pb = b T   on the strips
-__global__ __launch_bounds__(kThreads) void ac_pml_adj_b(const AcPml p, const float *cur)
+__device__ __forceinline__ void ac_pml_adj_b_cell(const AcPml &p, const int s, const int axis, const PmlCell &c, const float *u, const int pt)
 {
-    PML_PROLOGUE;
+    const int k = c.i0 * pt + c.i1;
+    (void)k;
     if (!c.strip) return;
     if (axis == 0) {
         const float *P = p.P0 + (long long)s * p.s0;
@@ -227,9 +220,10 @@ __global__ __launch_bounds__(kThreads) void ac_pml_adj_b(const AcPml p, const fl
 }
 
 // adjoint 3: e_d = D2_d P - D1_d Q on the regions
-__global__ __launch_bounds__(kThreads) void ac_pml_adj_c(const AcPml p, const float *cur)
+__device__ __forceinline__ void ac_pml_adj_c_cell(const AcPml &p, const int s, const int axis, const PmlCell &c, const float *u, const int pt)
 {
-    PML_PROLOGUE;
+    const int k = c.i0 * pt + c.i1;
+    (void)k;
     if (axis == 0) {
         const float *P = p.P0 + (long long)s * p.s0, *Q = p.Q0 + (long long)s * p.s0;
         float4 pv[5], qv[5];
@@ -249,4 +243,21 @@ __global__ __launch_bounds__(kThreads) void ac_pml_adj_c(const AcPml p, const fl
             pml_d2(gp_(-2), gp_(-1), gp_(0), gp_(1), gp_(2)) - pml_d1(gq_(-2), gq_(-1), gq_(1), gq_(2));
     }
 }
-#undef PML_PROLOGUE
+
+// ---- the thin launches of the one-launch-per-step family: one thread per cell (group), u = the global wavefield -------
+#define PML_KERNEL(NAME)                                                                                      \
+    __global__ __launch_bounds__(kThreads) void NAME(const AcPml p, const float *cur)                          \
+    {                                                                                                          \
+        const int s = p.shot0 + (int)blockIdx.y;                                                               \
+        if (s >= p.nshot) return;                                                                              \
+        const int axis = (int)blockIdx.z;                                                                      \
+        const PmlCell c = pml_cell(p, blockIdx.x * blockDim.x + threadIdx.x, axis);                            \
+        if (!c.ok) return;                                                                                     \
+        NAME##_cell(p, s, axis, c, cur + (long long)s * p.shot_stride + 2LL * p.pitch + 4, p.pitch);           \
+    }
+PML_KERNEL(ac_pml_fwd_psi)
+PML_KERNEL(ac_pml_fwd_zeta)
+PML_KERNEL(ac_pml_adj_a)
+PML_KERNEL(ac_pml_adj_b)
+PML_KERNEL(ac_pml_adj_c)
+#undef PML_KERNEL

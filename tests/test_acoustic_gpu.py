@@ -407,3 +407,34 @@ def test_cpml_born_is_the_transpose_partner_of_the_gradient(oracle32):
         a = acoustic.propagate(r + eps * dr, f, t("ab0"), t("ab1"), t("sc"), t("sw"), t("rc"), t("rw"), c["c0"], c["c1"], **kw)
         b = acoustic.propagate(r - eps * dr, f, t("ab0"), t("ab1"), t("sc"), t("sw"), t("rc"), t("rw"), c["c0"], c["c1"], **kw)
     assert rel_l2(drec.cpu().numpy(), ((a - b) / (2 * eps)).cpu().numpy()) < 2e-2
+
+
+def test_cpml_single_launch_and_per_step_families_agree(oracle32, monkeypatch):
+    """The C-PML inside the single-launch time loop (the layer's phases run by the slab's threads on the LDS-resident
+    field, memory variables and the layer's term through the XCD's L2; edge slabs of W + 2 rows) against the per-step
+    kernels with their thin layer launches and against the oracle: same cell functions, same bits."""
+    from physicsbasedfwi2_amd.acoustic import AcousticPlan
+    c = _cpml_case(seed=31, n0=100, n1=150, w=12, nt=140, ns=3, nrec=30)
+    N0, N1 = c["shape"]
+    pl = AcousticPlan(N0, N1, 140, 3, 1, 30, 1, 1.0, 1.0, 0, 0, 0, c["w"])
+    assert pl.cluster_slabs() >= 3                             # the single-launch plan is what runs by default
+    pl.close()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MIFWI_AC_CLUSTER", flag)
+        r, f, rec = _run_cpml(c)
+        rec.backward(torch.sign(rec.detach()))
+        outs.append((rec.detach().clone(), r.grad.clone(), f.grad.clone()))
+    assert float(outs[0][0].abs().max()) > 0 and torch.equal(outs[0][0], outs[1][0])
+    assert rel_l2(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy()) <= 2e-5
+    assert rel_l2(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()) <= 2e-5
+    geo = (c["sc"], c["sw"], c["rc"], c["rw"])
+    rec_o = oracle32.acoustic_cpml_forward(c["r"], c["ab0"], c["ab1"], c["f"], *geo, c["c0"], c["c1"])
+    assert np.abs(outs[0][0].cpu().numpy() - rec_o).max() == 0.0
+    # a forced slab count with thin interior slabs, and the checkpointed form (state copied out and in between calls)
+    monkeypatch.setenv("MIFWI_AC_CLUSTER", "1")
+    monkeypatch.setenv("MIFWI_AC_NW", "6")
+    r2, f2, rec2 = _run_cpml(c, budget=1 << 21)
+    rec2.backward(torch.sign(rec2.detach()))
+    assert torch.equal(rec2.detach(), outs[0][0])
+    assert rel_l2(r2.grad.cpu().numpy(), outs[1][1].cpu().numpy()) <= 2e-5
