@@ -566,15 +566,12 @@ __device__ __forceinline__ int cl_opaque(int x)
 // The layer's phases of one step inside a slab (PML variants): exactly the thin launches of the per-step family
 // (mifwi_acoustic_cpml.h: same cell functions, same bits), run by the slab's threads over the slab's own strip / region
 // cells with the wavefield read from LDS.  Memory variables, exchanged values (psi', P, Q) and the layer's term e
-// travel through global memory (the XCD's L2): a phase's stores are released, a barrier, the next phase acquires.
-// Edge slabs hold W + 2 rows (plan), so everything a phase reads of u lies in the slab's own rows - the phases run
-// before the hand-off poll.
-__device__ __forceinline__ void cl_pml_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
+// travel through global memory between the phases.  Writers and readers are waves of ONE workgroup, i.e. of one CU and
+// one (write-through) vector L1: workgroup scope is all the ordering they need, which is what __syncthreads() gives
+// (an agent-scope release / acquire pair here writes back and invalidates L2 lines at every phase boundary: measured
+// 224 us per step instead of 5).  Edge slabs hold W + 2 rows (plan), so everything a phase reads of u lies in the
+// slab's own rows - the phases run before the hand-off poll.
+__device__ __forceinline__ void cl_pml_sync() { __syncthreads(); }
 template <class F>
 __device__ __forceinline__ void cl_pml_cells(const AcPml &m, int w, int NW, int r0, int R, int t, F f)
 {
@@ -884,8 +881,11 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             const float *ul = cur + (2 - r0) * PL + 4;             // ul[i0 * PL + i1] = the current field at grid cell (i0, i1)
             if (!adj) {
                 cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_fwd_psi_cell(m, s, ax, c, ul, PL); });
+                CL_STAMP(11);
                 cl_pml_sync();
+                CL_STAMP(12);
                 cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_fwd_zeta_cell(m, s, ax, c, ul, PL); });
+                CL_STAMP(13);
             } else {
                 cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_adj_a_cell(m, s, ax, c, ul, PL); });
                 cl_pml_sync();
@@ -894,6 +894,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_adj_c_cell(m, s, ax, c, ul, PL); });
             }
             cl_pml_sync();
+            CL_STAMP(14);
         }
         // ---- stencil: new field overwrites prv in place (prv is only read at the own cell) --
         float *Gn = (MODE == 1) ? p.G + (long long)(n - p.g_first) * p.g_step + plane : nullptr;
@@ -914,26 +915,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                     q0 = ldq0[(jg_i >> 12) - r0];
                 }
                 float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (PML) {                               // the layer's term of the group's four cells, as ac_step<PML> reads it
-                    const AcPml &m = p.pml;
-                    const int W2 = m.W + 2, j = jg_i >> 12, g = jg_i & 4095;
-                    float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float *pe0 = m.e0 + (long long)s * m.r0;
-                    if (j < W2) e0 = *reinterpret_cast<const float4 *>(pe0 + j * m.gp + 4 * g);
-                    else if (j >= m.n0 - W2) e0 = *reinterpret_cast<const float4 *>(pe0 + (W2 + j - (m.n0 - W2)) * m.gp + 4 * g);
-                    const float *pe1 = m.e1 + (long long)s * m.r1 + j * 2 * W2;
-                    float ev[4];
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        const int i1 = 4 * g + cc;
-                        float e1 = 0.f;
-                        if (i1 < W2) e1 = pe1[i1];
-                        else if (i1 >= m.n1 - W2 && i1 < m.n1) e1 = pe1[W2 + i1 - (m.n1 - W2)];
-                        const float e0c = comp(e0, cc);
-                        ev[cc] = adj ? e0c + e1 : fmaf(p.c0, e0c, p.c1 * e1);
-                    }
-                    pe = make_float4(ev[0], ev[1], ev[2], ev[3]);
-                }
+                if (PML) pe = pml_term(p.pml, s, jg_i >> 12, jg_i & 4095, adj);      // the layer's term of the group's four cells
                 cl_update<MODE == 1, PML>(cur + lo_i, prv + lo_i, PL, rr[i], q0, q1, damped, p.c0, p.c1,
                                           p.n1 - 4 * (jg_i & 4095), un, gk, pe);
                 if (!adj && !slow_sparse && i == src_slot) {

@@ -35,12 +35,17 @@ __host__ __device__ inline long long pml_scratch_per_shot(int W, int n0, int gp)
 }
 
 // strip-shaped array of axis 0 / axis 1, zero outside the strip (and outside the grid)
+// strip-shaped arrays read at a cell that may lie outside the strip (zero there).  Branch-free: the load goes to a
+// clamped, always valid index and the result is selected afterwards, so that the four or five neighbour reads of a
+// cell are independent loads in flight together (as separate branches they were serialised round trips: 3 000 clocks
+// per cell in the single-launch kernel's layer phases).
 __device__ __forceinline__ float pml_get1(const AcPml &p, const float *a, int i0, int i1)
 {
-    if (i1 < 0 || i1 >= p.n1) return 0.f;
-    if (i1 < p.W) return a[((long long)i0 * 2) * p.W + i1];
-    if (i1 >= p.n1 - p.W) return a[((long long)i0 * 2 + 1) * p.W + i1 - (p.n1 - p.W)];
-    return 0.f;
+    const bool lo = i1 >= 0 && i1 < p.W, hi = i1 >= p.n1 - p.W && i1 < p.n1;
+    int l = lo ? i1 : p.W + i1 - (p.n1 - p.W);
+    l = l < 0 ? 0 : (l > 2 * p.W - 1 ? 2 * p.W - 1 : l);
+    const float v = a[i0 * 2 * p.W + l];
+    return (lo || hi) ? v : 0.f;          // (the load above is unconditional)
 }
 __device__ __forceinline__ float pml_d1(float m2, float m1, float p1, float p2) { return fmaf(CF1, p1 - m1, CF2 * (p2 - m2)); }
 __device__ __forceinline__ float pml_d2(float m2, float m1, float c, float p1, float p2)
@@ -88,12 +93,15 @@ __device__ __forceinline__ PmlCell pml_cell(const AcPml &p, unsigned id, int axi
 }
 __device__ __forceinline__ float4 pml_ld4(const float *q) { return *reinterpret_cast<const float4 *>(q); }
 __device__ __forceinline__ void pml_st4(float *q, const float (&v)[4]) { *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]); }
-// four cells of a strip-shaped axis-0 array at row i0 (zero outside the strip / the grid)
+// four cells of a strip-shaped axis-0 array at row i0 (zero outside the strip / the grid); branch-free as pml_get1
 __device__ __forceinline__ float4 pml_get0v(const AcPml &p, const float *a, int i0, int i1)
 {
-    if (i0 >= 0 && i0 < p.W) return pml_ld4(a + i0 * p.gp + i1);
-    if (i0 >= p.n0 - p.W && i0 < p.n0) return pml_ld4(a + (p.W + i0 - (p.n0 - p.W)) * p.gp + i1);
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool lo = i0 >= 0 && i0 < p.W, hi = i0 >= p.n0 - p.W && i0 < p.n0;
+    int l = lo ? i0 : p.W + i0 - (p.n0 - p.W);
+    l = l < 0 ? 0 : (l > 2 * p.W - 1 ? 2 * p.W - 1 : l);
+    const float4 v = pml_ld4(a + l * p.gp + i1);
+    const bool ok = lo || hi;
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
 // forward 1: Psi_d = fma(b, Psi_d, a * D1_d u) on the strips
@@ -122,38 +130,39 @@ __device__ __forceinline__ void ac_pml_fwd_psi_cell(const AcPml &p, const int s,
 __device__ __forceinline__ void ac_pml_fwd_zeta_cell(const AcPml &p, const int s, const int axis, const PmlCell &c, const float *u, const int pt)
 {
     const int k = c.i0 * pt + c.i1;
-    (void)k;
+    // every load is issued before the first use (and unconditionally, at a clamped index): one memory round trip per
+    // cell, not one per operand group
     if (axis == 0) {
         const float *A = p.A0 + (long long)s * p.s0;
-        float *B = p.B0 + (long long)s * p.s0 + c.sidx;
+        float *B = p.B0 + (long long)s * p.s0 + (c.strip ? c.sidx : 0);
         const float4 am2 = pml_get0v(p, A, c.i0 - 2, c.i1), am1 = pml_get0v(p, A, c.i0 - 1, c.i1);
         const float4 ap1 = pml_get0v(p, A, c.i0 + 1, c.i1), ap2 = pml_get0v(p, A, c.i0 + 2, c.i1);
-        float dp[4], z[4] = {0.f, 0.f, 0.f, 0.f}, e[4];
+        const float4 b4 = pml_ld4(B);
+        const float a = p.ab0[c.i0], b = p.ab0[p.n0 + c.i0];
+        const float4 m2 = pml_ld4(u + k - 2 * pt), m1 = pml_ld4(u + k - pt), uc = pml_ld4(u + k);
+        const float4 p1 = pml_ld4(u + k + pt), p2 = pml_ld4(u + k + 2 * pt);
+        float dp[4], z[4], e[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dp[q] = pml_d1(comp(am2, q), comp(am1, q), comp(ap1, q), comp(ap2, q));
-        if (c.strip) {
-            const float4 m2 = pml_ld4(u + k - 2 * pt), m1 = pml_ld4(u + k - pt), uc = pml_ld4(u + k);
-            const float4 p1 = pml_ld4(u + k + pt), p2 = pml_ld4(u + k + 2 * pt), b4 = pml_ld4(B);
-            const float a = p.ab0[c.i0], b = p.ab0[p.n0 + c.i0];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                z[q] = fmaf(b, comp(b4, q), a * (pml_d2(comp(m2, q), comp(m1, q), comp(uc, q), comp(p1, q), comp(p2, q)) + dp[q]));
-            pml_st4(B, z);
+        for (int q = 0; q < 4; ++q) {
+            dp[q] = pml_d1(comp(am2, q), comp(am1, q), comp(ap1, q), comp(ap2, q));
+            z[q] = fmaf(b, comp(b4, q), a * (pml_d2(comp(m2, q), comp(m1, q), comp(uc, q), comp(p1, q), comp(p2, q)) + dp[q]));
+            if (!c.strip) z[q] = 0.f;
+            e[q] = dp[q] + z[q];
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) e[q] = dp[q] + z[q];
+        if (c.strip) pml_st4(B, z);
         pml_st4(p.e0 + (long long)s * p.r0 + c.ridx, e);
     } else {
         const float *A = p.A1 + (long long)s * p.s1;
-        float *B = p.B1 + (long long)s * p.s1;
-        const float dp = pml_d1(pml_get1(p, A, c.i0, c.i1 - 2), pml_get1(p, A, c.i0, c.i1 - 1),
-                                pml_get1(p, A, c.i0, c.i1 + 1), pml_get1(p, A, c.i0, c.i1 + 2));
-        float z = 0.f;
-        if (c.strip) {
-            const float d2 = pml_d2(u[k - 2], u[k - 1], u[k], u[k + 1], u[k + 2]);
-            z = fmaf(p.ab1[p.gp + c.i1], B[c.sidx], p.ab1[c.i1] * (d2 + dp));
-            B[c.sidx] = z;
-        }
+        float *B = p.B1 + (long long)s * p.s1 + (c.strip ? c.sidx : 0);
+        const float a0 = pml_get1(p, A, c.i0, c.i1 - 2), a1 = pml_get1(p, A, c.i0, c.i1 - 1);
+        const float a2 = pml_get1(p, A, c.i0, c.i1 + 1), a3 = pml_get1(p, A, c.i0, c.i1 + 2);
+        const float bz = *B;
+        const float a = p.ab1[c.i1], b = p.ab1[p.gp + c.i1];
+        const float dp = pml_d1(a0, a1, a2, a3);
+        const float d2 = pml_d2(u[k - 2], u[k - 1], u[k], u[k + 1], u[k + 2]);
+        float z = fmaf(b, bz, a * (d2 + dp));
+        if (!c.strip) z = 0.f;
+        if (c.strip) *B = z;
         (p.e1 + (long long)s * p.r1)[c.ridx] = dp + z;
     }
 }
@@ -242,6 +251,32 @@ __device__ __forceinline__ void ac_pml_adj_c_cell(const AcPml &p, const int s, c
         (p.e1 + (long long)s * p.r1)[c.ridx] =
             pml_d2(gp_(-2), gp_(-1), gp_(0), gp_(1), gp_(2)) - pml_d1(gq_(-2), gq_(-1), gq_(1), gq_(2));
     }
+}
+
+// The layer's term of the four cells of group g in row j, read from the region arrays of shot s (what ac_step<PML> and
+// ac_cluster<PML> add to their Laplacian): forward fma(c0, e0, c1 e1), adjoint e0 + e1.  Branch-free loads.
+__device__ __forceinline__ float4 pml_term(const AcPml &m, int s, int j, int g, bool adjoint)
+{
+    const int W2 = m.W + 2;
+    const bool rlo = j < W2, rhi = j >= m.n0 - W2;
+    int l0 = rlo ? j : W2 + j - (m.n0 - W2);
+    l0 = l0 < 0 ? 0 : (l0 > 2 * W2 - 1 ? 2 * W2 - 1 : l0);
+    const float4 e0v = pml_ld4(m.e0 + (long long)s * m.r0 + l0 * m.gp + 4 * g);
+    const bool ok0 = rlo || rhi;
+    const float *pe1 = m.e1 + (long long)s * m.r1 + j * 2 * W2;
+    float ev[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i1 = 4 * g + c;
+        const bool clo = i1 < W2, chi = i1 >= m.n1 - W2 && i1 < m.n1;
+        int l1 = clo ? i1 : W2 + i1 - (m.n1 - W2);
+        l1 = l1 < 0 ? 0 : (l1 > 2 * W2 - 1 ? 2 * W2 - 1 : l1);
+        const float v1 = pe1[l1];
+        const float e1 = (clo || chi) ? v1 : 0.f;
+        const float e0 = ok0 ? comp(e0v, c) : 0.f;
+        ev[c] = adjoint ? e0 + e1 : fmaf(m.c0, e0, m.c1 * e1);
+    }
+    return make_float4(ev[0], ev[1], ev[2], ev[3]);
 }
 
 // ---- the thin launches of the one-launch-per-step family: one thread per cell (group), u = the global wavefield -------
