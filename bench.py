@@ -159,6 +159,8 @@ class AcousticMarmousi:
         self.torch, self.deepwave, self.dev, self.misfit = torch, deepwave, dev, misfit
         # BENCH_ABSORBING=cpml: the deepwave-shaped shim's second-order C-PML instead of the sponge (measurement runs)
         self.absorbing = os.environ.get("BENCH_ABSORBING", "sponge")
+        if os.environ.get("BENCH_PML_WIDTH"):
+            self.pml = int(os.environ["BENCH_PML_WIDTH"])
         self.full_nt = type(self).nt
         if nt:
             self.nt = nt

@@ -197,3 +197,41 @@ def test_stage_filter_is_the_causal_butterworth_and_differentiates_to_its_transp
     lhs = float((api.butterworth(x2, dt, 2.0, 12.0, 6) * yt).sum())
     rhs = float((x2 * xt.grad).sum())
     assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs))
+
+
+def test_wavesolver_shim_objects_match_the_reference_fixtures(golden_dir):
+    """Host-side classes of compat/seisgan_wavesolver.py (Model, TimeAxis, RickerSource: rows a12-a14) against the
+    vectors minted from the reference's own model.py / source.py - no GPU involved: construction only."""
+    from physicsbasedfwi2_amd.compat import seisgan_wavesolver as ws
+    g = _g(golden_dir, "seisgan_helpers.npz")
+    # Model: edge padding, the square-slowness setter, critical_dt, the damping field
+    nb, h0, h1 = g["cd_args"]
+    m = g["cd_m"].astype(np.float32)
+    model = ws.Model(origin=(0.0, 0.0), spacing=(float(h0), float(h1)), shape=m.shape, m=m, nbpml=int(nb))
+    assert model.shape_domain == tuple(g["cd_padded"].shape) and np.array_equal(model.m.data, g["cd_padded"].astype(np.float32))
+    assert np.allclose(model.vp, g["cd_vp"], rtol=1e-6) and np.isclose(model.critical_dt, g["cd_dt"], rtol=1e-6)
+    assert model.domain_size == ((m.shape[0] - 1) * float(h0), (m.shape[1] - 1) * float(h1))
+    n0, n1, nbd, d0, d1 = g["damp_b_args"]
+    mb = ws.Model(origin=(0.0, 0.0), spacing=(float(d0), float(d1)), shape=(int(n0) - 2 * int(nbd), int(n1) - 2 * int(nbd)),
+                  m=np.full((int(n0) - 2 * int(nbd), int(n1) - 2 * int(nbd)), 0.25, dtype=np.float32), nbpml=int(nbd))
+    assert np.allclose(mb.damp.data, g["damp_b"], rtol=1e-6, atol=0)
+    # TimeAxis: the three-of-four constructor, num derived as the reference derives it
+    for start, stop, step, num, stop2 in g["timeaxis"]:
+        ta = ws.TimeAxis(start=start, stop=stop, step=step)
+        assert ta.num == int(num) and ta.stop == stop2 and ta.time_values.size == int(num)
+    assert ws.TimeAxis(start=0.0, stop=1000.0, step=1.4).num == 716
+    import pytest
+    with pytest.raises(ValueError):
+        ws.TimeAxis(start=0.0, stop=1.0, step=0.1, num=11)
+    # RickerSource in both call styles of the reference (time= of the examples, time_range= of layers.py)
+    t = g["ricker_t"]
+    grid = model.grid
+    a = ws.RickerSource(name="src", grid=grid, f0=float(g["ricker_10hz_f0"]), time=t)
+    assert a.nt == t.size and a.npoint == 1 and np.allclose(a.data[:, 0], g["ricker_10hz"], rtol=1e-6, atol=1e-7)
+    ta = ws.TimeAxis(start=float(t[0]), stop=float(t[-1]), num=int(t.size))
+    b = ws.RickerSource(name="src", grid=grid, f0=float(g["ricker_25hz_f0"]), time_range=ta, npoint=2)
+    assert b.data.shape == (t.size, 2) and np.allclose(b.data[:, 1], g["ricker_25hz"], rtol=1e-5, atol=1e-6)
+    r = ws.Receiver(name="rec", grid=grid, ntime=t.size, npoint=5)
+    assert r.data.shape == (t.size, 5) and r.coordinates.data.shape == (5, 2)
+    f = ws.Function(name="grad", grid=grid)
+    assert f.data.shape == model.shape_domain and not f.data.any()
