@@ -370,6 +370,7 @@ __global__ void ac_finalize(const float *acc, int ngroups, int n0, int n1, int g
 // The arithmetic per cell is the same fmaf chain as ac_step (bitwise identical results).
 // ================================================================================================
 constexpr int kClThreads = 1024;
+constexpr int kClPmlLdsLimit = 160 * 1024 - 1024;    // dynamic LDS a C-PML launch may ask for (272 B of static LDS next to it)
 constexpr int kClMaxNG = 4;                  // groups of 4 cells a thread may own
 constexpr unsigned kClMaxSpin = 400000;
 // Ablation builds: wave 0..15 of slab NW/2 of the first shot writes s_memtime at phase boundary k of steps 64..127 to
@@ -431,6 +432,7 @@ struct ClParams {
     int *err;
     int *xcc_tab;                        // [nshot][NW] XCC_ID + 1 of each slab's workgroup (mifwi::same_xcd)
     AcPml pml;                           // second-order C-PML (PML = true variants): strip / region arrays in global memory
+    int pml_lds_floats;                  // dynamic LDS of the launch in floats: what a slab may carve layer arrays from (pml_place)
 #ifdef MIFWI_ABLATIONS
     long long *trace;                    // phase time stamps of one workgroup (MIFWI_AC_CL_TRACE), see CL_STAMP
 #endif
@@ -606,6 +608,36 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     float *bufA = lds, *bufB = lds + LR * PL;     // rows: 0,1 top halo | 2..R+1 own | R+2,R+3 bottom halo
     float *ldq1 = bufB + LR * PL;                 // damping tables (constant over the run): q1[gp], q0[R]
     float *ldq0 = ldq1 + p.gp;
+    // C-PML: the layer's arrays of this slab that fit behind the planes live in LDS (pml_place: exchanged ones first), the
+    // others in global memory.  `m` is p.pml with the pointers of the LDS-resident arrays redirected to the slab's own
+    // part of each array; m.lds / m.f* tell the cell functions which index that part starts at (pml_off).
+    AcPml m = p.pml;
+    if (PML) {
+        const long long W = m.W, W2 = m.W + 2;
+        const bool edge = w == 0 || w == p.NW - 1;
+        const long long base = 2LL * LR * PL + p.gp + ((R + 3) & ~3);
+        long long used = 0;
+        m.lds = pml_place(adj, edge, R, m.W, m.gp, (long long)p.pml_lds_floats - base, &used);
+        m.f0s = w == 0 ? 0 : W * m.gp; m.f0r = w == 0 ? 0 : W2 * m.gp;      // first index of this slab's part
+        m.f1s = (long long)r0 * 2 * W; m.f1r = (long long)r0 * 2 * W2;
+        float *q = ldq0 + ((R + 3) & ~3);
+        auto take = [&](int bit, float *&ptr) {
+            if (m.lds & (unsigned)bit) { ptr = q; q += pml_lds_floats(bit, R, m.W, m.gp); }
+        };
+        if (!adj) {                          // the order of pml_place
+            take(PML_A1, m.A1); take(PML_E1, m.e1); take(PML_A0, m.A0); take(PML_E0, m.e0); take(PML_B1, m.B1); take(PML_B0, m.B0);
+        } else {
+            take(PML_P1, m.P1); take(PML_Q1, m.Q1); take(PML_E1, m.e1); take(PML_P0, m.P0); take(PML_Q0, m.Q0);
+            take(PML_E0, m.e0); take(PML_A1, m.A1); take(PML_B1, m.B1); take(PML_A0, m.A0); take(PML_B0, m.B0);
+        }
+        // memory variables that live in LDS for the run: in from the global state (out again at the end)
+        auto copy = [&](int bit, float *dst, const float *src, long long first, long long n, long long shot_stride) {
+            if (m.lds & (unsigned)bit)
+                for (long long e = t; e < n; e += kClThreads) dst[e] = src[(long long)s * shot_stride + first + e];
+        };
+        copy(PML_A1, m.A1, p.pml.A1, m.f1s, 2 * W * R, m.s1); copy(PML_B1, m.B1, p.pml.B1, m.f1s, 2 * W * R, m.s1);
+        if (edge) { copy(PML_A0, m.A0, p.pml.A0, m.f0s, W * m.gp, m.s0); copy(PML_B0, m.B0, p.pml.B0, m.f0s, W * m.gp, m.s0); }
+    }
     const int ngrp = R * p.ng;
     // row order with the four boundary rows first, so that a thread's slot 0 covers every group the
     // neighbours wait for: 0, 1, R-2, R-1, 2, 3, ..., R-3   (R >= 4 is guaranteed by the plan)
@@ -877,7 +909,6 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         }
         CL_STAMP(1);
         if (PML) {
-            const AcPml &m = p.pml;
             const float *ul = cur + (2 - r0) * PL + 4;             // ul[i0 * PL + i1] = the current field at grid cell (i0, i1)
             if (!adj) {
                 cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_fwd_psi_cell(m, s, ax, c, ul, PL); });
@@ -915,7 +946,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                     q0 = ldq0[(jg_i >> 12) - r0];
                 }
                 float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (PML) pe = pml_term(p.pml, s, jg_i >> 12, jg_i & 4095, adj);      // the layer's term of the group's four cells
+                if (PML) pe = pml_term(m, s, jg_i >> 12, jg_i & 4095, adj);      // the layer's term of the group's four cells
                 cl_update<MODE == 1, PML>(cur + lo_i, prv + lo_i, PL, rr[i], q0, q1, damped, p.c0, p.c1,
                                           p.n1 - 4 * (jg_i & 4095), un, gk, pe);
                 if (!adj && !slow_sparse && i == src_slot) {
@@ -1082,6 +1113,17 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         float *tmp = cur; cur = prv; prv = tmp;
     }
 
+    if (PML) {                               // memory variables kept in LDS go back to the global state
+        __syncthreads();
+        const long long W = m.W;
+        const bool edge = w == 0 || w == p.NW - 1;
+        auto back = [&](int bit, float *dst, const float *src, long long first, long long n, long long shot_stride) {
+            if (m.lds & (unsigned)bit)
+                for (long long e = t; e < n; e += kClThreads) dst[(long long)s * shot_stride + first + e] = src[e];
+        };
+        back(PML_A1, p.pml.A1, m.A1, m.f1s, 2 * W * R, m.s1); back(PML_B1, p.pml.B1, m.B1, m.f1s, 2 * W * R, m.s1);
+        if (edge) { back(PML_A0, p.pml.A0, m.A0, m.f0s, W * m.gp, m.s0); back(PML_B0, p.pml.B0, m.B0, m.f0s, W * m.gp, m.s0); }
+    }
     // ---- write the state (own rows of both levels) and the accumulators back --------------------
     const int parE = adj ? ((p.nt - 1 - (p.n_last - 1)) & 1) : (p.n_last & 1);
     float *ocur = (parE ? p.ub : p.ua) + (long long)s * p.shot_stride;
@@ -1234,8 +1276,24 @@ void cluster_setup(mifwi_acoustic_plan *pl)
                 rt = hint;
                 rows = std::max(rt, mifwi::ceil_div(pl->d.n0 - 2 * rt, nw - 2));
             }
-            const long long lds = (2LL * (rows + 4) * pl->PL + pl->gp + rows + 8) * sizeof(float);
+            long long lds = (2LL * (rows + 4) * pl->PL + pl->gp + rows + 8) * sizeof(float);
             if (lds > 150 * 1024) continue;
+            if (pl->pmlW > 0) {
+                // the layer's arrays each slab class can keep in LDS (pml_place, same call as in the kernel): the launch asks
+                // for the largest need; nothing placed still works (everything through global memory)
+                const int rows_int = mifwi::ceil_div(pl->d.n0 - 2 * rt, nw - 2);
+                const long long cap = kClPmlLdsLimit / (long long)sizeof(float);
+                long long need = lds / (long long)sizeof(float);
+                for (int cls = 0; cls < 2; ++cls)
+                    for (int adjm = 0; adjm < 2; ++adjm) {
+                        const int rws = cls == 0 ? rt : rows_int;
+                        const long long base = 2LL * (rws + 4) * pl->PL + pl->gp + ((rws + 3) & ~3);
+                        long long used = 0;
+                        pml_place(adjm != 0, cls == 0, rws, pl->pmlW, pl->gp, cap - base, &used);
+                        need = std::max(need, base + used);
+                    }
+                lds = std::min<long long>(need, cap) * (long long)sizeof(float);
+            }
             if ((long long)rows * pl->ng > (long long)kClMaxNG * kClThreads || pl->ng > 4095 ||
                 4 * pl->gp > 3 * kClThreads) continue;
             // rows of the slowest slab, a sponge row counted 1.5 times (a division per cell and step)
@@ -1267,7 +1325,9 @@ void cluster_setup(mifwi_acoustic_plan *pl)
                            (const void *)ac_cluster<0, false, true, true>, (const void *)ac_cluster<1, false, true, true>,
                            (const void *)ac_cluster<2, false, true, true>, (const void *)ac_cluster<0, true, true, true>,
                            (const void *)ac_cluster<1, true, true, true>, (const void *)ac_cluster<2, true, true, true>})
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mifwi::kClusterLdsLimit) != hipSuccess) {
+        // one cap for every variant (the attribute is per function and plans of both kinds coexist): C-PML plans ask for up
+        // to kClPmlLdsLimit, the others never for more than kClusterLdsLimit
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kClPmlLdsLimit) != hipSuccess) {
             (void)hipGetLastError();           // not sticky: the plan simply uses one launch per step
             pl->cluster = 0;
             return;
@@ -1291,6 +1351,7 @@ ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const flo
     c.rcv_plain = env_int("MIFWI_AC_ADJ_PLAIN", 1);
     // fat slabs nap long between poll passes, thin ones short (mifwi::poll_nap)
     c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(pl->d.n0, pl->NW) >= 16 ? 48 : 1);
+    c.pml_lds_floats = env_int("MIFWI_AC_PML_LDS", 1) ? pl->cl_lds / (int)sizeof(float) : 0;      // 0: every layer array through global memory
     return c;
 }
 

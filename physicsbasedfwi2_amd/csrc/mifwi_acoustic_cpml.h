@@ -26,7 +26,56 @@ struct AcPml {
     float c0, c1;
     int shot0;                   // first shot of the launch (blockIdx.y counts from it)
     int nshot;
+    // single-launch kernels only: the arrays of `lds` (PML_* bits) live in the workgroup's LDS, where the pointer is the
+    // slab's own part of the array and f0s/f0r/f1s/f1r the element of the shot's array that part starts at
+    unsigned lds;
+    long long f0s, f0r, f1s, f1r;
 };
+
+// Which of the layer's arrays of ONE slab live in LDS inside the single-launch kernels (the rest stay in global memory,
+// i.e. the XCD's L2): as many as fit behind the slab's two field planes, the exchanged ones first (a neighbour's psi',
+// P, Q and the layer's term e are read by other threads: through L2 they cost the CU's 64 B/clk L1 fill rate, which is
+// what bounds the layer's phases), the pointwise memory variables last.  Same function on the host (LDS size of the
+// launch) and on the device (carving): bit k set = array k of kPmlOrder is in LDS.
+enum { PML_A0 = 1, PML_B0 = 2, PML_P0 = 4, PML_Q0 = 8, PML_E0 = 16, PML_A1 = 32, PML_B1 = 64, PML_P1 = 128, PML_Q1 = 256, PML_E1 = 512 };
+// Element offset of shot s inside array `bit`: s x the per-shot size in global memory; minus the first element the slab
+// holds when the array lives in LDS.  Always added to the cell's index BEFORE the pointer (the sum is a valid index of
+// the buffer; a pointer biased below an LDS buffer leaves the LDS aperture).
+__device__ __forceinline__ long long pml_off(const AcPml &p, const unsigned bit, const int s)
+{
+    const bool ax0 = bit & (PML_A0 | PML_B0 | PML_P0 | PML_Q0 | PML_E0), reg = bit & (PML_E0 | PML_E1);
+    const long long stride = ax0 ? (reg ? p.r0 : p.s0) : (reg ? p.r1 : p.s1);
+    const long long first = ax0 ? (reg ? p.f0r : p.f0s) : (reg ? p.f1r : p.f1s);
+    return (p.lds & bit) ? -first : (long long)s * stride;
+}
+__host__ __device__ inline long long pml_lds_floats(int bit, int rows, int W, int gp)
+{
+    const long long W2 = W + 2;
+    long long n = 0;
+    switch (bit) {
+        case PML_A0: case PML_B0: case PML_P0: case PML_Q0: n = (long long)W * gp; break;
+        case PML_E0: n = W2 * gp; break;
+        case PML_A1: case PML_B1: case PML_P1: case PML_Q1: n = 2LL * W * rows; break;
+        case PML_E1: n = 2LL * W2 * rows; break;
+    }
+    return (n + 3) & ~3LL;
+}
+__host__ __device__ inline unsigned pml_place(bool adjoint, bool edge, int rows, int W, int gp, long long free_floats, long long *used)
+{
+    const int fwd[6] = {PML_A1, PML_E1, PML_A0, PML_E0, PML_B1, PML_B0};
+    const int adj[10] = {PML_P1, PML_Q1, PML_E1, PML_P0, PML_Q0, PML_E0, PML_A1, PML_B1, PML_A0, PML_B0};
+    unsigned mask = 0;
+    long long u = 0;
+    for (int k = 0; k < (adjoint ? 10 : 6); ++k) {
+        const int bit = adjoint ? adj[k] : fwd[k];
+        const bool axis0 = bit & (PML_A0 | PML_B0 | PML_P0 | PML_Q0 | PML_E0);
+        if (axis0 && !edge) continue;
+        const long long n = pml_lds_floats(bit, rows, W, gp);
+        if (u + n <= free_floats) { mask |= (unsigned)bit; u += n; }
+    }
+    if (used) *used = u;
+    return mask;
+}
 
 __host__ __device__ inline long long pml_persist_per_shot(int W, int n0, int gp) { return 2LL * (2LL * W * gp) + 2LL * (2LL * W * n0); }
 __host__ __device__ inline long long pml_scratch_per_shot(int W, int n0, int gp)
@@ -39,12 +88,12 @@ __host__ __device__ inline long long pml_scratch_per_shot(int W, int n0, int gp)
 // clamped, always valid index and the result is selected afterwards, so that the four or five neighbour reads of a
 // cell are independent loads in flight together (as separate branches they were serialised round trips: 3 000 clocks
 // per cell in the single-launch kernel's layer phases).
-__device__ __forceinline__ float pml_get1(const AcPml &p, const float *a, int i0, int i1)
+__device__ __forceinline__ float pml_get1(const AcPml &p, const float *a, long long off, int i0, int i1)
 {
     const bool lo = i1 >= 0 && i1 < p.W, hi = i1 >= p.n1 - p.W && i1 < p.n1;
     int l = lo ? i1 : p.W + i1 - (p.n1 - p.W);
     l = l < 0 ? 0 : (l > 2 * p.W - 1 ? 2 * p.W - 1 : l);
-    const float v = a[i0 * 2 * p.W + l];
+    const float v = a[off + (i0 * 2 * p.W + l)];
     return (lo || hi) ? v : 0.f;          // (the load above is unconditional)
 }
 __device__ __forceinline__ float pml_d1(float m2, float m1, float p1, float p2) { return fmaf(CF1, p1 - m1, CF2 * (p2 - m2)); }
@@ -94,12 +143,13 @@ __device__ __forceinline__ PmlCell pml_cell(const AcPml &p, unsigned id, int axi
 __device__ __forceinline__ float4 pml_ld4(const float *q) { return *reinterpret_cast<const float4 *>(q); }
 __device__ __forceinline__ void pml_st4(float *q, const float (&v)[4]) { *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]); }
 // four cells of a strip-shaped axis-0 array at row i0 (zero outside the strip / the grid); branch-free as pml_get1
-__device__ __forceinline__ float4 pml_get0v(const AcPml &p, const float *a, int i0, int i1)
+__device__ __forceinline__ float4 pml_get0v(const AcPml &p, const float *a, long long off, int i0, int i1)
 {
     const bool lo = i0 >= 0 && i0 < p.W, hi = i0 >= p.n0 - p.W && i0 < p.n0;
     int l = lo ? i0 : p.W + i0 - (p.n0 - p.W);
-    l = l < 0 ? 0 : (l > 2 * p.W - 1 ? 2 * p.W - 1 : l);
-    const float4 v = pml_ld4(a + l * p.gp + i1);
+    const int l_lo = 2 * i0 >= p.n0 ? p.W : 0;            // clamped into the strip of the row's own side (the part a
+    l = l < l_lo ? l_lo : (l > l_lo + p.W - 1 ? l_lo + p.W - 1 : l);   // slab of a single-launch kernel holds in LDS)
+    const float4 v = pml_ld4(a + (off + (l * p.gp + i1)));
     const bool ok = lo || hi;
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
@@ -111,7 +161,7 @@ __device__ __forceinline__ void ac_pml_fwd_psi_cell(const AcPml &p, const int s,
     (void)k;
     if (!c.strip) return;
     if (axis == 0) {
-        float *A = p.A0 + (long long)s * p.s0 + c.sidx;
+        float *A = p.A0 + (pml_off(p, PML_A0, s) + c.sidx);
         const float4 m2 = pml_ld4(u + k - 2 * pt), m1 = pml_ld4(u + k - pt), p1 = pml_ld4(u + k + pt), p2 = pml_ld4(u + k + 2 * pt);
         const float4 a4 = pml_ld4(A);
         const float a = p.ab0[c.i0], b = p.ab0[p.n0 + c.i0];
@@ -120,9 +170,9 @@ __device__ __forceinline__ void ac_pml_fwd_psi_cell(const AcPml &p, const int s,
         for (int q = 0; q < 4; ++q) o[q] = fmaf(b, comp(a4, q), a * pml_d1(comp(m2, q), comp(m1, q), comp(p1, q), comp(p2, q)));
         pml_st4(A, o);
     } else {
-        float *A = p.A1 + (long long)s * p.s1;
+        float *A = p.A1 + (pml_off(p, PML_A1, s) + c.sidx);
         const float d = pml_d1(u[k - 2], u[k - 1], u[k + 1], u[k + 2]);
-        A[c.sidx] = fmaf(p.ab1[p.gp + c.i1], A[c.sidx], p.ab1[c.i1] * d);
+        *A = fmaf(p.ab1[p.gp + c.i1], *A, p.ab1[c.i1] * d);
     }
 }
 
@@ -133,10 +183,10 @@ __device__ __forceinline__ void ac_pml_fwd_zeta_cell(const AcPml &p, const int s
     // every load is issued before the first use (and unconditionally, at a clamped index): one memory round trip per
     // cell, not one per operand group
     if (axis == 0) {
-        const float *A = p.A0 + (long long)s * p.s0;
-        float *B = p.B0 + (long long)s * p.s0 + (c.strip ? c.sidx : 0);
-        const float4 am2 = pml_get0v(p, A, c.i0 - 2, c.i1), am1 = pml_get0v(p, A, c.i0 - 1, c.i1);
-        const float4 ap1 = pml_get0v(p, A, c.i0 + 1, c.i1), ap2 = pml_get0v(p, A, c.i0 + 2, c.i1);
+        const long long oA = pml_off(p, PML_A0, s);
+        float *B = p.B0 + (pml_off(p, PML_B0, s) + (c.strip ? (long long)c.sidx : p.f0s));
+        const float4 am2 = pml_get0v(p, p.A0, oA, c.i0 - 2, c.i1), am1 = pml_get0v(p, p.A0, oA, c.i0 - 1, c.i1);
+        const float4 ap1 = pml_get0v(p, p.A0, oA, c.i0 + 1, c.i1), ap2 = pml_get0v(p, p.A0, oA, c.i0 + 2, c.i1);
         const float4 b4 = pml_ld4(B);
         const float a = p.ab0[c.i0], b = p.ab0[p.n0 + c.i0];
         const float4 m2 = pml_ld4(u + k - 2 * pt), m1 = pml_ld4(u + k - pt), uc = pml_ld4(u + k);
@@ -150,12 +200,12 @@ __device__ __forceinline__ void ac_pml_fwd_zeta_cell(const AcPml &p, const int s
             e[q] = dp[q] + z[q];
         }
         if (c.strip) pml_st4(B, z);
-        pml_st4(p.e0 + (long long)s * p.r0 + c.ridx, e);
+        pml_st4(p.e0 + (pml_off(p, PML_E0, s) + c.ridx), e);
     } else {
-        const float *A = p.A1 + (long long)s * p.s1;
-        float *B = p.B1 + (long long)s * p.s1 + (c.strip ? c.sidx : 0);
-        const float a0 = pml_get1(p, A, c.i0, c.i1 - 2), a1 = pml_get1(p, A, c.i0, c.i1 - 1);
-        const float a2 = pml_get1(p, A, c.i0, c.i1 + 1), a3 = pml_get1(p, A, c.i0, c.i1 + 2);
+        const long long oA = pml_off(p, PML_A1, s);
+        float *B = p.B1 + (pml_off(p, PML_B1, s) + (c.strip ? c.sidx : c.i0 * 2 * p.W));
+        const float a0 = pml_get1(p, p.A1, oA, c.i0, c.i1 - 2), a1 = pml_get1(p, p.A1, oA, c.i0, c.i1 - 1);
+        const float a2 = pml_get1(p, p.A1, oA, c.i0, c.i1 + 1), a3 = pml_get1(p, p.A1, oA, c.i0, c.i1 + 2);
         const float bz = *B;
         const float a = p.ab1[c.i1], b = p.ab1[p.gp + c.i1];
         const float dp = pml_d1(a0, a1, a2, a3);
@@ -163,7 +213,7 @@ __device__ __forceinline__ void ac_pml_fwd_zeta_cell(const AcPml &p, const int s
         float z = fmaf(b, bz, a * (d2 + dp));
         if (!c.strip) z = 0.f;
         if (c.strip) *B = z;
-        (p.e1 + (long long)s * p.r1)[c.ridx] = dp + z;
+        p.e1[pml_off(p, PML_E1, s) + c.ridx] = dp + z;
     }
 }
 
@@ -174,7 +224,7 @@ __device__ __forceinline__ void ac_pml_adj_a_cell(const AcPml &p, const int s, c
     (void)k;
     if (!c.strip) return;
     if (axis == 0) {
-        float *B = p.B0 + (long long)s * p.s0 + c.sidx;
+        float *B = p.B0 + (pml_off(p, PML_B0, s) + c.sidx);
         const float4 w4 = pml_ld4(u + k), b4 = pml_ld4(B);
         const float a = p.ab0[c.i0], b = p.ab0[p.n0 + c.i0];
         float P[4], Z[4];
@@ -183,13 +233,13 @@ __device__ __forceinline__ void ac_pml_adj_a_cell(const AcPml &p, const int s, c
             const float t = fmaf(p.c0, comp(w4, q), comp(b4, q));
             P[q] = a * t; Z[q] = b * t;
         }
-        pml_st4(p.P0 + (long long)s * p.s0 + c.sidx, P);
+        pml_st4(p.P0 + (pml_off(p, PML_P0, s) + c.sidx), P);
         pml_st4(B, Z);
     } else {
-        float *B = p.B1 + (long long)s * p.s1;
-        const float a = fmaf(p.c1, u[k], B[c.sidx]);
-        (p.P1 + (long long)s * p.s1)[c.sidx] = p.ab1[c.i1] * a;
-        B[c.sidx] = p.ab1[p.gp + c.i1] * a;
+        float *B = p.B1 + (pml_off(p, PML_B1, s) + c.sidx);
+        const float a = fmaf(p.c1, u[k], *B);
+        p.P1[pml_off(p, PML_P1, s) + c.sidx] = p.ab1[c.i1] * a;
+        *B = p.ab1[p.gp + c.i1] * a;
     }
 }
 
@@ -200,12 +250,12 @@ __device__ __forceinline__ void ac_pml_adj_b_cell(const AcPml &p, const int s, c
     (void)k;
     if (!c.strip) return;
     if (axis == 0) {
-        const float *P = p.P0 + (long long)s * p.s0;
-        float *A = p.A0 + (long long)s * p.s0 + c.sidx;
+        const long long oP = pml_off(p, PML_P0, s);
+        float *A = p.A0 + (pml_off(p, PML_A0, s) + c.sidx);
         float4 w[4], pp[4];
         const int off[4] = {-2, -1, 1, 2};
 #pragma unroll
-        for (int o = 0; o < 4; ++o) { w[o] = pml_ld4(u + k + off[o] * pt); pp[o] = pml_get0v(p, P, c.i0 + off[o], c.i1); }
+        for (int o = 0; o < 4; ++o) { w[o] = pml_ld4(u + k + off[o] * pt); pp[o] = pml_get0v(p, p.P0, oP, c.i0 + off[o], c.i1); }
         const float4 a4 = pml_ld4(A);
         const float a = p.ab0[c.i0], b = p.ab0[p.n0 + c.i0];
         float Q[4], T[4];
@@ -216,15 +266,15 @@ __device__ __forceinline__ void ac_pml_adj_b_cell(const AcPml &p, const int s, c
             const float t = comp(a4, q) - pml_d1(v0, v1, v2, v3);
             Q[q] = a * t; T[q] = b * t;
         }
-        pml_st4(p.Q0 + (long long)s * p.s0 + c.sidx, Q);
+        pml_st4(p.Q0 + (pml_off(p, PML_Q0, s) + c.sidx), Q);
         pml_st4(A, T);
     } else {
-        const float *P = p.P1 + (long long)s * p.s1;
-        float *A = p.A1 + (long long)s * p.s1;
-        auto V = [&](int o) { return fmaf(p.c1, u[k + o], pml_get1(p, P, c.i0, c.i1 + o)); };
-        const float t = A[c.sidx] - pml_d1(V(-2), V(-1), V(1), V(2));
-        (p.Q1 + (long long)s * p.s1)[c.sidx] = p.ab1[c.i1] * t;
-        A[c.sidx] = p.ab1[p.gp + c.i1] * t;
+        const long long oP = pml_off(p, PML_P1, s);
+        float *A = p.A1 + (pml_off(p, PML_A1, s) + c.sidx);
+        auto V = [&](int o) { return fmaf(p.c1, u[k + o], pml_get1(p, p.P1, oP, c.i0, c.i1 + o)); };
+        const float t = *A - pml_d1(V(-2), V(-1), V(1), V(2));
+        p.Q1[pml_off(p, PML_Q1, s) + c.sidx] = p.ab1[c.i1] * t;
+        *A = p.ab1[p.gp + c.i1] * t;
     }
 }
 
@@ -234,21 +284,21 @@ __device__ __forceinline__ void ac_pml_adj_c_cell(const AcPml &p, const int s, c
     const int k = c.i0 * pt + c.i1;
     (void)k;
     if (axis == 0) {
-        const float *P = p.P0 + (long long)s * p.s0, *Q = p.Q0 + (long long)s * p.s0;
+        const long long oP = pml_off(p, PML_P0, s), oQ = pml_off(p, PML_Q0, s);
         float4 pv[5], qv[5];
 #pragma unroll
-        for (int o = 0; o < 5; ++o) { pv[o] = pml_get0v(p, P, c.i0 + o - 2, c.i1); qv[o] = pml_get0v(p, Q, c.i0 + o - 2, c.i1); }
+        for (int o = 0; o < 5; ++o) { pv[o] = pml_get0v(p, p.P0, oP, c.i0 + o - 2, c.i1); qv[o] = pml_get0v(p, p.Q0, oQ, c.i0 + o - 2, c.i1); }
         float e[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             e[q] = pml_d2(comp(pv[0], q), comp(pv[1], q), comp(pv[2], q), comp(pv[3], q), comp(pv[4], q)) -
                    pml_d1(comp(qv[0], q), comp(qv[1], q), comp(qv[3], q), comp(qv[4], q));
-        pml_st4(p.e0 + (long long)s * p.r0 + c.ridx, e);
+        pml_st4(p.e0 + (pml_off(p, PML_E0, s) + c.ridx), e);
     } else {
-        const float *P = p.P1 + (long long)s * p.s1, *Q = p.Q1 + (long long)s * p.s1;
-        auto gp_ = [&](int o) { return pml_get1(p, P, c.i0, c.i1 + o); };
-        auto gq_ = [&](int o) { return pml_get1(p, Q, c.i0, c.i1 + o); };
-        (p.e1 + (long long)s * p.r1)[c.ridx] =
+        const long long oP = pml_off(p, PML_P1, s), oQ = pml_off(p, PML_Q1, s);
+        auto gp_ = [&](int o) { return pml_get1(p, p.P1, oP, c.i0, c.i1 + o); };
+        auto gq_ = [&](int o) { return pml_get1(p, p.Q1, oQ, c.i0, c.i1 + o); };
+        p.e1[pml_off(p, PML_E1, s) + c.ridx] =
             pml_d2(gp_(-2), gp_(-1), gp_(0), gp_(1), gp_(2)) - pml_d1(gq_(-2), gq_(-1), gq_(1), gq_(2));
     }
 }
@@ -261,9 +311,9 @@ __device__ __forceinline__ float4 pml_term(const AcPml &m, int s, int j, int g, 
     const bool rlo = j < W2, rhi = j >= m.n0 - W2;
     int l0 = rlo ? j : W2 + j - (m.n0 - W2);
     l0 = l0 < 0 ? 0 : (l0 > 2 * W2 - 1 ? 2 * W2 - 1 : l0);
-    const float4 e0v = pml_ld4(m.e0 + (long long)s * m.r0 + l0 * m.gp + 4 * g);
+    const float4 e0v = pml_ld4(m.e0 + (pml_off(m, PML_E0, s) + (l0 * m.gp + 4 * g)));
     const bool ok0 = rlo || rhi;
-    const float *pe1 = m.e1 + (long long)s * m.r1 + j * 2 * W2;
+    const float *pe1 = m.e1 + (pml_off(m, PML_E1, s) + j * 2 * W2);
     float ev[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
