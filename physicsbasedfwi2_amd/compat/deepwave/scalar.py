@@ -16,9 +16,9 @@ edge-replicated into it, and rec[n] samples the field before step n.
 convolutional PML inside the same scalar scheme (memory variables psi, zeta on the layer's cells only; exact
 transposed adjoint; csrc/mifwi_acoustic_cpml.h, oracle/acoustic_cpml.c).  The 20-cell layer returns 1.6e-4 of the
 direct wave where the 20-cell sponge returns 4e-2 (tests/test_acoustic_cpml_oracle.py); inside the model the two
-modes are the same scheme bit for bit.  It runs on the one-launch-per-step kernels; the sponge stays the default
-because it is what the single-launch time loops carry.  ``pml_freq`` (Hz) sets the frequency
-shift of the layer (default: a fifth of the source band's upper end, 0.25 / dt / 5).
+modes are the same scheme bit for bit.  Both kernel families carry it (2.6-4.3x the sponge's time
+on Marmousi-sized grids); the sponge stays the default because it is the reference's in-tree absorbing layer.
+``pml_freq`` (Hz) sets the frequency shift of the layer (default: a fifth of the source band's upper end, 0.25 / dt / 5).
 
 ``absorbing="cpml-staggered"`` (round 2's C-PML) advances the scalar equation as the first-order pressure-velocity
 system on the staggered grid - the P-SV solver of this library in a fluid (Vs = 0, rho = 1) with its C-PML on every
