@@ -6,7 +6,7 @@ profiles/<round>_issue_counters.json: vector / scalar / LDS instructions per wav
 into the bound it quotes for an LDS-resident time loop: issue cycles of the SHIPPED kernel (guide: a wave's vector
 instruction costs 4 issue cycles, MI355X_MICROARCH.md "vector-instruction ISSUE cost") over the cycles of a step.
 
-usage: issue_counters.py PMC_DIR OUT.json --workload W [--nt N]
+usage: issue_counters.py PMC_DIR OUT.json --workload W [--nt N] [--suffix _cpml]
 """
 import argparse
 import json
@@ -30,10 +30,11 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--workload", required=True, choices=sorted(bench.WORKLOADS))
     ap.add_argument("--nt", type=int, default=0)
+    ap.add_argument("--suffix", default="", help="appended to the entry's key (\"_cpml\": the pass ran with BENCH_ABSORBING=cpml)")
     a = ap.parse_args()
     cls = bench.WORKLOADS[a.workload]
     physics = a.workload.split("_")[0]
-    key = "%s_%dx%d" % (physics, cls.nz, cls.nx)
+    key = "%s_%dx%d" % (physics, cls.nz, cls.nx) + a.suffix
     nt = a.nt or cls.nt
     tot = {c: pmc_traffic.totals(a.pmc_dir, c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")}
     try:

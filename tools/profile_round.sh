@@ -29,6 +29,11 @@ issue() {  # workload: one --pmc pass of the SQ instruction counters
     find $O/pmc_issue_$1 -name "*.csv" -size +200k -delete
 }
 issue elastic_marmousi && issue acoustic_marmousi || exit 1
+# the acoustic single-launch kernels with the second-order C-PML (bench.py's `also` entry "..._cpml20")
+rm -rf $O/pmc_issue_cpml
+BENCH_ABSORBING=cpml timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/pmc_issue_cpml -- python bench.py --workload acoustic_marmousi --steps 1 --warmup 0 --no-cpu-baseline --no-also --no-verify > $O/pmc.log 2>&1 || { tail -5 $O/pmc.log; exit 1; }
+python tools/issue_counters.py $O/pmc_issue_cpml $O/${R}_issue_counters.json --workload acoustic_marmousi --suffix _cpml > /dev/null || exit 1
+find $O/pmc_issue_cpml -name "*.csv" -size +200k -delete
 cp $O/${R}_issue_counters.json profiles/${R}_issue_counters.json
 pmc el100 --workload elastic_marmousi -- --workload elastic_marmousi &&
 pmc ac174 --workload acoustic_marmousi -- --workload acoustic_marmousi &&
