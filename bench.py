@@ -355,17 +355,18 @@ class ElasticMarmousi:
         xr = np.arange(self.x_first, min(self.rec_x_max, (self.nx - 2) * self.h) + self.h, self.rec_dx)
         _, _, rc = profiles.cells_round(xr, np.full(xr.size, rec_depth), self.h, self.nx)
         self.nrec = xr.size
-        self.sc = torch.tensor(sc).view(ns, 1, 1)
-        self.sw = torch.ones(ns, 1, 1)
-        self.rc = torch.tensor(rc).view(1, -1, 1).repeat(ns, 1, 1)
-        self.rw = torch.ones(ns, self.nrec, 1)
+        # acquisition and C-PML profiles live on the device, as the model does (a training loop builds them once)
+        self.sc = torch.tensor(sc, dtype=torch.int32).view(ns, 1, 1).to(dev)
+        self.sw = torch.ones(ns, 1, 1, device=dev)
+        self.rc = torch.tensor(rc, dtype=torch.int32).view(1, -1, 1).repeat(ns, 1, 1).to(dev)
+        self.rw = torch.ones(ns, self.nrec, 1, device=dev)
         wav = profiles.ricker(freq, self.nt, self.dt, 1.0 / freq) * (self.dt / self.h ** 2) * 1e9
         self.f = wav.reshape(-1, 1, 1).repeat(1, ns, 1).to(dev)
         vmax = 4500.0
         assert self.dt <= profiles.elastic_cfl_limit(self.h, vmax)
         self.pz = torch.tensor(profiles.cpml_tables(self.nz, self.pml, self.h, self.dt, 1500.0, 5.0,
-                                                    low=not self.free_surface))
-        self.px = torch.tensor(profiles.cpml_tables(self.nx, self.pml, self.h, self.dt, 1500.0, 5.0))
+                                                    low=not self.free_surface), dtype=torch.float32).to(dev)
+        self.px = torch.tensor(profiles.cpml_tables(self.nx, self.pml, self.h, self.dt, 1500.0, 5.0), dtype=torch.float32).to(dev)
         self.prm = [torch.tensor(a, device=dev, requires_grad=True)
                     for a in synth_elastic(self.nz, self.nx, 0)]
         with torch.no_grad():
@@ -375,7 +376,17 @@ class ElasticMarmousi:
                                                  self.rc, self.rw, self.pml, free_surface=self.free_surface)
         self._ev = []
         self._ev_chunks = []
-        self.last_rec = None
+        self._last = None
+
+    @property
+    def last_rec(self):
+        """[2][nt][shots][nrec]: vx and vz of the last pass (the in-run cross-check compares them between kernel families)."""
+        torch = self.torch
+        if self._last is None:
+            return None
+        if isinstance(self._last, tuple):
+            return torch.stack(list(self._last))
+        return torch.cat(self._last, dim=2)
 
     @property
     def profile_key(self):
@@ -445,7 +456,7 @@ class ElasticMarmousi:
         mat.backward(leaf.grad)
         if timed:
             self._ev_chunks.append((t_f, t_b))
-        self.last_rec = torch.cat(recs, dim=2)
+        self._last = recs                               # [vx | vz] of every chunk, concatenated on demand (cross-check only)
         return torch.stack([p.grad for p in self.prm]), total
 
     def step(self, timed=False):
@@ -468,7 +479,7 @@ class ElasticMarmousi:
         ev[3].record()
         if timed:
             self._ev.append(ev)
-        self.last_rec = torch.stack([rvx.detach(), rvz.detach()])
+        self._last = (rvx.detach(), rvz.detach())       # stacked on demand (cross-check only): not a 200 MB copy per timed pass
         return torch.stack([p.grad for p in self.prm]), loss
 
     def resident_nt(self):
@@ -533,8 +544,8 @@ class ElasticMarmousi:
         pz = H.cpml_profiles(self.nz, self.pml, self.h, self.dt, 1500.0, 5.0, lo=not self.free_surface)
         px = H.cpml_profiles(self.nx, self.pml, self.h, self.dt, 1500.0, 5.0)
         ns = min(self.ns, cores)
-        sc = self.sc.numpy()[:ns]
-        rc = self.rc.numpy()[:ns]
+        sc = self.sc.cpu().numpy()[:ns]
+        rc = self.rc.cpu().numpy()[:ns]
 
         def run(nt):
             f = np.zeros((nt, ns, 1), dtype=np.float32)
@@ -718,7 +729,7 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
     for _ in range(args.steps):
         grad, loss = one_step(True)
         losses.append(loss.detach())            # device scalars: no sync inside the timed region
-        gsums.append(grad.detach().double().abs().sum())
+        gsums.append(grad.detach().abs().sum(dtype=torch.float64))
     barrier()
     el = time.perf_counter() - t0
     # single-launch time loops that gave up inside the timed region and were re-run with one launch per step (rank 0's

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define MIFWI_VERSION_MAJOR 0
-#define MIFWI_VERSION_MINOR 5   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format; 4: mifwi_fallback_count; 5: mifwi_agent_handoff_count, mifwi_slow_handoff_count; acoustic desc gained cpml_width, layout state_elems */
+#define MIFWI_VERSION_MINOR 6   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format; 4: mifwi_fallback_count; 5: mifwi_agent_handoff_count, mifwi_slow_handoff_count; acoustic desc gained cpml_width, layout state_elems; 6: mifwi_elastic_materials, mifwi_elastic_materials_vjp */
 
 enum {
     MIFWI_OK = 0,
@@ -312,6 +312,23 @@ int64_t mifwi_gradient_condition_work_elems(int32_t nplane);
 int mifwi_gradient_condition(int device, const float *grad, const float *models, float *out, int32_t nplane,
                              int32_t nz, int32_t nx, const float *row_weight, float sigma, int32_t flip,
                              int32_t mute_rows, const float *factors, float *work, void *stream);
+
+/* ======================================================================================
+ * MATERIAL PARAMETERISATION of the elastic kernels and its chain rule
+ *
+ * (Vp, Vs, rho) -> mat[5][nz][nx] = lambda dt/h, (lambda + 2 mu) dt/h, mu_xz dt/h (harmonic mean of the four mu
+ * around the sxz node, 0 in water), dt/(h rho_x), dt/(h rho_z) (arithmetic means at the vx / vz nodes), edge values
+ * replicated; free_surface: row 0 in the effective form of the stress-imaging condition.  What DENISE does inside
+ * set_model before a forward run and undoes when get_fwi_gradients returns Vp / Vs / rho gradients
+ * (models/networks.py:7698-7712, 7802-7806, 9790-9800); physicsbasedfwi2_amd/elastic.py:staggered_materials is the
+ * definition (same operations and roundings).  All arrays device, [nz][nx] row-major, no padding.
+ * mifwi_elastic_materials_vjp: grad_out [5][nz][nx] -> grad_vp, grad_vs, grad_rho (gather, bitwise repeatable).
+ * ==================================================================================== */
+int mifwi_elastic_materials(int device, const float *vp, const float *vs, const float *rho, float *mat, int32_t nz,
+                            int32_t nx, float dt_over_h, int32_t free_surface, void *stream);
+int mifwi_elastic_materials_vjp(int device, const float *vp, const float *vs, const float *rho, const float *grad_out,
+                                float *grad_vp, float *grad_vs, float *grad_rho, int32_t nz, int32_t nx,
+                                float dt_over_h, int32_t free_surface, void *stream);
 
 #ifdef __cplusplus
 }

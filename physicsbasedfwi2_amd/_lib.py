@@ -92,6 +92,9 @@ SIGNATURES = {
     "mifwi_gradient_condition_work_elems": (ctypes.c_int64, [ctypes.c_int32]),
     "mifwi_gradient_condition": (ctypes.c_int, [ctypes.c_int] + [_P] * 3 + [ctypes.c_int32] * 3 + [_P, ctypes.c_float] +
                                  [ctypes.c_int32] * 2 + [_P] * 3),
+    "mifwi_elastic_materials": (ctypes.c_int, [ctypes.c_int] + [_P] * 4 + [ctypes.c_int32] * 2 + [ctypes.c_float, ctypes.c_int32, _P]),
+    "mifwi_elastic_materials_vjp": (ctypes.c_int, [ctypes.c_int] + [_P] * 7 + [ctypes.c_int32] * 2 +
+                                    [ctypes.c_float, ctypes.c_int32, _P]),
 }
 MISFIT_L1_TRACE_NORM = 0
 MISFIT_L2 = 1

@@ -68,10 +68,40 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Geometries already built from the caller's four tap tensors, when those live on the device (weak references + versions:
+# an entry is used only while the very same, unmodified tensor objects are passed again).  A training loop passes the same
+# acquisition every iteration: the validation of the cells (a host round trip that stalls the launch queue) is paid once.
+_GEOMETRIES = []
+
+
 class _Geometry:
     """Device-resident sparse-point description shared by forward and backward."""
 
+    @classmethod
+    def get(cls, src_cell, src_w, rec_cell, rec_w, device):
+        import weakref
+        given = (src_cell, src_w, rec_cell, rec_w)
+        if not all(t.is_cuda for t in given):      # host tensors may alias numpy buffers (no version counter there): rebuilt every call
+            return cls(src_cell, src_w, rec_cell, rec_w, device)
+        for refs, versions, dev, geom in _GEOMETRIES:
+            if dev == device and all(r() is t for r, t in zip(refs, given)) and versions == tuple(t._version for t in given):
+                return geom
+        geom = cls(src_cell, src_w, rec_cell, rec_w, device)
+        _GEOMETRIES[:] = [e for e in _GEOMETRIES if all(r() is not None for r in e[0])][-15:]
+        _GEOMETRIES.append((tuple(weakref.ref(t) for t in given), tuple(t._version for t in given), device, geom))
+        return geom
+
+    def check_cells(self, ncell, what):
+        """Every tap inside the grid (an out-of-grid cell would fault the kernels).  One host round trip, once per
+        geometry."""
+        if self._top is None:
+            tops = [c.max() for c in (self.src_cell, self.rec_cell) if c.numel()]
+            self._top = int(torch.stack(tops).max()) if tops else -1
+        if self._top >= ncell:
+            raise MifwiError("src_cell/rec_cell hold a cell outside the %s grid" % what)
+
     def __init__(self, src_cell, src_w, rec_cell, rec_w, device):
+        self._top = None
         self.src_cell = src_cell.to(device=device, dtype=torch.int32).contiguous()
         self.src_w = src_w.to(device=device, dtype=torch.float32).contiguous()
         self.rec_cell = rec_cell.to(device=device, dtype=torch.int32).contiguous()
@@ -99,10 +129,7 @@ class _AcousticFn(torch.autograd.Function):
                                                                       tuple(geom.src_cell.shape)))
         nrec, ntap = geom.rec_cell.shape[1], geom.rec_cell.shape[2]
         ncell = n0 * n1
-        # one host round trip validates every tap (an out-of-grid cell would fault the kernels)
-        tops = [c.max() for c in (geom.src_cell, geom.rec_cell) if c.numel()]
-        if tops and int(torch.stack(tops).max()) >= ncell:
-            raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (n0, n1))
+        geom.check_cells(ncell, "%dx%d" % (n0, n1))
         with torch.cuda.device(dev):
             plan = AcousticPlan(n0, n1, nt, ns, nsrc, nrec, ntap, c0, c1, dev.index,
                                 shots_per_group, edge_rows, cpml_width)
@@ -242,7 +269,7 @@ def propagate(r, f, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
     returns rec [nt,nshot,nrec] with rec[n] sampled from u^n.
     """
     _require_cuda(r, "r")
-    geom = _Geometry(src_cell, src_w, rec_cell, rec_w, r.device)
+    geom = _Geometry.get(src_cell, src_w, rec_cell, rec_w, r.device)
     f = f.to(device=r.device)
     ntap = geom.src_cell.shape[2]
     if ntap > 1 and not cpml_width and _flatten_taps_pays(r, f, geom, c0, c1, edge_rows):
@@ -289,15 +316,13 @@ def born(r, f, dr, q0, q1, src_cell, src_w, rec_cell, rec_w, c0=1.0, c1=1.0,
     _require_cuda(r, "r")
     dev = r.device
     lib = _lib.load()
-    geom = _Geometry(src_cell, src_w, rec_cell, rec_w, dev)
+    geom = _Geometry.get(src_cell, src_w, rec_cell, rec_w, dev)
     n0, n1 = r.shape
     nt, ns, nsrc = f.shape
     nrec, ntap = geom.rec_cell.shape[1], geom.rec_cell.shape[2]
     if tuple(dr.shape) != (n0, n1):
         raise MifwiError("dr must have the shape of r")
-    tops = [c.max() for c in (geom.src_cell, geom.rec_cell) if c.numel()]
-    if tops and int(torch.stack(tops).max()) >= n0 * n1:
-        raise MifwiError("src_cell/rec_cell hold a cell outside the %dx%d grid" % (n0, n1))
+    geom.check_cells(n0 * n1, "%dx%d" % (n0, n1))
     with torch.cuda.device(dev), torch.no_grad():
         plan = AcousticPlan(n0, n1, nt, ns, nsrc, nrec, ntap, float(c0), float(c1), dev.index, 0, 0, int(cpml_width))
         lay = plan.layout

@@ -96,6 +96,28 @@ class _EdgePad(torch.autograd.Function):
         return out, None
 
 
+# (weakref to the caller's location tensor, its version, spacing, pad, n1) -> (cells, weights) on the device.  The reference
+# builds x_s / x_r once and passes them to a new Propagator every iteration (networks.py:5430-5449): the coordinates ->
+# cells conversion (a dozen small launches) and, downstream, the validation of the cells are paid once.  Device tensors
+# only: a host tensor may alias a numpy buffer, which has no version counter.
+_CELLS = []
+
+
+def _cells(loc, spacing, pad, n1, dev):
+    import weakref
+    key = (tuple(spacing), int(pad), int(n1))
+    if loc.is_cuda:
+        for ref, ver, k, out in _CELLS:
+            if ref() is loc and ver == loc._version and k == key:
+                return out
+    cells, w = profiles.cells_truncate(loc.detach(), spacing, pad, n1)
+    out = (cells.to(dev), w.to(dev))
+    if loc.is_cuda:
+        _CELLS[:] = [e for e in _CELLS if e[0]() is not None][-15:]
+        _CELLS.append((weakref.ref(loc), loc._version, key, out))
+    return out
+
+
 @functools.lru_cache(maxsize=32)
 def _sponge(n, width, d, h, dt, device):
     """Damping profile of one axis as a device tensor (a new Propagator is built every iteration,
@@ -189,8 +211,8 @@ class Propagator(torch.nn.Module):
         f = source_amplitudes.to(device=dev, dtype=torch.float32) * (h * h)
         f = _upsample(f, ratio)
         # coordinates -> cells where the coordinates live (no host round trip when they are on the GPU)
-        sc, sw = profiles.cells_truncate(source_locations.detach(), self.spacing, P, n1)
-        rc, rw = profiles.cells_truncate(receiver_locations.detach(), self.spacing, P, n1)
+        sc, sw = _cells(source_locations, self.spacing, P, n1, dev)
+        rc, rw = _cells(receiver_locations, self.spacing, P, n1, dev)
         if self.absorbing == "cpml" and P > 0:
             fpml = float(self.pml_freq) if self.pml_freq is not None else 0.25 / abs(dt) / 5.0
             ab0, ab1 = _cpml_ab(n0, P, dz, dti, vmax, fpml), _cpml_ab(n1, P, dx, dti, vmax, fpml)
