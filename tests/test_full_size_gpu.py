@@ -95,6 +95,40 @@ def test_c2_acoustic_full_grid_vs_oracle(oracle32, ns, nt):
     assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 2e-5
 
 
+@pytest.mark.parametrize("ns,nt", [(2, 200), (29, 100)])
+def test_c2_acoustic_cpml_full_grid_vs_oracle(oracle32, monkeypatch, ns, nt):
+    """BASELINE config 2's grid with `pml_width` as a PML (deepwave's meaning, networks.py:5408-5411): 174x500 + a 20-cell
+    second-order C-PML = 214x540 through the single-launch time loop the plan picks.  With 29 shots (8 slabs per shot)
+    the two edge slabs' planes leave LDS room for only a few of the layer's arrays - the mixed placement (pml_place) -
+    against oracle/acoustic_cpml.c: traces bit for bit, gradients <= 2e-5; and the same with every layer array kept in
+    global memory (MIFWI_AC_PML_LDS=0): identical bits."""
+    from physicsbasedfwi2_amd.acoustic import AcousticPlan
+    from oracle import helpers as H
+    from test_acoustic_gpu import _cpml_case, _run_cpml
+    c = _cpml_case(seed=53, n0=174, n1=500, w=20, nt=nt, ns=ns, nrec=500)
+    c["sc"], c["sw"] = H.cell_taps(np.full((ns, 1), 20), 20 + np.linspace(0, 499, ns).astype(int)[:, None], 540)
+    c["rc"], c["rw"] = H.cell_taps(np.full((ns, 500), 20), np.tile(20 + np.arange(500), (ns, 1)), 540)
+    pl = AcousticPlan(214, 540, nt, ns, 1, 500, 1, 1.0, 1.0, 0, 0, 0, 20)
+    assert pl.cluster_slabs() >= 3
+    pl.close()
+    geo = (c["sc"], c["sw"], c["rc"], c["rw"])
+    rec_o, G_o = oracle32.acoustic_cpml_forward(c["r"], c["ab0"], c["ab1"], c["f"], *geo, c["c0"], c["c1"], save=True)
+    g = np.sign(rec_o).astype(np.float32)
+    gr_o, gf_o = oracle32.acoustic_cpml_backward(c["r"], c["ab0"], c["ab1"], *geo, g, G_o, c["c0"], c["c1"])
+    outs = []
+    for lds in ("1", "0"):
+        monkeypatch.setenv("MIFWI_AC_PML_LDS", lds)
+        r, f, rec = _run_cpml(c)
+        rec_h = rec.detach().cpu().numpy()
+        assert all(np.abs(rec_o[:, s]).max() > 0 for s in range(ns))
+        assert np.abs(rec_h - rec_o).max() == 0.0
+        rec.backward(torch.tensor(g, device=DEV))
+        assert rel_l2(r.grad.cpu().numpy(), gr_o) <= 2e-5
+        assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 2e-5
+        outs.append((r.grad.clone(), f.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def _seam_case(ns=2, nt=40, nz=1000, nx=3000, fw=10):
     """BASELINE config 5's grid and set-up (networks.py:9638, 9792-9811: 1000x3000, h = 30 m, dt = 2.5 ms,
     FREE_SURF = 1, C-PML on the other three sides) with a time axis the oracle finishes in seconds.  In 40
