@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define MIFWI_VERSION_MAJOR 0
-#define MIFWI_VERSION_MINOR 6   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format; 4: mifwi_fallback_count; 5: mifwi_agent_handoff_count, mifwi_slow_handoff_count; acoustic desc gained cpml_width, layout state_elems; 6: mifwi_elastic_materials, mifwi_elastic_materials_vjp */
+#define MIFWI_VERSION_MINOR 6   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format; 4: mifwi_fallback_count; 5: mifwi_agent_handoff_count, mifwi_slow_handoff_count; acoustic desc gained cpml_width, layout state_elems; 6: mifwi_elastic_materials(_vjp), mifwi_acoustic_coefficients(_vjp) */
 
 enum {
     MIFWI_OK = 0,
@@ -329,6 +329,15 @@ int mifwi_elastic_materials(int device, const float *vp, const float *vs, const 
 int mifwi_elastic_materials_vjp(int device, const float *vp, const float *vs, const float *rho, const float *grad_out,
                                 float *grad_vp, float *grad_vs, float *grad_rho, int32_t nz, int32_t nx,
                                 float dt_over_h, int32_t free_surface, void *stream);
+
+/* vp [nz][nx] (m/s) -> r [nz + 2 pad][nx + 2 pad] = (vp dt/h)^2 with the model edge-replicated into the absorbing
+ * layer: the coefficient of the scalar scheme as the deepwave-shaped call protocol needs it per call
+ * (deepwave.scalar.Propagator({'vp': model}, dx), models/networks.py:5408-5411, 5449), and its chain rule
+ * (grad_r [nz + 2 pad][nx + 2 pad] -> grad_vp [nz][nx]; the layer's cells folded into the edge cells in a fixed order). */
+int mifwi_acoustic_coefficients(int device, const float *vp, float *r, int32_t nz, int32_t nx, int32_t pad,
+                                float dt_over_h, void *stream);
+int mifwi_acoustic_coefficients_vjp(int device, const float *vp, const float *grad_r, float *grad_vp, int32_t nz,
+                                    int32_t nx, int32_t pad, float dt_over_h, void *stream);
 
 #ifdef __cplusplus
 }

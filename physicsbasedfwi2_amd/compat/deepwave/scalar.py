@@ -118,6 +118,41 @@ def _cells(loc, spacing, pad, n1, dev):
     return out
 
 
+class _Coefficients(torch.autograd.Function):
+    """r = (edge-replicated vp * dt / h) ** 2 on the padded grid and its chain rule, one launch each way
+    (csrc/mifwi_materials.hip: mifwi_acoustic_coefficients) instead of pad, scale, square and their autograd nodes
+    (~20 small launches per gradient pass).  The layer's gradient is folded into the edge cells in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, vp, pad, scale):
+        from ... import _lib
+        from ...acoustic import _stream
+        dev = vp.device
+        nz, nx = vp.shape
+        v = vp.detach().contiguous()
+        r = torch.empty((nz + 2 * pad, nx + 2 * pad), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mifwi_acoustic_coefficients(dev.index or 0, _lib.ptr(v), _lib.ptr(r), nz, nx, int(pad),
+                                                               float(scale), _stream()))
+        ctx.save_for_backward(v)
+        ctx.pad, ctx.scale = int(pad), float(scale)
+        return r
+
+    @staticmethod
+    def backward(ctx, g):
+        from ... import _lib
+        from ...acoustic import _stream
+        (v,) = ctx.saved_tensors
+        dev = v.device
+        nz, nx = v.shape
+        g = g.to(dtype=torch.float32).contiguous()
+        gv = torch.empty_like(v)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mifwi_acoustic_coefficients_vjp(dev.index or 0, _lib.ptr(v), _lib.ptr(g), _lib.ptr(gv), nz, nx,
+                                                                   ctx.pad, ctx.scale, _stream()))
+        return gv, None, None
+
+
 @functools.lru_cache(maxsize=32)
 def _sponge(n, width, d, h, dt, device):
     """Damping profile of one axis as a device tensor (a new Propagator is built every iteration,
@@ -205,9 +240,11 @@ class Propagator(torch.nn.Module):
         ratio = max(1, int(math.ceil(abs(dt) / dt_max - 1e-9)))
         dti = dt / ratio
 
-        vp_pad = _EdgePad.apply(vp.float(), P)
-        n0, n1 = vp_pad.shape
-        r = (vp_pad * (dti / h)) ** 2
+        n0, n1 = vp.shape[0] + 2 * P, vp.shape[1] + 2 * P
+        if vp.dtype == torch.float32:
+            r = _Coefficients.apply(vp, P, dti / h)
+        else:
+            r = (_EdgePad.apply(vp.float(), P) * (dti / h)) ** 2
         f = source_amplitudes.to(device=dev, dtype=torch.float32) * (h * h)
         f = _upsample(f, ratio)
         # coordinates -> cells where the coordinates live (no host round trip when they are on the GPU)

@@ -1,4 +1,5 @@
-// (Vp, Vs, rho) -> the five staggered material planes of the elastic kernels, and the chain rule back (libmifwi, gfx950).
+// Model parameterisations on the device (libmifwi, gfx950): (Vp, Vs, rho) -> the five staggered material planes of the
+// elastic kernels, vp -> the scalar scheme's coefficient r on the padded grid, and their chain rules back.
 // What DENISE does inside `set_model` / its model-averaging step before a forward run (the reference hands it Vp, Vs, rho:
 // models/networks.py:7698-7712, 9790-9800) and undoes on the way back when `get_fwi_gradients` returns gradients with
 // respect to Vp, Vs, rho (7802-7806): here one launch each way instead of the ~60 + ~100 elementwise launches of the torch
@@ -127,9 +128,63 @@ __global__ __launch_bounds__(kMT) void materials_vjp(const float *vp, const floa
     grho[k] = drho + dlam * p * p + dmu * q * q;
 }
 
+// ---- scalar scheme: vp [nz][nx] -> r [nz + 2 pad][nx + 2 pad] = (vp dt / h)^2, the model replicated into the absorbing
+// layer (what the deepwave-shaped shim computes per call: compat/deepwave/scalar.py) ------------------------------------
+__global__ __launch_bounds__(kMT) void coef_fwd(const float *vp, float *r, int nz, int nx, int pad, float c)
+{
+    const int n1 = nx + 2 * pad;
+    const long long k = (long long)blockIdx.x * kMT + threadIdx.x, n = (long long)(nz + 2 * pad) * n1;
+    if (k >= n) return;
+    const int a = (int)(k / n1), b = (int)(k - (long long)a * n1);
+    const int i = min(max(a - pad, 0), nz - 1), j = min(max(b - pad, 0), nx - 1);
+    const float x = vp[(long long)i * nx + j] * c;
+    r[k] = x * x;
+}
+// one thread per model cell: the cells of the layer that replicate it are folded in here, in a fixed order
+__global__ __launch_bounds__(kMT) void coef_vjp(const float *vp, const float *gr, float *gvp, int nz, int nx, int pad, float c)
+{
+    const long long k = (long long)blockIdx.x * kMT + threadIdx.x;
+    if (k >= (long long)nz * nx) return;
+    const int i = (int)(k / nx), j = (int)(k - (long long)i * nx);
+    const int n0 = nz + 2 * pad, n1 = nx + 2 * pad;
+    const int a0 = i == 0 ? 0 : i + pad, a1 = i == nz - 1 ? n0 - 1 : i + pad;
+    const int b0 = j == 0 ? 0 : j + pad, b1 = j == nx - 1 ? n1 - 1 : j + pad;
+    float sum = 0.f;
+    for (int a = a0; a <= a1; ++a)
+        for (int b = b0; b <= b1; ++b) sum += gr[(long long)a * n1 + b];
+    const float x = vp[k] * c;
+    gvp[k] = sum * (2.0f * x) * c;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mifwi_acoustic_coefficients(int device, const float *vp, float *r, int32_t nz, int32_t nx, int32_t pad, float dt_over_h,
+                                void *stream)
+{
+    if (!vp || !r || nz < 1 || nx < 1 || pad < 0) return mifwi::fail(MIFWI_EINVAL, "mifwi_acoustic_coefficients: bad argument");
+    MIFWI_HIP_TRY(hipSetDevice(device));
+    const long long n = (long long)(nz + 2 * pad) * (nx + 2 * pad);
+    hipLaunchKernelGGL(coef_fwd, dim3((unsigned)((n + kMT - 1) / kMT)), dim3(kMT), 0, (hipStream_t)stream, vp, r, nz, nx, pad,
+                       dt_over_h);
+    MIFWI_HIP_TRY(hipGetLastError());
+    return MIFWI_OK;
+}
+
+int mifwi_acoustic_coefficients_vjp(int device, const float *vp, const float *grad_r, float *grad_vp, int32_t nz, int32_t nx,
+                                    int32_t pad, float dt_over_h, void *stream)
+{
+    if (!vp || !grad_r || !grad_vp || nz < 1 || nx < 1 || pad < 0)
+        return mifwi::fail(MIFWI_EINVAL, "mifwi_acoustic_coefficients_vjp: bad argument");
+    MIFWI_HIP_TRY(hipSetDevice(device));
+    const long long n = (long long)nz * nx;
+    hipLaunchKernelGGL(coef_vjp, dim3((unsigned)((n + kMT - 1) / kMT)), dim3(kMT), 0, (hipStream_t)stream, vp, grad_r, grad_vp, nz,
+                       nx, pad, dt_over_h);
+    MIFWI_HIP_TRY(hipGetLastError());
+    return MIFWI_OK;
+}
+
 
 int mifwi_elastic_materials(int device, const float *vp, const float *vs, const float *rho, float *out, int32_t nz, int32_t nx,
                             float dt_over_h, int32_t free_surface, void *stream)

@@ -64,3 +64,26 @@ def test_fused_materials_directional_derivative():
     (elastic.staggered_materials(*gpu, dt, h, free_surface=True) * c.float().to(dev)).sum().backward()
     an = sum(float((a.grad.double().cpu() * b).sum()) for a, b in zip(gpu, d))
     assert abs(an - fd) <= 2e-5 * abs(fd), (an, fd)
+
+
+@pytest.mark.parametrize("nz,nx,pad", [(174, 500, 20), (33, 47, 6), (5, 3, 0), (1, 7, 4)])
+def test_fused_acoustic_coefficients_match_the_torch_expression(nz, nx, pad):
+    """vp -> r = (edge-replicated vp dt/h)^2 of the deepwave-shaped shim: the fused launch against pad, scale, square;
+    the chain rule (layer folded into the edge cells) against autograd's, to the round-off of another summation order."""
+    from physicsbasedfwi2_amd.compat.deepwave import scalar
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(8)
+    vp0 = torch.tensor(1500.0 + 3000.0 * rng.random((nz, nx)), dtype=torch.float32, device=dev)
+    c = 1e-3 / 10.0
+    a = vp0.clone().requires_grad_(True)
+    b = vp0.clone().requires_grad_(True)
+    r = scalar._Coefficients.apply(a, pad, c)
+    ref = (scalar._EdgePad.apply(b, pad) * c) ** 2
+    assert r.shape == (nz + 2 * pad, nx + 2 * pad) and torch.equal(r, ref)
+    g = torch.tensor(rng.standard_normal(tuple(r.shape)), dtype=torch.float32, device=dev)
+    r.backward(g)
+    ref.backward(g)
+    assert float((a.grad - b.grad).norm() / b.grad.norm()) <= 1e-6
+    a2 = vp0.clone().requires_grad_(True)
+    scalar._Coefficients.apply(a2, pad, c).backward(g)
+    assert torch.equal(a2.grad, a.grad)
