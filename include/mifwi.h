@@ -224,7 +224,10 @@ typedef struct {
 /* kernel_flags: forward / adjoint as ONE launch for the whole time loop (LDS-resident slabs), or - on grids that do not
    fit - V+S (S^T+V^T) fused into one launch per step; neither bit = one launch per half step */
 enum { MIFWI_EL_KERNEL_FWD_SINGLE_LAUNCH = 1, MIFWI_EL_KERNEL_ADJ_SINGLE_LAUNCH = 2, MIFWI_EL_KERNEL_FWD_FUSED_STEP = 4,
-       MIFWI_EL_KERNEL_ADJ_FUSED_STEP = 8 };
+       MIFWI_EL_KERNEL_ADJ_FUSED_STEP = 8,
+       /* the single-launch loop takes the outer cells of its x-stencils from the neighbouring lanes (DPP wave shifts)
+          instead of misaligned LDS reads: chosen when the plan's deal of groups to lanes allows it */
+       MIFWI_EL_KERNEL_FWD_LANE_HALO = 16, MIFWI_EL_KERNEL_ADJ_LANE_HALO = 32 };
 
 typedef struct mifwi_elastic_plan mifwi_elastic_plan;
 

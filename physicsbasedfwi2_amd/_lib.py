@@ -53,6 +53,7 @@ class ElasticLayout(ctypes.Structure):
 
 
 EL_KERNEL_FWD_SINGLE_LAUNCH, EL_KERNEL_ADJ_SINGLE_LAUNCH, EL_KERNEL_FWD_FUSED_STEP, EL_KERNEL_ADJ_FUSED_STEP = 1, 2, 4, 8
+EL_KERNEL_FWD_LANE_HALO, EL_KERNEL_ADJ_LANE_HALO = 16, 32
 SNAPSHOT_F32, SNAPSHOT_BF16 = 0, 1
 _P = ctypes.c_void_p
 

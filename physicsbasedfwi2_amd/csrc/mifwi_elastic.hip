@@ -1142,6 +1142,7 @@ struct mifwi_elastic_plan {
     long long psi_elems;  // psix+psiz rounded up to 64
     // cluster path (LDS-resident time loop); 0 when a shot does not fit
     int cluster, NW, PL, fwd_PL, adj_PL, cl_shots, cl_lds, cl_ng;
+    int cl_xh, adj_xh;           // single-launch kernels fetch the x-stencils' outer cells from the neighbouring lanes (ec_xhalo)
     // adjoint cluster kernel (its own slab count: different LDS footprint)
     int cl_adj, adj_NW, adj_shots, adj_lds, adj_ng, adj_zrows;
     long long xbuf_elems, list_elems, xcc_elems;
@@ -1201,6 +1202,7 @@ void launch_s(const mifwi_elastic_plan *pl, const ElParams &p0, int nshot, hipSt
 void el_cluster_setup(mifwi_elastic_plan *pl)
 {
     pl->cluster = 0; pl->NW = 0; pl->PL = 4 * (pl->ng + 2); pl->cl_shots = 0;
+    pl->cl_xh = 0; pl->adj_xh = 0;
     pl->adj_PL = pl->PL; pl->fwd_PL = pl->PL;
     // LDS row pitch: with the dense group -> thread deal (lane v <-> group v of the slab, row-major) a wave's 64 lanes
     // cross a row break almost always; the 16-byte slot of lane v stays congruent to v (mod 16) across the break - and
@@ -1249,11 +1251,24 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
             pl->fwd_PL = PLq;
         }
     }
+    // every slab's deal must suit the lane-shift form of the x-halo (ec_xhalo_deal_ok); MIFWI_EL_XHALO=0: plain LDS reads
+    auto xhalo_ok = [&](int nw, int ngq) {
+        if (env_int("MIFWI_EL_XHALO", 1) == 0) return 0;
+        for (int w = 0; w < nw; ++w) {
+            int r0, R;
+            ec_slab_rows(pl->d.nz, nw, w, r0, R);
+            if (!ec_xhalo_deal_ok(R, pl->ng, ngq * kEcThreads)) return 0;
+        }
+        return 1;
+    };
+    pl->cl_xh = pl->cluster ? xhalo_ok(pl->NW, pl->cl_ng) : 0;
     if (pl->cluster) {
         for (const void *fn : {(const void *)el_cluster_fwd<false, 1, false>, (const void *)el_cluster_fwd<true, 1, false>,
                                (const void *)el_cluster_fwd<false, 2, false>, (const void *)el_cluster_fwd<true, 2, false>,
                                (const void *)el_cluster_fwd<false, 1, true>, (const void *)el_cluster_fwd<true, 1, true>,
-                               (const void *)el_cluster_fwd<false, 2, true>, (const void *)el_cluster_fwd<true, 2, true>})
+                               (const void *)el_cluster_fwd<false, 2, true>, (const void *)el_cluster_fwd<true, 2, true>,
+                               (const void *)el_cluster_fwd<false, 1, false, true>, (const void *)el_cluster_fwd<true, 1, false, true>,
+                               (const void *)el_cluster_fwd<false, 2, false, true>, (const void *)el_cluster_fwd<true, 2, false, true>})
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mifwi::kClusterLdsLimit) != hipSuccess) {
                 (void)hipGetLastError();       // not sticky: fall back to one launch per half step
                 pl->cluster = 0;
@@ -1291,9 +1306,11 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
                 pl->adj_ng = mifwi::ceil_div(rows * pl->ng, kEcThreads); pl->adj_zrows = zmax;
             }
         }
+        pl->adj_xh = pl->cl_adj ? xhalo_ok(pl->adj_NW, pl->adj_ng) : 0;
         if (pl->cl_adj)
             for (const void *fn : {(const void *)el_cluster_adj<1, false>, (const void *)el_cluster_adj<2, false>,
-                                   (const void *)el_cluster_adj<1, true>, (const void *)el_cluster_adj<2, true>})
+                                   (const void *)el_cluster_adj<1, true>, (const void *)el_cluster_adj<2, true>,
+                                   (const void *)el_cluster_adj<1, false, true>, (const void *)el_cluster_adj<2, false, true>})
                 if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kEaLdsLimit) != hipSuccess) {
                     (void)hipGetLastError();
                     pl->cl_adj = 0;
@@ -1329,10 +1346,16 @@ int el_cluster_run(const mifwi_elastic_plan *pl, EcParams c, float *xbuf, hipStr
         c.shot0 = s0;
         c.shot1 = std::min(pl->d.nshot, s0 + pl->cl_shots);
         const int nsl8 = mifwi::ceil_div(c.shot1 - s0, 8);
-        if (pl->cl_ng == 1)
-            hipLaunchKernelGGL((el_cluster_fwd<SAVE, 1, AG>), dim3(8 * pl->NW * nsl8), dim3(kEcThreads), pl->cl_lds, st, c);
-        else
-            hipLaunchKernelGGL((el_cluster_fwd<SAVE, 2, AG>), dim3(8 * pl->NW * nsl8), dim3(kEcThreads), pl->cl_lds, st, c);
+        const dim3 grid(8 * pl->NW * nsl8), block(kEcThreads);
+        if constexpr (!AG) {                 // (the agent-scope tier keeps the plain reads: one variant less to build)
+            if (pl->cl_xh) {
+                if (pl->cl_ng == 1) hipLaunchKernelGGL((el_cluster_fwd<SAVE, 1, false, true>), grid, block, pl->cl_lds, st, c);
+                else hipLaunchKernelGGL((el_cluster_fwd<SAVE, 2, false, true>), grid, block, pl->cl_lds, st, c);
+                continue;
+            }
+        }
+        if (pl->cl_ng == 1) hipLaunchKernelGGL((el_cluster_fwd<SAVE, 1, AG>), grid, block, pl->cl_lds, st, c);
+        else hipLaunchKernelGGL((el_cluster_fwd<SAVE, 2, AG>), grid, block, pl->cl_lds, st, c);
     }
     MIFWI_HIP_TRY(hipGetLastError());
     int err[4] = {0, 0, 0, 0};
@@ -1551,7 +1574,9 @@ int mifwi_elastic_plan_layout(const mifwi_elastic_plan *pl, mifwi_elastic_layout
     out->snap_step_elems = pl->snap_shot * pl->d.nshot;
     out->snapshot_format = pl->snap_bf16 ? MIFWI_SNAPSHOT_BF16 : MIFWI_SNAPSHOT_F32;
     out->kernel_flags = (pl->cluster ? MIFWI_EL_KERNEL_FWD_SINGLE_LAUNCH : 0) | (pl->cl_adj ? MIFWI_EL_KERNEL_ADJ_SINGLE_LAUNCH : 0) |
-                        (pl->fused ? MIFWI_EL_KERNEL_FWD_FUSED_STEP : 0) | (pl->fused_adj ? MIFWI_EL_KERNEL_ADJ_FUSED_STEP : 0);
+                        (pl->fused ? MIFWI_EL_KERNEL_FWD_FUSED_STEP : 0) | (pl->fused_adj ? MIFWI_EL_KERNEL_ADJ_FUSED_STEP : 0) |
+                        (pl->cluster && pl->cl_xh ? MIFWI_EL_KERNEL_FWD_LANE_HALO : 0) |
+                        (pl->cl_adj && pl->adj_xh ? MIFWI_EL_KERNEL_ADJ_LANE_HALO : 0);
     const long long psi = pl->psi_elems;
     const long long bbox = mifwi::round_up64(4LL * pl->d.nshot, 64);
     out->state_elems = pl->fields_elems + psi;
@@ -1831,7 +1856,11 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
                 c.shot0 = s0;
                 c.shot1 = std::min(d.nshot, s0 + pl->adj_shots);
                 const dim3 grid(8 * pl->adj_NW * mifwi::ceil_div(c.shot1 - s0, 8));
-                if (pl->adj_ng == 1 && !agent) hipLaunchKernelGGL((el_cluster_adj<1, false>), grid, dim3(kEcThreads), pl->adj_lds, st, c);
+                if (!agent && pl->adj_xh) {
+                    if (pl->adj_ng == 1) hipLaunchKernelGGL((el_cluster_adj<1, false, true>), grid, dim3(kEcThreads), pl->adj_lds, st, c);
+                    else hipLaunchKernelGGL((el_cluster_adj<2, false, true>), grid, dim3(kEcThreads), pl->adj_lds, st, c);
+                }
+                else if (pl->adj_ng == 1 && !agent) hipLaunchKernelGGL((el_cluster_adj<1, false>), grid, dim3(kEcThreads), pl->adj_lds, st, c);
                 else if (pl->adj_ng == 1) hipLaunchKernelGGL((el_cluster_adj<1, true>), grid, dim3(kEcThreads), pl->adj_lds, st, c);
                 else if (!agent) hipLaunchKernelGGL((el_cluster_adj<2, false>), grid, dim3(kEcThreads), pl->adj_lds, st, c);
                 else hipLaunchKernelGGL((el_cluster_adj<2, true>), grid, dim3(kEcThreads), pl->adj_lds, st, c);

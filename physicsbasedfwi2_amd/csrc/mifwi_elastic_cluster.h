@@ -68,7 +68,7 @@ struct EcParams {
 #define EC_LAGGARD() do { } while (0)
 #endif
 
-__device__ __forceinline__ void ec_slab_rows(int nz, int NW, int w, int &r0, int &rows)
+__host__ __device__ __forceinline__ void ec_slab_rows(int nz, int NW, int w, int &r0, int &rows)
 {
     const int base = nz / NW, rem = nz - base * NW;
     rows = base + (w < rem ? 1 : 0);
@@ -330,7 +330,7 @@ struct EcHandoff {
 #define EA_MATS_AHEAD_C 1
 #endif
 struct EcSlot { int lrw, g, cls; };
-__device__ __forceinline__ EcSlot ec_slot(int v, int R, int ng, int slots)       // slots = NG * kEcThreads >= R * ng
+__host__ __device__ __forceinline__ EcSlot ec_slot(int v, int R, int ng, int slots)       // slots = NG * kEcThreads >= R * ng
 {
     EcSlot s;
     s.lrw = 0; s.g = 0; s.cls = 0;
@@ -356,8 +356,70 @@ __device__ __forceinline__ EcSlot ec_slot(int v, int R, int ng, int slots)      
     return s;
 }
 
+// The x-stencils of a group of four cells reach two cells into the groups left and right of it.  Those cells sit in the
+// registers of the neighbouring LANES (the deal is row-major: consecutive lanes hold consecutive groups), which have just
+// read them from LDS as part of their own group: a DPP wave shift fetches them instead of two 8-byte LDS reads at
+// misaligned offsets per field (two lanes per bank by construction; together with the row breaks of the 16-byte reads the
+// LDS pipe spent more cycles on bank conflicts than on accesses: SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 1.6 forward,
+// 1.3 adjoint).  A lane at the end of a grid row EXPORTS zeros (what the planes' side pads hold) to the lane that starts
+// the next row; a lane without an active lane of its class next to it (wave ends, the ends of a class's lanes) keeps the
+// value of ONE LDS read per field - the other lanes of that read all fetch one address, a conflict-free broadcast - as
+// the DPP move's `old` operand.  Straight-line code: a branch around it costs more than the reads it saves (measured), so
+// the kernels come in two variants (template XH) and the host launches XH = true only for deals in which no lane needs
+// two reads and no two classes that run in one pass meet inside a wave (ec_xhalo_deal_ok).
+// ec_nb: kNbL / kNbR = the lane below / above holds a group of the same class; kNbFirst / kNbLast = first / last group of
+// a grid row.
+constexpr int kNbL = 1, kNbR = 2, kNbFirst = 4, kNbLast = 8;
+__host__ __device__ __forceinline__ int ec_nb(int v, int R, int ng, int slots)
+{
+    const EcSlot s = ec_slot(v, R, ng, slots);
+    if (s.cls == 0) return 0;
+    const int lane = v & 63;                          // (kEcThreads is a multiple of 64)
+    const bool lv = lane != 0 && ec_slot(v - 1, R, ng, slots).cls == s.cls;
+    const bool rv = lane != 63 && ec_slot(v + 1, R, ng, slots).cls == s.cls;
+    return (lv ? kNbL : 0) | (rv ? kNbR : 0) | (s.g == 0 ? kNbFirst : 0) | (s.g == ng - 1 ? kNbLast : 0);
+}
+// host: may the XH variants run the deal of a slab of R rows?
+inline bool ec_xhalo_deal_ok(int R, int ng, int slots)
+{
+    for (int v = 0; v < slots; ++v) {
+        const EcSlot s = ec_slot(v, R, ng, slots);
+        if (s.cls == 0) continue;
+        const int nb = ec_nb(v, R, ng, slots), lane = v & 63;
+        if (!(nb & (kNbL | kNbR))) return false;                               // a lane that would need two reads
+        // boundary (2) and late-interior (3) groups run in ONE pass of the adjoint's phase B: side by side in a wave the
+        // shift would hand a lane the cells of another row
+        const int lc = lane != 0 ? ec_slot(v - 1, R, ng, slots).cls : 0;
+        if (lc >= 2 && s.cls >= 2 && lc != s.cls) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ float ec_lane_below(float old, float x)          // x of lane - 1 (wave_shr:1); `old` without one
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float ec_lane_above(float old, float x)          // x of lane + 1 (wave_shl:1)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), 0x130, 0xf, 0xf, false));
+}
+// the two cells left (L) and right (R) of a group (own four cells c, plane row at q); dummy = any 8-byte aligned LDS address
+template <bool XH>
+__device__ __forceinline__ void ec_xhalo(const float *q, const float4 &c, const int nb, const float *dummy, float2 &L, float2 &R)
+{
+    if (!XH) {
+        L = ld2(q - 2); R = ld2(q + 4);
+        return;
+    }
+    const float2 rd = ld2(!(nb & kNbL) ? q - 2 : !(nb & kNbR) ? q + 4 : dummy);
+    const float ez = (nb & kNbLast) ? 0.f : c.z, ew = (nb & kNbLast) ? 0.f : c.w;
+    const float ex = (nb & kNbFirst) ? 0.f : c.x, ey = (nb & kNbFirst) ? 0.f : c.y;
+    L.x = ec_lane_below(rd.x, ez); L.y = ec_lane_below(rd.y, ew);
+    R.x = ec_lane_above(rd.x, ex); R.y = ec_lane_above(rd.y, ey);
+}
+
 struct EcGroup {
     int cls;                                      // 0: none, 1: interior rows of the slab, 2: boundary rows (stencils reach the halo)
+    int nb;                                       // ec_nb: how the x-neighbours' cells reach this lane
     int g, j;                                     // group in the row, grid row
     int lo;                                       // LDS float offset of the group inside a field plane
     unsigned gcb;                                 // byte offset of the group inside a [nz][gp] plane (snapshots, materials)
@@ -410,21 +472,23 @@ struct EcCtx {
 };
 
 // V update (reads stresses from LDS, writes the group's velocities in place)
-template <bool EDGE>   // EDGE: the group may sit on grid rows 0/1 (free-surface mirroring); interior rows never do
+template <bool EDGE, bool XH>   // EDGE: the group may sit on grid rows 0/1 (free-surface mirroring); interior rows never do
 __device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const int lo, const int jq, float4 &S4, float4 &S5,
                                             float4 &o0, float4 &o1)
 {
     const int PL = ec_su(c.PL);
     const FdK K = c.K;
     const float *sxx = c.Lf[F_SXX] + lo, *szz = c.Lf[F_SZZ] + lo, *sxz = c.Lf[F_SXZ] + lo;
+    const int nb = XH ? ec_opaque(G.nb) : 0;
     float4 cxx = ld4(sxx);
-    float2 Lxx = ld2(sxx - 2), Rxx = ld2(sxx + 4);
     float4 a2 = ld4(sxz);
-    float2 Lxz = ld2(sxz - 2), Rxz = ld2(sxz + 4);
+    float2 Lxx, Rxx, Lxz, Rxz;
     float4 a0 = ld4(sxz - 2 * PL), a1 = ld4(sxz - PL);
     float4 a3 = ld4(sxz + PL);
     float4 b0 = ld4(szz - PL);
     float4 b1 = ld4(szz), b2 = ld4(szz + PL), b3 = ld4(szz + 2 * PL);
+    ec_xhalo<XH>(sxx, cxx, nb, c.Lf[0], Lxx, Rxx);
+    ec_xhalo<XH>(sxz, a2, nb, c.Lf[0], Lxz, Rxz);
 #ifdef EC_PIN
     ec_pin(Lxx, Rxx, Lxz, Rxz);
     ec_pin(cxx, a2, a0, a1);
@@ -484,19 +548,21 @@ __device__ __forceinline__ void ec_update_v(EcGroup &G, const EcCtx &c, const in
 
 // S update (reads velocities from LDS, writes the group's stresses in place); `amp` = source term
 // of this step for the group's cells (0 where there is none)
-template <bool EDGE>
+template <bool EDGE, bool XH>
 __device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const int lo, const int jq, const float4 &amp, float4 &S1,
                                             float4 &S2, float4 &S3, float4 &o0, float4 &o1)
 {
     const int PL = ec_su(c.PL);
     const FdK K = c.K;
     const float *vx = c.Lf[F_VX] + lo, *vz = c.Lf[F_VZ] + lo;
+    const int nb = XH ? ec_opaque(G.nb) : 0;
     float4 b1 = ld4(vx);
-    float2 Lvx = ld2(vx - 2), Rvx = ld2(vx + 4);
     float4 a2 = ld4(vz);
-    float2 Lvz = ld2(vz - 2), Rvz = ld2(vz + 4);
+    float2 Lvx, Rvx, Lvz, Rvz;
     float4 a0 = ld4(vz - 2 * PL), a1 = ld4(vz - PL), a3 = ld4(vz + PL);
     float4 b0 = ld4(vx - PL), b2 = ld4(vx + PL), b3 = ld4(vx + 2 * PL);
+    ec_xhalo<XH>(vx, b1, nb, c.Lf[0], Lvx, Rvx);
+    ec_xhalo<XH>(vz, a2, nb, c.Lf[0], Lvz, Rvz);
 #ifdef EC_PIN
     ec_pin(Lvx, Rvx, Lvz, Rvz);
     ec_pin(b1, a2, a0, a1);
@@ -553,7 +619,7 @@ __device__ __forceinline__ void ec_update_s(EcGroup &G, const EcCtx &c, const in
     st4(c.Lf[F_SXZ] + lo, o1);
 }
 
-template <bool SAVE, int NG, bool AG>
+template <bool SAVE, int NG, bool AG, bool XH = false>
 __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -597,6 +663,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         g.g = sl.g;
         g.j = r0 + lrw;
         g.cls = sl.cls;                      // 1, 3: stencils stay inside the own rows
+        g.nb = XH ? ec_nb(t + q * kEcThreads, R, p.ng, NG * kEcThreads) : 0;
         g.lo = (lrw + 2) * PL + 4 + 4 * g.g;
         const unsigned gcc = (unsigned)g.j * p.gp + 4 * g.g;
         g.gcb = 4u * gcc;
@@ -717,10 +784,10 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         const int lo = ec_opaque(g.lo);
         if (edge) {
             const int jq = ec_opaque(g.j);
-            ec_update_v<true>(g, c, lo, jq, S4, S5, o0, o1);
+            ec_update_v<true, XH>(g, c, lo, jq, S4, S5, o0, o1);
             if (do_x && !(kDbg(p) & 16)) X.template publish<AG>(jq - r0, ec_opaque(g.g), 0, (unsigned)(2 * it + 1), it & 1, o0, o1);
         } else {
-            ec_update_v<false>(g, c, lo, 2, S4, S5, o0, o1);
+            ec_update_v<false, XH>(g, c, lo, 2, S4, S5, o0, o1);
         }
         if (SAVE && !(kDbg(p) & 2)) {
             float *Sn = S_shot + (long long)(n - p.s_first) * p.s_step;
@@ -734,10 +801,10 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_fwd(const EcParams p)
         const float4 amp = source_amp(g, q, n);
         if (edge) {
             const int jq = ec_opaque(g.j);
-            ec_update_s<true>(g, c, lo, jq, amp, S1, S2, S3, o0, o1);
+            ec_update_s<true, XH>(g, c, lo, jq, amp, S1, S2, S3, o0, o1);
             if (do_x && !(kDbg(p) & 16)) X.template publish<AG>(jq - r0, ec_opaque(g.g), 1, (unsigned)(2 * it + 2), it & 1, o0, o1);
         } else {
-            ec_update_s<false>(g, c, lo, 2, amp, S1, S2, S3, o0, o1);
+            ec_update_s<false, XH>(g, c, lo, 2, amp, S1, S2, S3, o0, o1);
         }
         if (SAVE && !(kDbg(p) & 2)) {
             float *Sn = S_shot + (long long)(n - p.s_first) * p.s_step;
@@ -956,6 +1023,7 @@ __global__ void ec_build_slab_lists(const int *rec_cell, int nrec, int nz, int n
 
 struct EaGroup {
     int cls;                                      // 0: none, 1: interior rows of the slab, 2: boundary rows
+    int nb;                                       // ec_nb: how the x-neighbours' cells reach this lane
     int g, j, lo;                                 // group in the row, grid row, LDS float offset inside a plane
     int xsl, zsl;                                 // LDS float offset of the group's psi-bar slot, or -1
     float4 bxx, bzz, bxz, vx, vz;                 // adjoint fields
@@ -965,7 +1033,7 @@ struct EaGroup {
     float src_wt;
 };
 
-template <int NG, bool AG>
+template <int NG, bool AG, bool XH = false>
 __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1018,6 +1086,7 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         g.j = r0 + lrw;
         g.lo = (lrw + 2) * PL + 4 + 4 * g.g;
         g.cls = sl.cls;
+        g.nb = XH ? ec_nb(t + q * kEcThreads, R, p.ng, NG * kEcThreads) : 0;
         g.bxx = g.bzz = g.bxz = g.vx = g.vz = zero4;
         g.a0 = g.a1 = g.a2 = g.a3 = g.a4 = zero4;
         g.S1 = g.S2 = g.S3 = g.S4 = g.S5 = zero4;
@@ -1240,12 +1309,14 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         const int fsz = ec_su(fsz_), PL = ec_su(PL_);
         const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g);
         const float *E1 = pln + lo, *E2 = pln + fsz + lo, *E3 = pln + 2 * fsz + lo, *E4 = pln + 3 * fsz + lo;
+        const int nb = XH ? ec_opaque(g.nb) : 0;
         const float4 c1 = ld4(E1);
-        const float2 L1 = ld2(E1 - 2), R1 = ld2(E1 + 4);
         const float4 c4 = ld4(E4);
-        const float2 L4 = ld2(E4 - 2), R4 = ld2(E4 + 4);
         const float4 t0 = ld4(E3 - 2 * PL), t1 = ld4(E3 - PL), t2 = ld4(E3), t3 = ld4(E3 + PL);
         const float4 u0 = ld4(E2 - PL), u1 = ld4(E2), u2 = ld4(E2 + PL), u3 = ld4(E2 + 2 * PL);
+        float2 L1, R1, L4, R4;
+        ec_xhalo<XH>(E1, c1, nb, pln, L1, R1);
+        ec_xhalo<XH>(E4, c4, nb, pln, L4, R4);
         const float x1[8] = {L1.x, L1.y, c1.x, c1.y, c1.z, c1.w, R1.x, R1.y};
         const float x4[8] = {L4.x, L4.y, c4.x, c4.y, c4.z, c4.w, R4.x, R4.y};
         float nvx[4], nvz[4];
@@ -1327,12 +1398,14 @@ __global__ __launch_bounds__(kEcThreads) void el_cluster_adj(const EaParams p)
         const int fsz = ec_su(fsz_), PL = ec_su(PL_);
         const int lo = ec_opaque(g.lo), gq = ec_opaque(g.g);
         const float *D1 = pln + lo, *D2 = pln + fsz + lo, *D4 = pln + 2 * fsz + lo, *D3 = pln + 3 * fsz + lo;
+        const int nb = XH ? ec_opaque(g.nb) : 0;
         const float4 c1 = ld4(D1);
-        const float2 L1 = ld2(D1 - 2), R1 = ld2(D1 + 4);
         const float4 c3 = ld4(D3);
-        const float2 L3 = ld2(D3 - 2), R3 = ld2(D3 + 4);
         const float4 u0 = ld4(D2 - PL), u1 = ld4(D2), u2 = ld4(D2 + PL), u3 = ld4(D2 + 2 * PL);
         const float4 t0 = ld4(D4 - 2 * PL), t1 = ld4(D4 - PL), t2 = ld4(D4), t3 = ld4(D4 + PL);
+        float2 L1, R1, L3, R3;
+        ec_xhalo<XH>(D1, c1, nb, pln, L1, R1);
+        ec_xhalo<XH>(D3, c3, nb, pln, L3, R3);
         const float x1[8] = {L1.x, L1.y, c1.x, c1.y, c1.z, c1.w, R1.x, R1.y};
         const float x3[8] = {L3.x, L3.y, c3.x, c3.y, c3.z, c3.w, R3.x, R3.y};
         float nxx[4], nzz[4], nxz[4];

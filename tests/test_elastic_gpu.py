@@ -119,6 +119,41 @@ def test_cluster_group_dealing_shapes(oracle32, monkeypatch, nz, nx, nw):
     _check_parity(oracle32, elastic_case(seed=61 + nz, nz=nz, nx=nx, fw=6, ns=2, nrec=12, nt=60), bitwise=True)
 
 
+@pytest.mark.parametrize("nz,nx,nw,expect", [(100, 300, 8, True), (52, 300, 4, True), (45, 272, 3, False), (24, 100, 6, None)],
+                         ids=lambda v: str(v))
+def test_cluster_lane_halo_form_equals_the_lds_reads(monkeypatch, nz, nx, nw, expect):
+    """The single-launch kernels take the outer cells of their x-stencils from the neighbouring lanes (DPP wave shifts,
+    ec_xhalo) where the deal of groups to lanes allows it - BASELINE config 3's 100x300 on 8 slabs does (layout.kernel_flags)
+    - and from LDS otherwise (15 rows x 68 groups: boundary and late-interior groups meet inside a wave).  Data movement
+    only: seismograms and gradients are the same bits as with MIFWI_EL_XHALO=0."""
+    from physicsbasedfwi2_amd import _lib, elastic
+    from physicsbasedfwi2_amd.elastic import ElasticPlan
+    monkeypatch.setenv("MIFWI_EL_NW", str(nw))
+    case = elastic_case(seed=77, nz=nz, nx=nx, fw=6, ns=2, nrec=12, nt=60)
+    both = _lib.EL_KERNEL_FWD_LANE_HALO | _lib.EL_KERNEL_ADJ_LANE_HALO
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MIFWI_EL_XHALO", flag)
+        pl = ElasticPlan(nz, nx, 60, 2, 1, 12, 1, 6, 0)
+        assert pl.cluster_slabs(False) == nw and pl.cluster_slabs(True) == nw
+        got = pl.layout.kernel_flags & both
+        pl.close()
+        if flag == "0":
+            assert got == 0
+        elif expect is not None:
+            assert got == (both if expect else 0), got
+        dev = torch.device("cuda:0")
+        mat = torch.tensor(case["mat"], dtype=torch.float32, device=dev, requires_grad=True)
+        f = torch.tensor(case["f"], dtype=torch.float32, device=dev, requires_grad=True)
+        rvx, rvz = elastic.propagate(mat, f, torch.tensor(case["pz"]), torch.tensor(case["px"]), torch.tensor(case["sc"]),
+                                     torch.tensor(case["sw"]), torch.tensor(case["rc"]), torch.tensor(case["rw"]), case["fw"])
+        (0.5 * (rvx ** 2).sum() + 0.5 * (rvz ** 2).sum()).backward()
+        outs.append((rvx.detach().clone(), rvz.detach().clone(), mat.grad.clone(), f.grad.clone()))
+    assert float(outs[0][0].abs().max()) > 0
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
 def test_cluster_adjoint_source_paths_agree(oracle32, monkeypatch):
     """The single-launch adjoint adds its sources through a receiver-row buffer (plain LDS stores) where every tap of a
     slab has a cell of its own on at most four rows, and through LDS float atomics otherwise (MIFWI_EL_ADJ_DIRECT=0
