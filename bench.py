@@ -726,12 +726,16 @@ def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, 
     agent0 = int(_mifwi_lib.load().mifwi_agent_handoff_count())
     slow0 = int(_mifwi_lib.load().mifwi_slow_handoff_count())
     t0 = time.perf_counter()
+    kept = []
     for _ in range(args.steps):
         grad, loss = one_step(True)
-        losses.append(loss.detach())            # device scalars: no sync inside the timed region
-        gsums.append(grad.detach().abs().sum(dtype=torch.float64))
+        kept.append((grad.detach(), loss.detach()))      # looked at after the timed region (repeatability check below)
     barrier()
     el = time.perf_counter() - t0
+    for grad, loss in kept:
+        losses.append(loss)
+        gsums.append(grad.abs().sum(dtype=torch.float64))
+    del kept
     # single-launch time loops that gave up inside the timed region and were re-run with one launch per step (rank 0's
     # count): must be 0 for `kernel_family` to describe what was timed
     fallbacks = int(_mifwi_lib.load().mifwi_fallback_count()) - fallbacks0
