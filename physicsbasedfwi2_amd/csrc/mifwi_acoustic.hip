@@ -1226,6 +1226,7 @@ AcPml pml_params(const mifwi_acoustic_plan *pl, const float *ab0, const float *a
     m.A0 = persist; m.B0 = m.A0 + ns * m.s0; m.A1 = m.B0 + ns * m.s0; m.B1 = m.A1 + ns * m.s1;
     m.P0 = scratch; m.Q0 = m.P0 + ns * m.s0; m.P1 = m.Q0 + ns * m.s0; m.Q1 = m.P1 + ns * m.s1;
     m.e0 = m.Q1 + ns * m.s1; m.e1 = m.e0 + ns * m.r0;
+    m.mg_ng = pml_magic((unsigned)pl->gp / 4u); m.mg_w2 = pml_magic(2u * (unsigned)(m.W + 2));
     return m;
 }
 // the thin launches of one step for shots [shot0, shot0 + count): forward (Psi, Z, e) or adjoint (P/Zb, Q/Pb, e)

@@ -26,6 +26,7 @@ struct AcPml {
     float c0, c1;
     int shot0;                   // first shot of the launch (blockIdx.y counts from it)
     int nshot;
+    unsigned mg_ng, mg_w2;       // floor(2^32 / (gp / 4)), floor(2^32 / (2 (W + 2))): pml_div
     // single-launch kernels only: the arrays of `lds` (PML_* bits) live in the workgroup's LDS, where the pointer is the
     // slab's own part of the array and f0s/f0r/f1s/f1r the element of the shot's array that part starts at
     unsigned lds;
@@ -83,6 +84,16 @@ __host__ __device__ inline long long pml_scratch_per_shot(int W, int n0, int gp)
     return pml_persist_per_shot(W, n0, gp) + 2LL * (W + 2) * gp + 2LL * (W + 2) * n0;
 }
 
+// x / d for d < 2^31 with mg = floor(2^32 / d): a multiply-high and one correction instead of a division sequence (the
+// thread maps below divide once per cell, phase and step)
+__host__ __device__ inline unsigned pml_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ULL / d); }
+__device__ __forceinline__ unsigned pml_div(unsigned x, unsigned d, unsigned mg)
+{
+    unsigned q = __umulhi(x, mg);
+    if (x - q * d >= d) ++q;
+    return q;
+}
+
 // strip-shaped array of axis 0 / axis 1, zero outside the strip (and outside the grid)
 // strip-shaped arrays read at a cell that may lie outside the strip (zero there).  Branch-free: the load goes to a
 // clamped, always valid index and the result is selected afterwards, so that the four or five neighbour reads of a
@@ -90,9 +101,9 @@ __host__ __device__ inline long long pml_scratch_per_shot(int W, int n0, int gp)
 // per cell in the single-launch kernel's layer phases).
 __device__ __forceinline__ float pml_get1(const AcPml &p, const float *a, long long off, int i0, int i1)
 {
-    const bool lo = i1 >= 0 && i1 < p.W, hi = i1 >= p.n1 - p.W && i1 < p.n1;
-    int l = lo ? i1 : p.W + i1 - (p.n1 - p.W);
-    l = l < 0 ? 0 : (l > 2 * p.W - 1 ? 2 * p.W - 1 : l);
+    // (unsigned compares: one each for "inside the low strip" / "inside the high strip")
+    const bool lo = (unsigned)i1 < (unsigned)p.W, hi = (unsigned)(i1 - (p.n1 - p.W)) < (unsigned)p.W;
+    const int l = (lo || hi) ? (lo ? i1 : p.W + i1 - (p.n1 - p.W)) : 0;         // outside: any valid element of the row
     const float v = a[off + (i0 * 2 * p.W + l)];
     return (lo || hi) ? v : 0.f;          // (the load above is unconditional)
 }
@@ -119,7 +130,7 @@ __device__ __forceinline__ PmlCell pml_cell(const AcPml &p, unsigned id, int axi
     if (axis == 0) {
         const unsigned ng = (unsigned)p.gp / 4u;
         if (id >= 2u * W2 * ng) return c;
-        const unsigned row = id / ng;                                // side * W2 + l
+        const unsigned row = pml_div(id, ng, p.mg_ng);               // side * W2 + l
         const unsigned side = row >= W2 ? 1u : 0u, l = row - side * W2;
         c.ok = true; c.i1 = 4 * (int)(id - row * ng);
         c.i0 = side == 0 ? (int)l : p.n0 - (int)W2 + (int)l;
@@ -129,7 +140,7 @@ __device__ __forceinline__ PmlCell pml_cell(const AcPml &p, unsigned id, int axi
         c.ridx = (int)row * p.gp + c.i1;
     } else {
         if (id >= 2u * W2 * (unsigned)p.n0) return c;
-        const unsigned i0 = id / (2u * W2), rem = id - i0 * 2u * W2;
+        const unsigned i0 = pml_div(id, 2u * W2, p.mg_w2), rem = id - i0 * 2u * W2;
         const unsigned side = rem >= W2 ? 1u : 0u, l = rem - side * W2;
         c.ok = true; c.i0 = (int)i0;
         c.i1 = side == 0 ? (int)l : p.n1 - (int)W2 + (int)l;
@@ -145,10 +156,10 @@ __device__ __forceinline__ void pml_st4(float *q, const float (&v)[4]) { *reinte
 // four cells of a strip-shaped axis-0 array at row i0 (zero outside the strip / the grid); branch-free as pml_get1
 __device__ __forceinline__ float4 pml_get0v(const AcPml &p, const float *a, long long off, int i0, int i1)
 {
-    const bool lo = i0 >= 0 && i0 < p.W, hi = i0 >= p.n0 - p.W && i0 < p.n0;
-    int l = lo ? i0 : p.W + i0 - (p.n0 - p.W);
-    const int l_lo = 2 * i0 >= p.n0 ? p.W : 0;            // clamped into the strip of the row's own side (the part a
-    l = l < l_lo ? l_lo : (l > l_lo + p.W - 1 ? l_lo + p.W - 1 : l);   // slab of a single-launch kernel holds in LDS)
+    const bool lo = (unsigned)i0 < (unsigned)p.W, hi = (unsigned)(i0 - (p.n0 - p.W)) < (unsigned)p.W;
+    // outside the strips: the first row of the strip on the row's own side (the part a slab of a single-launch kernel
+    // holds in LDS) - any valid element, the value is discarded
+    const int l = (lo || hi) ? (lo ? i0 : p.W + i0 - (p.n0 - p.W)) : (2 * i0 >= p.n0 ? p.W : 0);
     const float4 v = pml_ld4(a + (off + (l * p.gp + i1)));
     const bool ok = lo || hi;
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
