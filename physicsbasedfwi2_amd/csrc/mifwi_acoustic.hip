@@ -666,7 +666,9 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             if (gi < nb) { perm[gi] = gi; continue; }
             const int kr = gi / p.ng, g = gi - kr * p.ng;
             const float4 q1 = *reinterpret_cast<const float4 *>(p.q1 + 4 * g);
-            const bool dmp = p.q0[r0 + row_of(kr)] != 0.f || q1.x != 0.f || q1.y != 0.f || q1.z != 0.f || q1.w != 0.f;
+            // (C-PML plans have no sponge: there the groups of the layer, whose update adds the layer's term, go last)
+            const bool dmp = PML ? pml_layer_group(m, r0 + row_of(kr), g)
+                                 : p.q0[r0 + row_of(kr)] != 0.f || q1.x != 0.f || q1.y != 0.f || q1.z != 0.f || q1.w != 0.f;
             if (!dmp) perm[nb + atomicAdd(&perm_cnt[0], 1)] = gi;
             else perm[ngrp - 1 - atomicAdd(&perm_cnt[1], 1)] = gi;
         }
@@ -687,7 +689,10 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             rr[i] = *reinterpret_cast<const float4 *>(p.r + (long long)j * p.gp + 4 * g);
             const float4 q1 = *reinterpret_cast<const float4 *>(p.q1 + 4 * g);
             const float q0 = p.q0[j];
-            if (q0 != 0.f || q1.x != 0.f || q1.y != 0.f || q1.z != 0.f || q1.w != 0.f) dampmask |= 1u << i;
+            if (PML ? pml_layer_group(m, j, g) : (q0 != 0.f || q1.x != 0.f || q1.y != 0.f || q1.z != 0.f || q1.w != 0.f))
+                dampmask |= 1u << i;             // C-PML plans: "a group of the layer" (their damping tables are zero)
+            if (PML && (4 * g < m.W + 2 || 4 * g + 3 >= m.n1 - (m.W + 2)))
+                dampmask |= 16u << i;            // ... and "some of its cells lie in the region of axis 1" 
             if (adj) acc[i] = *reinterpret_cast<const float4 *>(p.acc + ((long long)s * p.n0 + j) * p.gp + 4 * g);
             if (MODE == 3) acc[i] = *reinterpret_cast<const float4 *>(p.born_dr + (long long)j * p.gp + 4 * g);
         }
@@ -939,14 +944,15 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 float un[4], gk[4];
                 float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
                 float q0 = 0.f;
-                const bool damped = (dampmask >> i) & 1u;
+                const bool damped = !PML && ((dampmask >> i) & 1u);
                 const int lo_i = cl_opaque(loff[i]), jg_i = cl_opaque(jg[i]);
                 if (damped) {
                     q1 = *reinterpret_cast<const float4 *>(ldq1 + 4 * (jg_i & 4095));
                     q0 = ldq0[(jg_i >> 12) - r0];
                 }
                 float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (PML) pe = pml_term(m, s, jg_i >> 12, jg_i & 4095, adj);      // the layer's term of the group's four cells
+                // the layer's term of the group's four cells (an exact zero for the groups away from the layer: not read)
+                if (PML && ((dampmask >> i) & 1u)) pe = pml_term(m, s, jg_i >> 12, jg_i & 4095, adj, (dampmask >> (4 + i)) & 1u);
                 cl_update<MODE == 1, PML>(cur + lo_i, prv + lo_i, PL, rr[i], q0, q1, damped, p.c0, p.c1,
                                           p.n1 - 4 * (jg_i & 4095), un, gk, pe);
                 if (!adj && !slow_sparse && i == src_slot) {

@@ -314,9 +314,17 @@ __device__ __forceinline__ void ac_pml_adj_c_cell(const AcPml &p, const int s, c
     }
 }
 
+// does group g of row j touch the layer's regions at all?  (the single-launch kernels skip pml_term for the others)
+__device__ __forceinline__ bool pml_layer_group(const AcPml &m, int j, int g)
+{
+    const int W2 = m.W + 2;
+    return j < W2 || j >= m.n0 - W2 || 4 * g < W2 || 4 * g + 3 >= m.n1 - W2;
+}
 // The layer's term of the four cells of group g in row j, read from the region arrays of shot s (what ac_step<PML> and
 // ac_cluster<PML> add to their Laplacian): forward fma(c0, e0, c1 e1), adjoint e0 + e1.  Branch-free loads.
-__device__ __forceinline__ float4 pml_term(const AcPml &m, int s, int j, int g, bool adjoint)
+// in1 = false: the caller knows that none of the group's cells lies in the region of axis 1 (only the two short runs at
+// the ends of a row do): e1 is an exact zero there and is not read
+__device__ __forceinline__ float4 pml_term(const AcPml &m, int s, int j, int g, bool adjoint, bool in1 = true)
 {
     const int W2 = m.W + 2;
     const bool rlo = j < W2, rhi = j >= m.n0 - W2;
@@ -324,18 +332,24 @@ __device__ __forceinline__ float4 pml_term(const AcPml &m, int s, int j, int g, 
     l0 = l0 < 0 ? 0 : (l0 > 2 * W2 - 1 ? 2 * W2 - 1 : l0);
     const float4 e0v = pml_ld4(m.e0 + (pml_off(m, PML_E0, s) + (l0 * m.gp + 4 * g)));
     const bool ok0 = rlo || rhi;
-    const float *pe1 = m.e1 + (pml_off(m, PML_E1, s) + j * 2 * W2);
+    float e1v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (in1) {
+        const float *pe1 = m.e1 + (pml_off(m, PML_E1, s) + j * 2 * W2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i1 = 4 * g + c;
+            const bool clo = i1 < W2, chi = i1 >= m.n1 - W2 && i1 < m.n1;
+            int l1 = clo ? i1 : W2 + i1 - (m.n1 - W2);
+            l1 = l1 < 0 ? 0 : (l1 > 2 * W2 - 1 ? 2 * W2 - 1 : l1);
+            const float v1 = pe1[l1];
+            e1v[c] = (clo || chi) ? v1 : 0.f;
+        }
+    }
     float ev[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int i1 = 4 * g + c;
-        const bool clo = i1 < W2, chi = i1 >= m.n1 - W2 && i1 < m.n1;
-        int l1 = clo ? i1 : W2 + i1 - (m.n1 - W2);
-        l1 = l1 < 0 ? 0 : (l1 > 2 * W2 - 1 ? 2 * W2 - 1 : l1);
-        const float v1 = pe1[l1];
-        const float e1 = (clo || chi) ? v1 : 0.f;
         const float e0 = ok0 ? comp(e0v, c) : 0.f;
-        ev[c] = adjoint ? e0 + e1 : fmaf(m.c0, e0, m.c1 * e1);
+        ev[c] = adjoint ? e0 + e1v[c] : fmaf(m.c0, e0, m.c1 * e1v[c]);
     }
     return make_float4(ev[0], ev[1], ev[2], ev[3]);
 }
