@@ -438,3 +438,27 @@ def test_cpml_single_launch_and_per_step_families_agree(oracle32, monkeypatch):
     rec2.backward(torch.sign(rec2.detach()))
     assert torch.equal(rec2.detach(), outs[0][0])
     assert rel_l2(r2.grad.cpu().numpy(), outs[1][1].cpu().numpy()) <= 2e-5
+
+
+def test_geometry_cache_follows_tensor_identity_and_version():
+    """propagate() keeps the device-resident geometry (and the validation of its cells: a host round trip) of tap tensors it
+    has seen - while the very same device tensors are passed again, unmodified.  An in-place change makes a new one (and is
+    validated again: an out-of-grid cell still raises); host tensors - which may alias numpy buffers - are never cached."""
+    from physicsbasedfwi2_amd.acoustic import _Geometry
+    from physicsbasedfwi2_amd._lib import MifwiError
+    dev = torch.device("cuda:0")
+    sc = torch.tensor([[[5]], [[9]]], dtype=torch.int32, device=dev)
+    rc = torch.tensor([[[7], [8]], [[7], [8]]], dtype=torch.int32, device=dev)
+    sw, rw = torch.ones(2, 1, 1, device=dev), torch.ones(2, 2, 1, device=dev)
+    g1 = _Geometry.get(sc, sw, rc, rw, dev)
+    assert _Geometry.get(sc, sw, rc, rw, dev) is g1
+    g1.check_cells(100, "10x10")
+    with pytest.raises(MifwiError):
+        g1.check_cells(9, "3x3")
+    rc[0, 0, 0] = 1000                                   # in place: the version counter moves
+    g2 = _Geometry.get(sc, sw, rc, rw, dev)
+    assert g2 is not g1
+    with pytest.raises(MifwiError):
+        g2.check_cells(100, "10x10")
+    cpu = [t.cpu() for t in (sc, sw, rc, rw)]
+    assert _Geometry.get(*cpu, dev) is not _Geometry.get(*cpu, dev)
