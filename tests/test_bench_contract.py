@@ -81,17 +81,72 @@ def test_roofline_objects_use_one_cell_convention_and_never_exceed_one(tmp_path,
     assert k2["adjoint+imaging"]["traffic_note"].startswith("workload not in")
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    path = os.path.join(ROOT, "profiles", bench.PROFILE_ROUND + "_bench_default_output.json")
+def _committed(suffix):
+    """Newest committed profiles/rNN_<suffix> (this round's once it has been measured, else the round before)."""
+    rounds = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_" + suffix)), reverse=True)
+    assert rounds, suffix
+    return os.path.join(ROOT, "profiles", rounds[0])
+
+
+def _committed_full_report():
+    """The full report of the last measured default run: rNN_bench_default_detail.json (round 4 on), or round 3's
+    rNN_bench_default_output.json, which had the same layout (it was printed whole, and the driver lost it)."""
+    det = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_default_detail.json"))
+    path = os.path.join(ROOT, "profiles", det[-1]) if det else os.path.join(ROOT, "profiles", "r03_bench_default_output.json")
     with open(path) as fh:
-        d = json.load(fh)
+        return json.load(fh)
+
+
+def test_final_stdout_line_is_one_bounded_json_object():
+    """Round 3's line grew to 23 KB and the driver parsed nothing.  The line bench.py prints LAST is formatted here from
+    a committed full report: one JSON object, <= 6000 bytes, carrying the contract fields with roofline.frac and
+    cpu_baseline.value - whatever the secondary workloads add."""
+    d = _committed_full_report()
+    also = d.pop("also", [])
+    for a in also:                                  # the full report keeps these per entry already
+        assert "config" in a and "kernels" in a and "roofline" in a
+    text = bench.final_line(d, also)
+    assert "\n" not in text and len(text.encode()) <= bench.MAX_LINE_BYTES <= 6000
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "check", "ranks"):
+        assert k in line, k
+    assert line["config"]["workload"] == bench.ElasticMarmousi.name and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= 1.0
+    assert "traffic" in r and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    assert abs(line["value"] - d["value"]) <= 1e-3 * d["value"]
+    assert len(line.get("also", [])) == len(also)
+    for a in line.get("also", []):
+        assert a["roofline"]["frac"] > 0 and a["value"] > 0 and set(a["kernels"]) == {"forward+save", "adjoint+imaging"}
+    # a report that would not fit loses its extras, never the headline
+    fat = [dict(a, config=dict(a["config"], workload="w" * 1500)) for a in also] * 2
+    text = bench.final_line(d, fat)
+    assert len(text.encode()) <= bench.MAX_LINE_BYTES
+    assert "also" not in json.loads(text) and json.loads(text)["roofline"]["frac"] == r["frac"]
+
+
+def test_committed_compact_line_is_what_the_driver_can_parse():
+    """profiles/rNN_bench_default_output.json from round 4 on is the very line the run printed."""
+    path = _committed("bench_default_output.json")
+    raw = open(path).read().strip()
+    d = json.loads(raw)
+    if "also" in d and d["also"] and "config" in d["also"][0]:
+        return                                      # round 3's full-format file: covered by the test above
+    assert len(raw.encode()) <= bench.MAX_LINE_BYTES and "\n" not in raw
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["check"]["verified"] is True
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = _committed_full_report()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "check"):
         assert k in d, k
     assert d["config"]["workload"] == bench.ElasticMarmousi.name and "model" not in d["config"]
     assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["vs_baseline"] is None
     entries = [d] + d.get("also", [])
-    assert [e["config"]["workload"] for e in entries[1:]][:1] == [bench.AcousticMarmousi.name]
+    assert entries[1]["config"]["workload"].startswith(bench.AcousticMarmousi.name)
     assert any(e["config"]["grid"] == [1000, 3000] for e in entries[1:])          # the SEAM-sized sample (C5's grid)
     for e in entries:
         r = e["roofline"]
@@ -101,16 +156,16 @@ def test_committed_bench_line_has_the_contract_fields():
         assert e["check"]["bitwise_repeatable"] is True and e["check"]["verified"] is True
         assert e["check"].get("fallbacks", 0) == 0           # no single-launch time loop gave up inside the timed region
         assert e["check"]["loss"] > 1e-8 and e["check"]["grad_abs_sum"] > 1e-8
-        # time-axis samples of the big grids and the C-PML variant of C2 carry no CPU leg
-        if "acquisition" not in e["config"] and "cpml" not in e["config"]["workload"]:
+        if "cpu_baseline" in e:
             c = e["cpu_baseline"]
             assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "C oracle" in c["sample"]
         for k in e["kernels"].values():
             if k["lds_resident"]:
-                # the bound quoted for an LDS-resident loop: issue cycles of the shipped kernel over the step's cycles
-                assert k["issue"]["bound"] == "issue" and 0.05 < k["issue"]["frac_wave"] < 1.0
-                assert 0.05 < k["issue"]["frac_simd_valu"] <= 1.0 and k["issue"]["waves_per_simd"] in (2, 4)
+                # diagnostic quoted for an LDS-resident loop: issue cycles of the shipped kernel over the step's cycles
+                assert k["issue"]["bound"] == "issue"
+                assert k["issue"]["frac_simd_valu"] is None or 0.05 < k["issue"]["frac_simd_valu"] <= 1.0
                 assert k["latency"]["bound"] == "latency"
+    assert "cpu_baseline" in entries[0] and "cpu_baseline" in entries[1]
     # whole-job throughput = interior cells*steps of all shots / wall time
     wl = bench.ElasticMarmousi
     units = wl.nz * wl.nx * wl.nt * wl.shots_per_gpu * d["steps"]
@@ -126,8 +181,9 @@ def test_pmc_tool_knows_the_kernels_the_bench_runs():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_traffic
     seen = {}
+    last_round = os.path.basename(_committed("bench_default_kernel_stats.csv"))[:3]
     for fname in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-        if fname.startswith(bench.PROFILE_ROUND) and fname.endswith("kernel_stats.csv"):
+        if fname.startswith(last_round) and fname.endswith("kernel_stats.csv"):
             for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fname))):
                 seen[pmc_traffic.clean(r["Name"])] = fname
     assert any(n.startswith("el_cluster_adj<") for n in seen) and any(n.startswith("ac_cluster<2,") for n in seen)
