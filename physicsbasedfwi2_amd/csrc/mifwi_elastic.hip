@@ -67,7 +67,9 @@ struct ElParams {
     float *psix, *psiz;          // forward: updated in place; adjoint: read side
     float *psix_out, *psiz_out;  // adjoint: write side (ping-pong)
     float *S;                    // snapshot slice of this step: f32 [nshot][5][nz][gp]; bf16: snap_shot floats per shot
-    long long snap_shot;         // floats per shot of one snapshot step (5*nz*gp for f32)
+    long long snap_shot;         // floats per shot of one snapshot step (5 * splane for f32)
+    unsigned splane;             // floats per snapshot plane: nz*gp, or nz * 64 * ceil(ng / 16) in the column-blocked layout
+    int sblk;                    // 1: snapshot planes stored as [column block of 16 groups][row][64 floats] (snap_cell)
     float *acc;                  // [ngroups][5][nz][gp]
     // injection (S launch: sxx,szz += a ; S^T launch: vx += ax, vz += az)
     int ninj, ntap_inj;
@@ -82,6 +84,9 @@ struct ElParams {
     const float *smp_w;
     float *smp_out0, *smp_out1;
     int tiles_z;
+    int walk_rows;               // el_adj_walk: rows of a column chunk (a multiple of 14)
+    float *trash;                // el_adj_walk: 1024 floats that lanes without an owned cell store to (stores stay branch-free)
+    int walk_dbg;                // -DMIFWI_ABLATIONS builds: streams switched off for traffic / timing experiments (wrong results)
     int xcd;                     // 1: XCD-contiguous tile order (xcd_tile)
     FdK K;                       // stencil weights
 };
@@ -165,6 +170,18 @@ __device__ __forceinline__ void bf_widen(const BfPlanes &q, float4 &S1, float4 &
     S4 = make_float4(bf_lo(q.de.x), bf_hi(q.de.x), bf_lo(q.de.y), bf_hi(q.de.y));
     S5 = make_float4(bf_lo(q.de.z), bf_hi(q.de.z), bf_lo(q.de.w), bf_hi(q.de.w));
     S3 = make_float4(bf_lo(q.c.x), bf_hi(q.c.x), bf_lo(q.c.y), bf_hi(q.c.y));
+}
+
+// Offset (floats) of group g of row j inside a snapshot plane.  Row-major [nz][gp] (the layout the single-launch
+// kernels share), or - per-step family, plans without a single-launch kernel - blocked by columns of 16 groups:
+// [g / 16][j][64 floats].  Every kernel of the family works on tiles 16 groups wide, so a tile row is 256 contiguous,
+// 256-byte aligned bytes of the plane and consecutive rows follow each other: whole 128-byte lines on the way out
+// and on the way back in.  (Row-major rows are gp * 4 bytes apart, not a multiple of 128 in general: a 256-byte tile
+// row straddles three lines, and the adjoint read 33 B per cell-step of the 20 B snapshot stream.)
+__device__ __forceinline__ unsigned snap_cell(const ElParams &p, int j, int g)
+{
+    return p.sblk ? ((unsigned)(g >> 4) * (unsigned)p.nz + (unsigned)j) * 64u + 4u * (unsigned)(g & 15)
+                  : (unsigned)j * p.gp + 4u * (unsigned)g;
 }
 
 // x-strip column offset of group g (or -1)
@@ -394,11 +411,11 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_v(const E
             st4(vx + o, vxv);
             st4(vz + o, vzv);
             if (SAVE == 1) {
-                float *Sp = p.S + (long long)s * p.snap_shot + cc;
-                mifwi::stnt4(Sp + 3 * (long long)ncell, make_float4(s4v[0], s4v[1], s4v[2], s4v[3]));
-                mifwi::stnt4(Sp + 4 * (long long)ncell, make_float4(s5v[0], s5v[1], s5v[2], s5v[3]));
+                float *Sp = p.S + (long long)s * p.snap_shot + snap_cell(p, j, g);
+                mifwi::stnt4(Sp + 3 * (long long)p.splane, make_float4(s4v[0], s4v[1], s4v[2], s4v[3]));
+                mifwi::stnt4(Sp + 4 * (long long)p.splane, make_float4(s5v[0], s5v[1], s5v[2], s5v[3]));
             } else if (SAVE == 2) {
-                bf_store2(p.S + (long long)s * p.snap_shot + bf_reg_de(ncell), cc >> 2, s4v, s5v);
+                bf_store2(p.S + (long long)s * p.snap_shot + bf_reg_de(p.splane), snap_cell(p, j, g) >> 2, s4v, s5v);
             }
             a0 = a1; a1 = a2; a2 = a3;
             b0 = b1; b1 = b2; b2 = b3;
@@ -522,14 +539,14 @@ __global__ __launch_bounds__(kThreads, MIFWI_EL_MINWAVES) void el_step_s(const E
                     st4(szz + o, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
                     st4(sxz + o, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
                     if (SAVE == 1) {
-                        float *Sp = p.S + (long long)s * p.snap_shot + cc;
+                        float *Sp = p.S + (long long)s * p.snap_shot + snap_cell(p, j, g);
                         mifwi::stnt4(Sp, make_float4(e1[0], e1[1], e1[2], e1[3]));
-                        mifwi::stnt4(Sp + (long long)ncell, make_float4(e2[0], e2[1], e2[2], e2[3]));
-                        mifwi::stnt4(Sp + 2 * (long long)ncell, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
+                        mifwi::stnt4(Sp + (long long)p.splane, make_float4(e2[0], e2[1], e2[2], e2[3]));
+                        mifwi::stnt4(Sp + 2 * (long long)p.splane, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
                     } else if (SAVE == 2) {
                         float *Sp = p.S + (long long)s * p.snap_shot;
-                        bf_store2(Sp, cc >> 2, e1, e2);
-                        bf_store1(Sp + bf_reg_c(ncell), cc >> 2, s3v);
+                        bf_store2(Sp, snap_cell(p, j, g) >> 2, e1, e2);
+                        bf_store1(Sp + bf_reg_c(p.splane), snap_cell(p, j, g) >> 2, s3v);
                     }
                     a0 = a1; a1 = a2; a2 = a3;
                     b0 = b1; b1 = b2; b2 = b3;
@@ -771,11 +788,12 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
         }
         // the snapshot planes are only needed after the barrier: requested last, they do not delay the staging
         if (own_ok && !BF16) {
-            const float *Sp = p.S + (long long)s * p.snap_shot + occ;
-            S1 = mifwi::ldnt4(Sp); S2 = mifwi::ldnt4(Sp + (long long)ncell); S3 = mifwi::ldnt4(Sp + 2 * (long long)ncell);
-            S4 = mifwi::ldnt4(Sp + 3 * (long long)ncell); S5 = mifwi::ldnt4(Sp + 4 * (long long)ncell);
+            const float *Sp = p.S + (long long)s * p.snap_shot + snap_cell(p, oj, og);
+            const long long sp = p.splane;
+            S1 = mifwi::ldnt4(Sp); S2 = mifwi::ldnt4(Sp + sp); S3 = mifwi::ldnt4(Sp + 2 * sp);
+            S4 = mifwi::ldnt4(Sp + 3 * sp); S5 = mifwi::ldnt4(Sp + 4 * sp);
         } else if (own_ok) {
-            bf_request(p.S + (long long)s * p.snap_shot, ncell, occ >> 2, packed);
+            bf_request(p.S + (long long)s * p.snap_shot, p.splane, snap_cell(p, oj, og) >> 2, packed);
         }
         __syncthreads();
         // ---- stencils from LDS + injection + gradient accumulation ---------------------------
@@ -966,6 +984,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_v(const ElParams p)
 }
 
 #include "mifwi_elastic_fused.h"
+#include "mifwi_elastic_walk.h"
 
 // receivers of the state in p.fields (the last step of a fused range)
 __global__ __launch_bounds__(kThreads) void el_sample_v(const ElParams p)
@@ -1133,11 +1152,15 @@ struct mifwi_elastic_plan {
     const float *g_p;
     int snap_bf16;         // snapshot planes as bf16 (per-step kernels on both sides only)
     long long snap_shot;   // floats per shot of one snapshot step
+    long long splane;      // floats per snapshot plane
+    int sblk;              // snapshot planes blocked by columns of 16 groups (snap_cell)
     int pass_shots;        // forward per-step family: shots per pass over the time range
     int pass_groups;       // adjoint per-step family: shot groups per pass
     int fused;             // forward V+S in one launch (second copy of the state in the work buffer)
     int fused_pass_shots;  // shots per pass of the fused forward (both copies of the state in the Infinity Cache)
-    int fused_adj;         // adjoint S^T+V^T in one launch (second copy of the adjoint fields in the work buffer)
+    int fused_adj;         // adjoint S^T+V^T in one launch (second copy of the adjoint fields in the work buffer):
+                           // 1 = el_adj_fused (16 x 64 tiles, recomputed z halo), 2 = el_adj_walk (column walk)
+    int walk_rows, walk_chunks;   // el_adj_walk: rows per column chunk, chunks per column
     long long field_stride, shot_stride, fields_elems, psix_elems, psiz_elems, coef_elems;
     long long psi_elems;  // psix+psiz rounded up to 64
     // cluster path (LDS-resident time loop); 0 when a shot does not fit
@@ -1164,6 +1187,7 @@ ElParams el_base(const mifwi_elastic_plan *pl, const float *mat, const float *pz
     p.mat = mat; p.pz = pz; p.px = px;
     p.xcd = pl->xcd;
     p.snap_shot = pl->snap_shot;
+    p.splane = (unsigned)pl->splane; p.sblk = pl->sblk;
     p.K = fd_weights(pl->d.fd_order);
     return p;
 }
@@ -1214,11 +1238,12 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
     while ((Pskew - pl->ng) % 16) ++Pskew;
     const int PL_plain = pl->PL;
     if (skew & 1) pl->PL = 4 * Pskew;
-    if (skew & 2) pl->adj_PL = 4 * Pskew; pl->cl_lds = 0; pl->xbuf_elems = 0; pl->xcc_elems = 0;
+    if (skew & 2) pl->adj_PL = 4 * Pskew;
+    pl->cl_lds = 0; pl->xbuf_elems = 0; pl->xcc_elems = 0;
     pl->cl_adj = 0; pl->adj_NW = 0; pl->adj_shots = 0; pl->adj_lds = 0; pl->adj_ng = 0; pl->adj_zrows = 0; pl->list_elems = 0;
     {   // el_build_tile_taps: start [nshot][ntiles + 1], cursor [nshot][ntiles], list [nshot][nrec * ntap]
         const long long ntiles = (long long)mifwi::ceil_div(pl->ng, AGO) * mifwi::ceil_div(pl->d.nz, ATZ);
-        pl->tile_elems = mifwi::round_up64(pl->d.nshot * (2 * ntiles + 1 + (long long)pl->d.nrec * pl->d.ntap), 64);
+        pl->tile_elems = std::max<long long>(1024, mifwi::round_up64(pl->d.nshot * (2 * ntiles + 1 + (long long)pl->d.nrec * pl->d.ntap), 64));
     }
     if (pl->d.ntap != 1 || pl->d.source_type != 0 || pl->d.record_pressure) return;   // per-step kernels only
     const bool want_fwd = env_int("MIFWI_EL_CLUSTER", 1) != 0;
@@ -1474,8 +1499,14 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     // bf16 snapshot planes: the per-step kernels only (the single-launch time loops are not bound by the
     // snapshot stream, and their grids' snapshots fit in memory many times over)
     pl->snap_bf16 = d->snapshot_format == MIFWI_SNAPSHOT_BF16 && !pl->cluster && !pl->cl_adj;
-    pl->snap_shot = pl->snap_bf16 ? mifwi::round_up64(5 * pl->coef_elems / 2, 4) : 5 * pl->coef_elems;
-    pl->fused_adj = !pl->cl_adj && d->source_type == 0 && !d->record_pressure && env_int("MIFWI_EL_FUSED_ADJ", 0) != 0;
+    // column-blocked snapshot planes (snap_cell): plans that never run a single-launch kernel (those write and read
+    // row-major planes, and a call may change family between checkpoint segments); MIFWI_EL_SNAP_BLOCKED=0: row-major
+    pl->sblk = (!pl->cluster && !pl->cl_adj && env_int("MIFWI_EL_SNAP_BLOCKED", 1) != 0) ? 1 : 0;
+    pl->splane = pl->sblk ? 64LL * d->nz * mifwi::ceil_div(pl->ng, 16) : pl->coef_elems;
+    pl->snap_shot = pl->snap_bf16 ? mifwi::round_up64(5 * pl->splane / 2, 4) : 5 * pl->splane;
+    pl->fused_adj = (!pl->cl_adj && d->source_type == 0 && !d->record_pressure) ? env_int("MIFWI_EL_FUSED_ADJ", 0) : 0;
+    if (pl->fused_adj < 0 || pl->fused_adj > 2) pl->fused_adj = 0;
+    pl->walk_rows = 0; pl->walk_chunks = 0;
     {
         // Infinity Cache residency (per-step family, large grids): a pass over the time range takes only as
         // many shots as keep state + materials (+ gradient accumulators) under kResident bytes; measured on
@@ -1530,6 +1561,34 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     if (pl->cl_adj) {                    // the adjoint cluster kernel keeps one accumulator set per shot
         pl->gs = 1;
         pl->ngroups = d->nshot;
+    }
+    if (pl->fused_adj == 2) {
+        // el_adj_walk: columns of 16 groups are cut into chunks of rows; every chunk pays one start-up iteration (the
+        // rows above it that its first rows depend on), so as few chunks as still fill the chip a few times over
+        const size_t lds = walk_lds_bytes(pl->gs);
+        bool ok = lds <= 160 * 1024;
+        for (const void *fn : {(const void *)el_adj_walk<false>, (const void *)el_adj_walk<true>})
+            if (ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                ok = false;
+            }
+        if (!ok) {
+            pl->fused_adj = 0;            // a group too large for the carry area: the two-launch form
+        } else {
+            int ncu = 256;
+            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device);
+            const int per_cu = std::max(1, std::min(MIFWI_WALK_WAVES, (int)(160 * 1024 / lds)));
+            const int cols = mifwi::ceil_div(pl->ng, WOG), tiles = mifwi::ceil_div(d->nz, WTZ);
+            const int launch_groups = std::min(pl->pass_groups, pl->ngroups);
+            const int want = mifwi::ceil_div(2 * per_cu * ncu, std::max(1, cols * launch_groups));
+            int chunks = std::min(tiles, std::max(1, want));
+            chunks = std::min(chunks, std::max(1, tiles / 2));          // at least two iterations per start-up iteration
+            int rows = mifwi::ceil_div(mifwi::ceil_div(d->nz, chunks), WTZ) * WTZ;
+            rows = env_int("MIFWI_EL_WALK_ROWS", rows);
+            rows = std::max(WTZ, rows / WTZ * WTZ);
+            pl->walk_rows = rows;
+            pl->walk_chunks = mifwi::ceil_div(d->nz, rows);
+        }
     }
     *plan = pl;
     return MIFWI_OK;
@@ -1937,6 +1996,24 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
             ElParams pq = ps;
             pq.gs = cs;
             hipLaunchKernelGGL(el_inject_adjsrc, dim3(mifwi::ceil_div(cs * d.nrec * d.ntap, 64)), dim3(64), 0, st, pq);
+        }
+        if (pl->fused_adj == 2) {
+            const int tx = mifwi::ceil_div(pl->ng, WOG);
+            ps.tiles_z = pl->walk_chunks;
+            ps.walk_rows = pl->walk_rows;
+            {   // the per-tile receiver lists of el_adj_s are not in use with this kernel: their room takes the dummy stores
+                mifwi_elastic_layout lay;
+                mifwi_elastic_plan_layout(pl, &lay);
+                ps.trash = work + lay.work_backward_elems - pl->tile_elems;
+            }
+#ifdef MIFWI_ABLATIONS
+            ps.walk_dbg = env_int("MIFWI_WALK_DBG", 0);
+#endif
+            const int ex = want_f ? mifwi::ceil_div(mifwi::ceil_div(ps.gs * ps.nsmp, kThreads), tx) : 0;
+            const size_t lds = walk_lds_bytes(ps.gs);
+            if (pl->snap_bf16) hipLaunchKernelGGL(el_adj_walk<true>, dim3(tx, pl->walk_chunks + ex, cg), dim3(kThreads), lds, st, ps);
+            else hipLaunchKernelGGL(el_adj_walk<false>, dim3(tx, pl->walk_chunks + ex, cg), dim3(kThreads), lds, st, ps);
+            continue;
         }
         if (pl->fused_adj) {
             const int tx = mifwi::ceil_div(pl->ng, FTG), tz = mifwi::ceil_div(d.nz, FTZ);

@@ -205,11 +205,11 @@ __global__ __launch_bounds__(kThreads, 4) void el_fwd_fused(const ElParams p)
             st4(fout + F_VX * fs + oo, vxn);
             st4(fout + F_VZ * fs + oo, vzn);
             if (SNAP == 1) {
-                float *Sp = p.S + (long long)s * p.snap_shot + occ;
-                mifwi::stnt4(Sp + 3 * (long long)ncell, make_float4(s4v[0], s4v[1], s4v[2], s4v[3]));
-                mifwi::stnt4(Sp + 4 * (long long)ncell, make_float4(s5v[0], s5v[1], s5v[2], s5v[3]));
+                float *Sp = p.S + (long long)s * p.snap_shot + snap_cell(p, oj, og);
+                mifwi::stnt4(Sp + 3 * (long long)p.splane, make_float4(s4v[0], s4v[1], s4v[2], s4v[3]));
+                mifwi::stnt4(Sp + 4 * (long long)p.splane, make_float4(s5v[0], s5v[1], s5v[2], s5v[3]));
             } else if (SNAP == 2) {
-                bf_store2(p.S + (long long)s * p.snap_shot + bf_reg_de(ncell), occ >> 2, s4v, s5v);
+                bf_store2(p.S + (long long)s * p.snap_shot + bf_reg_de(p.splane), snap_cell(p, oj, og) >> 2, s4v, s5v);
             }
         }
         sts4(Vx + (orow + 2) * FSW + 4 * (ogrp + 2), vxn);
@@ -297,14 +297,14 @@ __global__ __launch_bounds__(kThreads, 4) void el_fwd_fused(const ElParams p)
         st4(fout + F_SZZ * fs + oo, make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
         st4(fout + F_SXZ * fs + oo, make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
         if (SNAP == 1) {
-            float *Sp = p.S + (long long)s * p.snap_shot + occ;
+            float *Sp = p.S + (long long)s * p.snap_shot + snap_cell(p, oj, og);
             mifwi::stnt4(Sp, make_float4(e1[0], e1[1], e1[2], e1[3]));
-            mifwi::stnt4(Sp + (long long)ncell, make_float4(e2[0], e2[1], e2[2], e2[3]));
-            mifwi::stnt4(Sp + 2 * (long long)ncell, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
+            mifwi::stnt4(Sp + (long long)p.splane, make_float4(e2[0], e2[1], e2[2], e2[3]));
+            mifwi::stnt4(Sp + 2 * (long long)p.splane, make_float4(s3v[0], s3v[1], s3v[2], s3v[3]));
         } else if (SNAP == 2) {
             float *Sp = p.S + (long long)s * p.snap_shot;
-            bf_store2(Sp, occ >> 2, e1, e2);
-            bf_store1(Sp + bf_reg_c(ncell), occ >> 2, s3v);
+            bf_store2(Sp, snap_cell(p, oj, og) >> 2, e1, e2);
+            bf_store1(Sp + bf_reg_c(p.splane), snap_cell(p, oj, og) >> 2, s3v);
         }
     }
 }
@@ -322,16 +322,17 @@ __global__ __launch_bounds__(kThreads, 4) void el_fwd_fused(const ElParams p)
 constexpr int kAFRows = 2 * FRS + 2 * FRV + 4 * FRV;       // E2, E3 (FRS rows), E1, E4 (FRV rows), D1..D4 (FRV rows)
 constexpr int kAFElems = kAFRows * FSW;
 // v_bar' of group (j, g) from the E planes: `lr` = row in the FRV-row planes, `lc` = first column
+template <int SW = FSW>      // floats per LDS row of the planes
 __device__ __forceinline__ void adj_v_update(const ElParams &p, int g, const float *E1, const float *E2, const float *E3,
                                              const float *E4, int lr, int lc, const float4 &vxb, const float4 &vzb,
                                              float *nvx, float *nvz)
 {
     const FdK K = p.K;
-    const Row8 x1 = row8(E1 + lr * FSW, lc), x4 = row8(E4 + lr * FSW, lc);
-    const float4 z3a = lds4(E3 + (lr + 0) * FSW + lc), z3b = lds4(E3 + (lr + 1) * FSW + lc);
-    const float4 z3c = lds4(E3 + (lr + 2) * FSW + lc), z3d = lds4(E3 + (lr + 3) * FSW + lc);
-    const float4 z2a = lds4(E2 + (lr + 1) * FSW + lc), z2b = lds4(E2 + (lr + 2) * FSW + lc);
-    const float4 z2c = lds4(E2 + (lr + 3) * FSW + lc), z2d = lds4(E2 + (lr + 4) * FSW + lc);
+    const Row8 x1 = row8(E1 + lr * SW, lc), x4 = row8(E4 + lr * SW, lc);
+    const float4 z3a = lds4(E3 + (lr + 0) * SW + lc), z3b = lds4(E3 + (lr + 1) * SW + lc);
+    const float4 z3c = lds4(E3 + (lr + 2) * SW + lc), z3d = lds4(E3 + (lr + 3) * SW + lc);
+    const float4 z2a = lds4(E2 + (lr + 1) * SW + lc), z2b = lds4(E2 + (lr + 2) * SW + lc);
+    const float4 z2c = lds4(E2 + (lr + 3) * SW + lc), z2d = lds4(E2 + (lr + 4) * SW + lc);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float dx1 = dfw(K, x1.v[c + 1], x1.v[c + 2], x1.v[c + 3], x1.v[c + 4]);
@@ -472,11 +473,12 @@ __global__ __launch_bounds__(kThreads, 3) void el_adj_fused(const ElParams p)
                 hbx = ld4(p.mat + M_BX * ncell + h.cc); hbz = ld4(p.mat + M_BZ * ncell + h.cc);
             }
             if (o.ok && !BF16) {
-                const float *Sp = p.S + (long long)s * p.snap_shot + o.occ;
-                S1 = mifwi::ldnt4(Sp); S2 = mifwi::ldnt4(Sp + (long long)ncell); S3 = mifwi::ldnt4(Sp + 2 * (long long)ncell);
-                S4 = mifwi::ldnt4(Sp + 3 * (long long)ncell); S5 = mifwi::ldnt4(Sp + 4 * (long long)ncell);
+                const float *Sp = p.S + (long long)s * p.snap_shot + snap_cell(p, o.oj, o.og);
+                const long long sp = p.splane;
+                S1 = mifwi::ldnt4(Sp); S2 = mifwi::ldnt4(Sp + sp); S3 = mifwi::ldnt4(Sp + 2 * sp);
+                S4 = mifwi::ldnt4(Sp + 3 * sp); S5 = mifwi::ldnt4(Sp + 4 * sp);
             } else if (o.ok) {
-                bf_request(p.S + (long long)s * p.snap_shot, ncell, o.occ >> 2, packed);
+                bf_request(p.S + (long long)s * p.snap_shot, p.splane, snap_cell(p, o.oj, o.og) >> 2, packed);
             }
         }
         __syncthreads();

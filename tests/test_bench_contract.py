@@ -189,7 +189,7 @@ def test_pmc_tool_knows_the_kernels_the_bench_runs():
     assert any(n.startswith("el_cluster_adj<") for n in seen) and any(n.startswith("ac_cluster<2,") for n in seen)
     assert any(n.startswith(("el_fwd_fused<", "el_step_v<")) for n in seen) and any(n.startswith("el_adj_s<") for n in seen)
     loop_re = (r"(ac_cluster<[12],|ac_step<\d+, \d+, (true, false|false, true)>|el_cluster_fwd<true|el_cluster_adj<|"
-               r"el_step_[vs]<\d+, \d+, [12]>|el_adj_s<|el_adj_v$|el_fwd_fused<[12]>|el_adj_fused<|el_inject_adjsrc$)")
+               r"el_step_[vs]<\d+, \d+, [12]>|el_adj_s<|el_adj_v$|el_fwd_fused<[12]>|el_adj_fused<|el_adj_walk<|el_inject_adjsrc$)")
     for n in seen:
         phys = "acoustic" if n.startswith("ac_") else "elastic" if n.startswith("el_") else None
         if phys is None:

@@ -358,9 +358,16 @@ def test_fused_steps_match_the_two_launch_form(monkeypatch):
     for fused, adj, fsurf, budget, pass_shots, fmt, gs in (
             ("0", "0", 0, big, None, "f32", 0), ("1", "0", 0, big, None, "f32", 0), ("1", "1", 0, big, 2, "f32", 0),
             ("0", "0", 1, big, None, "f32", 2), ("0", "1", 1, big, None, "f32", 2), ("1", "1", 1, 3 << 20, 2, "f32", 2),
-            ("0", "0", 1, big, None, "bf16", 0), ("1", "1", 1, big, 2, "bf16", 0), ("1", "1", 1, 3 << 20, None, "bf16", 0)):
+            ("0", "0", 1, big, None, "bf16", 0), ("1", "1", 1, big, 2, "bf16", 0), ("1", "1", 1, 3 << 20, None, "bf16", 0),
+            # the column-walk adjoint (el_adj_walk): default chunking, one-iteration chunks, one chunk per column
+            ("1", "2", 0, big, 2, "f32", 0), ("0", "2:16", 1, big, None, "f32", 2), ("1", "2:80", 1, 3 << 20, 2, "f32", 2),
+            ("1", "2:32", 1, big, 2, "bf16", 0), ("0", "2", 1, 3 << 20, None, "bf16", 0)):
         monkeypatch.setenv("MIFWI_EL_FUSED", fused)
-        monkeypatch.setenv("MIFWI_EL_FUSED_ADJ", adj)
+        monkeypatch.setenv("MIFWI_EL_FUSED_ADJ", adj.split(":")[0])
+        if ":" in adj:
+            monkeypatch.setenv("MIFWI_EL_WALK_ROWS", adj.split(":")[1])
+        else:
+            monkeypatch.delenv("MIFWI_EL_WALK_ROWS", raising=False)
         if pass_shots:
             monkeypatch.setenv("MIFWI_EL_FUSED_PASS_SHOTS", str(pass_shots))
             monkeypatch.setenv("MIFWI_EL_PASS_GROUPS", "1")
@@ -380,7 +387,7 @@ def test_fused_steps_match_the_two_launch_form(monkeypatch):
                      f.grad.clone()))
     assert outs[1][0] > outs[0][0] and outs[2][1] > outs[0][1]     # the fused plans carry a second copy of the state
     assert float(outs[0][2].abs().max()) > 0 and float(outs[0][4].abs().max()) > 0
-    for a, b in ((0, 1), (0, 2), (3, 4), (3, 5), (6, 7), (6, 8)):
+    for a, b in ((0, 1), (0, 2), (3, 4), (3, 5), (6, 7), (6, 8), (0, 9), (3, 10), (3, 11), (6, 12), (6, 13)):
         for x, y in zip(outs[a][2:], outs[b][2:]):
             assert torch.equal(x, y), (a, b)
     assert not torch.equal(outs[3][4], outs[6][4])      # the bf16 planes were in use

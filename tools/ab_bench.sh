@@ -7,4 +7,4 @@ i=0
 for E in "$@"; do i=$((i+1)); env $E timeout -k 10 300 python bench.py $ARGS --nt ${NT:-90} --steps ${STEPS:-5} --warmup 3 > gpurun_out/ab_$i.json 2>gpurun_out/ab_err.log || { echo "FAILED: $E"; tail -5 gpurun_out/ab_err.log; continue; }; python -c "
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(sys.argv[2], round(d['value']), {k:round(v['avg_step_s']*1e6,1) for k,v in d['kernels'].items()}, 'frac', {k:round(v['alg_GBs']/8000,3) for k,v in d['kernels'].items()}, 'loss %.4g gsum %.4g rep %s' % (d['check']['loss'], d['check']['grad_abs_sum'], d['check']['bitwise_repeatable']))" gpurun_out/ab_$i.json "$E"; done
+print(sys.argv[2], round(d['value']), {k:round(v['us_per_step'],1) for k,v in d['kernels'].items()}, 'frac', {k:round(v['frac_of_hbm_peak'],3) for k,v in d['kernels'].items()}, 'loss %.6g gsum %.6g rep %s' % (d['check']['loss'], d['check']['grad_abs_sum'], d['check']['bitwise_repeatable']))" gpurun_out/ab_$i.json "$E"; done

@@ -33,7 +33,7 @@ LABELS = {
     "elastic": {
         "forward+save": [r"^el_cluster_fwd<true", r"^el_step_v<\d+, \d+, [12]>", r"^el_step_s<\d+, \d+, [12]>",
                          r"^el_fwd_fused<[12]>"],
-        "adjoint+imaging": [r"^el_cluster_adj<", r"^el_adj_s<", r"^el_adj_v$", r"^el_adj_fused<", r"^el_inject_adjsrc$"],
+        "adjoint+imaging": [r"^el_cluster_adj<", r"^el_adj_s<", r"^el_adj_v$", r"^el_adj_fused<", r"^el_adj_walk<", r"^el_inject_adjsrc$"],
     },
 }
 
@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--grid", default="")
     ap.add_argument("--nt", type=int, default=0)
     ap.add_argument("--shots", type=int, default=0)
-    a = ap.parse_args()
+    a, _ = ap.parse_known_args()            # tools/pmc_one.sh hands over the bench arguments as they are
     cls = bench.WORKLOADS[a.workload]
     nz, nx = (int(v) for v in a.grid.lower().split("x")) if a.grid else (cls.nz, cls.nx)
     nt, ns = a.nt or cls.nt, a.shots or cls.shots_per_gpu
