@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define MIFWI_VERSION_MAJOR 0
-#define MIFWI_VERSION_MINOR 6   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format; 4: mifwi_fallback_count; 5: mifwi_agent_handoff_count, mifwi_slow_handoff_count; acoustic desc gained cpml_width, layout state_elems; 6: mifwi_elastic_materials(_vjp), mifwi_acoustic_coefficients(_vjp) */
+#define MIFWI_VERSION_MINOR 7   /* 3: elastic desc gained snapshot_format, fd_order; layout snap_step_elems, snapshot_format; 4: mifwi_fallback_count; 5: mifwi_agent_handoff_count, mifwi_slow_handoff_count; acoustic desc gained cpml_width, layout state_elems; 6: mifwi_elastic_materials(_vjp), mifwi_acoustic_coefficients(_vjp); 7: mifwi_elastic_gradient_parametrization; elastic snapshot planes column-blocked in plans without a single-launch kernel */
 
 enum {
     MIFWI_OK = 0,
@@ -332,6 +332,25 @@ int mifwi_elastic_materials(int device, const float *vp, const float *vs, const 
 int mifwi_elastic_materials_vjp(int device, const float *vp, const float *vs, const float *rho, const float *grad_out,
                                 float *grad_vp, float *grad_vs, float *grad_rho, int32_t nz, int32_t nx,
                                 float dt_over_h, int32_t free_surface, void *stream);
+
+/* DENISE's INVMAT1 (models/networks.py:11025 sets 2): the parameter set the gradients of `d.grad` / get_fwi_gradients
+ * refer to.  Input: the gradients with respect to (Vp, Vs, rho) - what mifwi_elastic_materials_vjp returns - and the
+ * model; output: the gradients with respect to
+ *   MIFWI_PARAM_VELOCITY  (1)  Vp, Vs, rho                   (copy)
+ *   MIFWI_PARAM_IMPEDANCE (2)  Zp = rho Vp, Zs = rho Vs, rho:  g_Zp = g_vp / rho,  g_Zs = g_vs / rho,
+ *                              g_rho' = g_rho - (Vp g_vp + Vs g_vs) / rho
+ *   MIFWI_PARAM_LAME      (3)  lambda, mu, rho:               g_lambda = g_vp / (2 rho Vp),
+ *                              g_mu = g_vp / (rho Vp) + g_vs / (2 rho Vs)   (second term 0 where Vs = 0: a fluid has no mu to move),
+ *                              g_rho' = g_rho - (Vp g_vp + Vs g_vs) / (2 rho)
+ * i.e. the exact chain rule of the change of variables, cell by cell (a 3 x 3 Jacobian).  out_* may alias the inputs.
+ * n = number of cells; all arrays device. */
+#define MIFWI_PARAM_VELOCITY 1
+#define MIFWI_PARAM_IMPEDANCE 2
+#define MIFWI_PARAM_LAME 3
+int mifwi_elastic_gradient_parametrization(int device, int32_t parametrization, const float *vp, const float *vs,
+                                           const float *rho, const float *grad_vp, const float *grad_vs,
+                                           const float *grad_rho, float *out_a, float *out_b, float *out_rho,
+                                           int64_t n, void *stream);
 
 /* vp [nz][nx] (m/s) -> r [nz + 2 pad][nx + 2 pad] = (vp dt/h)^2 with the model edge-replicated into the absorbing
  * layer: the coefficient of the scalar scheme as the deepwave-shaped call protocol needs it per call

@@ -96,6 +96,7 @@ SIGNATURES = {
     "mifwi_elastic_materials": (ctypes.c_int, [ctypes.c_int] + [_P] * 4 + [ctypes.c_int32] * 2 + [ctypes.c_float, ctypes.c_int32, _P]),
     "mifwi_elastic_materials_vjp": (ctypes.c_int, [ctypes.c_int] + [_P] * 7 + [ctypes.c_int32] * 2 +
                                     [ctypes.c_float, ctypes.c_int32, _P]),
+    "mifwi_elastic_gradient_parametrization": (ctypes.c_int, [ctypes.c_int, ctypes.c_int32] + [_P] * 9 + [ctypes.c_int64, _P]),
     "mifwi_acoustic_coefficients": (ctypes.c_int, [ctypes.c_int] + [_P] * 2 + [ctypes.c_int32] * 3 + [ctypes.c_float, _P]),
     "mifwi_acoustic_coefficients_vjp": (ctypes.c_int, [ctypes.c_int] + [_P] * 3 + [ctypes.c_int32] * 3 + [ctypes.c_float, _P]),
 }

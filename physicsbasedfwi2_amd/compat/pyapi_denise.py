@@ -231,8 +231,56 @@ def _nice_dt(limit):
     return best
 
 
+# ---- what an assignment `d.NAME = value` means here -----------------------------------------------------------------
+# pyapi_denise is an attribute bag written into DENISE's parameter file; the reference configures a run by assignment only
+# (networks.py:7603-7731, 9686-9833, 10419-10505, 10899-11090).  A silent bag would accept a parameter this library does
+# not serve - or a typo - and return gradients of another problem, so every name falls in one of four classes:
+# acted on by the kernels and the host chain around them
+_SERVED = frozenset((
+    "root", "verbose", "device", "save_folder", "PHYSICS", "TIME", "DT", "FD_ORDER", "FW", "DAMPING", "FPML", "npower",
+    "k_max_PML", "FREE_SURF", "QUELLART", "QUELLTYP", "QUELLTYPB", "FC_SPIKE_1", "FC_SPIKE_2", "ORDER_SPIKE", "SEISMO",
+    "ITERMAX", "DATA_DIR", "SWS_TAPER_GRAD_HOR", "EXP_TAPER_GRAD_HOR", "GRADT1", "GRADT2", "GRADT3", "GRADT4", "INVMAT1",
+    "fwi_stages", "loss", "DT_used"))
+# DENISE parameters that cannot change what ONE gradient evaluation (ITERMAX = 1) returns: the MPI decomposition, names of
+# files this shim keeps in memory, logging, model bounds and line-search / optimiser settings that only act on model
+# updates, grid sizes that come from the Model object.  Accepted; one warning per name says so.
+_INERT = frozenset((
+    "NPROCX", "NPROCY", "VPUPPERLIM", "VPLOWERLIM", "VSUPPERLIM", "VSLOWERLIM", "RHOUPPERLIM", "RHOLOWERLIM",
+    "SEIS_FILE_VX", "SEIS_FILE_VY", "SEIS_FILE_P", "SEIS_FILE_CURL", "SEIS_FILE_DIV", "SEIS_FORMAT", "JACOBIAN", "MFILE",
+    "LOG", "LOG_FILE", "MISFIT_LOG_FILE", "INV_MOD_OUT", "INV_MODELFILE", "NX", "NY", "DH", "NT", "SOURCE_FILE", "REC_FILE",
+    "SIGNAL_FILE", "GRAD_METHOD", "PCG_BETA", "NLBFGS", "EPS_SCALE", "STEPMAX", "SCALEFAC", "TESTSHOT_START", "TESTSHOT_END",
+    "TESTSHOT_INCR", "PRO", "MIN_ITER", "SNAP", "SNAP_FORMAT", "SNAP_FILE", "TSNAP1", "TSNAP2", "TSNAPINC", "IDX", "IDY"))
+# parameters that DO change the result and are not built: only their neutral value is accepted
+_NEUTRAL = {"TIMEWIN": 0, "TRKILL": 0, "NORMALIZE": 0, "INV_STF": 0, "SPATFILTER": 0, "MODEL_FILTER": 0, "SWS_TAPER_GRAD_VERT": 0,
+            "SWS_TAPER_GRAD_SOURCES": 0, "SWS_TAPER_CIRCULAR_PER_SHOT": 0, "SWS_TAPER_FILE": 0, "NDT": 1, "MAXRELERROR": 0,
+            "RTMOD": 0, "GRAVITY": 0, "INVMAT": 0, "EPRECOND": 0, "RUN_MULTIPLE_SHOTS": 1, "READREC": 0, "READMOD": 0,
+            "TW_IND": 0, "GAMMA": 0, "BOUNDARY": 0}
+_warned = set()
+
+
 class Denise:
-    """Stand-in for pyapi_denise.Denise: attribute bag + forward / grad on the HIP propagator."""
+    """Stand-in for pyapi_denise.Denise: DENISE's parameters as attributes + forward / grad on the HIP propagator.
+    Assigning a name this class does not know raises (a typo must not pass for a parameter); a known parameter that has
+    no effect on a single gradient evaluation is accepted with one warning; a parameter that would change the result and
+    is not built accepts its neutral value only."""
+
+    def __setattr__(self, name, value):
+        if name.startswith("_") or name in _SERVED:
+            return object.__setattr__(self, name, value)
+        if name in _INERT:
+            if name not in _warned:
+                _warned.add(name)
+                import warnings
+                warnings.warn("pyapi_denise shim: %s is accepted and has no effect on forward() / grad() "
+                              "(see compat/pyapi_denise.py: _INERT)" % name, stacklevel=2)
+            return object.__setattr__(self, name, value)
+        if name in _NEUTRAL:
+            if value != _NEUTRAL[name]:
+                raise MifwiError("%s=%r is not implemented: this parameter changes the gradient and only its neutral "
+                                 "value %r is served" % (name, value, _NEUTRAL[name]))
+            return object.__setattr__(self, name, value)
+        raise AttributeError("pyapi_denise shim: unknown parameter %r (served: %s)" % (name, ", ".join(sorted(
+            n for n in _SERVED if n.isupper() or n in ("npower", "k_max_PML", "fwi_stages", "save_folder")))))
 
     def __init__(self, root=None, verbose=1, device=None):
         self.root = root
@@ -243,8 +291,11 @@ class Denise:
         self.PHYSICS = 1
         self.TIME = 6.0
         self.DT = None
-        self.NPROCX = 1
-        self.NPROCY = 1
+        object.__setattr__(self, "NPROCX", 1)          # inert here (no warning for the defaults)
+        object.__setattr__(self, "NPROCY", 1)
+        # INVMAT1: the parameters the gradients refer to - 1: Vp, Vs, rho; 2: Zp = rho Vp, Zs = rho Vs, rho (networks.py:11025);
+        # 3: lambda, mu, rho.  get_fwi_gradients keeps DENISE's file names: "..._vp" holds the first, "..._vs" the second
+        self.INVMAT1 = 1
         # the reference never sets FD_ORDER (`#d.FD_ORDER = 4` is commented out, networks.py:10447), so every prop()
         # runs the pyapi_denise default, recorded as 2 in SURVEY.md appendix C: same default here (4 on request)
         self.FD_ORDER = 2
@@ -264,14 +315,9 @@ class Denise:
         self.SEISMO = 1
         self.ITERMAX = 1
         self.DATA_DIR = None
-        self.SEIS_FILE_VX = None
-        self.SEIS_FILE_VY = None
-        self.VPUPPERLIM = 6000.0
-        self.VPLOWERLIM = 0.0
-        self.VSUPPERLIM = 4000.0
-        self.VSLOWERLIM = 0.0
-        self.RHOUPPERLIM = 3000.0
-        self.RHOLOWERLIM = 1000.0
+        for k, v in (("SEIS_FILE_VX", None), ("SEIS_FILE_VY", None), ("VPUPPERLIM", 6000.0), ("VPLOWERLIM", 0.0),
+                     ("VSUPPERLIM", 4000.0), ("VSLOWERLIM", 0.0), ("RHOUPPERLIM", 3000.0), ("RHOLOWERLIM", 1000.0)):
+            object.__setattr__(self, k, v)
         self.SWS_TAPER_GRAD_HOR = 0
         self.EXP_TAPER_GRAD_HOR = 2.0
         self.GRADT1, self.GRADT2, self.GRADT3, self.GRADT4 = 21, 25, 490, 500
@@ -436,6 +482,11 @@ class Denise:
                 self.load_observed_su(len(src))
             else:
                 raise MifwiError("no observed data: call set_observed(vx, vy) or set DATA_DIR")
+        if int(self.ITERMAX) != 1:
+            raise MifwiError("ITERMAX=%s: grad() is one gradient evaluation (the reference sets ITERMAX = 1 and lets its "
+                             "own optimiser update the model)" % self.ITERMAX)
+        if int(self.INVMAT1) not in (1, 2, 3):
+            raise MifwiError("INVMAT1=%s not implemented (1: Vp, Vs, rho; 2: Zp, Zs, rho; 3: lambda, mu, rho)" % self.INVMAT1)
         dev, h, dt, nt, g, f, pz, px, fw, fsurf = self._setup(model, src, rec)
         prm, mat = self._materials(model, dev, dt, h, True, fsurf)
         vx, vy, p = self._propagate(mat, f.to(dev), pz, px, g, fw, fsurf, h)
@@ -468,11 +519,15 @@ class Denise:
             fh.write("%e\n" % self.loss)
         # re-apply the caller's flipud convention on the way out
         grads = [p.grad.detach() for p in prm]
+        if int(self.INVMAT1) != 1:
+            # the same objective differentiated with respect to (Zp, Zs, rho) or (lambda, mu, rho): exact chain rule of
+            # the change of variables, one launch (csrc/mifwi_materials.hip: mifwi_elastic_gradient_parametrization)
+            grads = list(elastic.gradient_parametrization([q.detach() for q in prm], grads, int(self.INVMAT1)))
         if int(self.SWS_TAPER_GRAD_HOR) == 1:
             w = torch.tensor(gradient_taper(model.ny, h, self.GRADT1, self.GRADT2, self.GRADT3, self.GRADT4,
                                             self.EXP_TAPER_GRAD_HOR), device=dev)[:, None]
             grads = [g * w for g in grads]
-        self._gradients_dev = torch.stack(grads)           # [vp, vs, rho] on the device, row 0 = surface
+        self._gradients_dev = torch.stack(grads)           # [vp, vs, rho] (INVMAT1 = 2: Zp, Zs, rho; 3: lambda, mu, rho), row 0 = surface
         gvp, gvs, grho = (np.flipud(g.cpu().numpy()).copy() for g in grads)
         self._gradients = {"rho": grho, "vp": gvp, "vs": gvs}
         self.DT_used = dt
@@ -480,7 +535,8 @@ class Denise:
 
     def get_fwi_gradients(self, keys=("seis",), return_filenames=False):
         """Arrays in filename order: jacobian/..._rho, ..._vp, ..._vs  =>  [rho, vp, vs]
-        (the order models/networks.py:7800-7802 indexes)."""
+        (the order models/networks.py:7800-7802 indexes).  With INVMAT1 = 2 / 3 the "vp" and "vs" files hold the
+        gradients with respect to Zp, Zs / lambda, mu - DENISE keeps the file names (networks.py:11108-11110)."""
         if self._gradients is None:
             raise MifwiError("run grad() first")
         names = ["jacobian/gradient_seis_rho.bin", "jacobian/gradient_seis_vp.bin",

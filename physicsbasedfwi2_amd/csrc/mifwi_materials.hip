@@ -128,6 +128,25 @@ __global__ __launch_bounds__(kMT) void materials_vjp(const float *vp, const floa
     grho[k] = drho + dlam * p * p + dmu * q * q;
 }
 
+// DENISE's INVMAT1: gradients with respect to (Vp, Vs, rho) -> (Zp, Zs, rho) or (lambda, mu, rho); include/mifwi.h
+template <int MODE>
+__global__ __launch_bounds__(kMT) void reparam_vjp(const float *vp, const float *vs, const float *rho, const float *gvp,
+                                                   const float *gvs, const float *grho, float *oa, float *ob, float *orho, long long n)
+{
+    const long long k = (long long)blockIdx.x * kMT + threadIdx.x;
+    if (k >= n) return;
+    const float p = vp[k], q = vs[k], r = rho[k], a = gvp[k], b = gvs[k], c = grho[k];
+    if (MODE == 2) {
+        oa[k] = a / r;
+        ob[k] = b / r;
+        orho[k] = c - (p * a + q * b) / r;
+    } else {
+        oa[k] = a / (2.0f * r * p);
+        ob[k] = a / (r * p) + (q == 0.f ? 0.f : b / (2.0f * r * q));
+        orho[k] = c - (p * a + q * b) / (2.0f * r);
+    }
+}
+
 // ---- scalar scheme: vp [nz][nx] -> r [nz + 2 pad][nx + 2 pad] = (vp dt / h)^2, the model replicated into the absorbing
 // layer (what the deepwave-shaped shim computes per call: compat/deepwave/scalar.py) ------------------------------------
 __global__ __launch_bounds__(kMT) void coef_fwd(const float *vp, float *r, int nz, int nx, int pad, float c)
@@ -185,6 +204,30 @@ int mifwi_acoustic_coefficients_vjp(int device, const float *vp, const float *gr
     return MIFWI_OK;
 }
 
+
+int mifwi_elastic_gradient_parametrization(int device, int32_t parametrization, const float *vp, const float *vs, const float *rho,
+                                           const float *grad_vp, const float *grad_vs, const float *grad_rho, float *out_a,
+                                           float *out_b, float *out_rho, int64_t n, void *stream)
+{
+    if (!vp || !vs || !rho || !grad_vp || !grad_vs || !grad_rho || !out_a || !out_b || !out_rho || n < 1)
+        return mifwi::fail(MIFWI_EINVAL, "mifwi_elastic_gradient_parametrization: bad argument");
+    if (parametrization < MIFWI_PARAM_VELOCITY || parametrization > MIFWI_PARAM_LAME)
+        return mifwi::fail(MIFWI_EINVAL, "parametrization %d: 1 = Vp/Vs/rho, 2 = Zp/Zs/rho, 3 = lambda/mu/rho", parametrization);
+    MIFWI_HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((n + kMT - 1) / kMT)), block(kMT);
+    if (parametrization == MIFWI_PARAM_VELOCITY) {
+        if (out_a != grad_vp) MIFWI_HIP_TRY(hipMemcpyAsync(out_a, grad_vp, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+        if (out_b != grad_vs) MIFWI_HIP_TRY(hipMemcpyAsync(out_b, grad_vs, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+        if (out_rho != grad_rho) MIFWI_HIP_TRY(hipMemcpyAsync(out_rho, grad_rho, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+    } else if (parametrization == MIFWI_PARAM_IMPEDANCE) {
+        hipLaunchKernelGGL(reparam_vjp<2>, grid, block, 0, st, vp, vs, rho, grad_vp, grad_vs, grad_rho, out_a, out_b, out_rho, (long long)n);
+    } else {
+        hipLaunchKernelGGL(reparam_vjp<3>, grid, block, 0, st, vp, vs, rho, grad_vp, grad_vs, grad_rho, out_a, out_b, out_rho, (long long)n);
+    }
+    MIFWI_HIP_TRY(hipGetLastError());
+    return MIFWI_OK;
+}
 
 int mifwi_elastic_materials(int device, const float *vp, const float *vs, const float *rho, float *out, int32_t nz, int32_t nx,
                             float dt_over_h, int32_t free_surface, void *stream)

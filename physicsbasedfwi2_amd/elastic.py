@@ -86,6 +86,26 @@ class _MaterialsFn(torch.autograd.Function):
         return grads[0], grads[1], grads[2], None, None
 
 
+PARAM_VELOCITY, PARAM_IMPEDANCE, PARAM_LAME = 1, 2, 3
+
+
+def gradient_parametrization(prm, grads, mode):
+    """Gradients with respect to (Vp, Vs, rho) -> the parameter set DENISE calls INVMAT1 (``models/networks.py:11025``):
+    1 unchanged, 2 (Zp = rho Vp, Zs = rho Vs, rho), 3 (lambda, mu, rho).  ``prm`` = (vp, vs, rho), ``grads`` = the three
+    gradients, float32 tensors of one shape on a HIP device; returns three new tensors.  One launch
+    (``mifwi_elastic_gradient_parametrization``): the 3 x 3 Jacobian of the change of variables cell by cell."""
+    vp, vs, rho = (t.detach().contiguous().float() for t in prm)
+    gv, gs, gr = (t.detach().contiguous().float() for t in grads)
+    if not vp.is_cuda:
+        raise MifwiError("gradient_parametrization: tensors must live on a HIP device (libmifwi has no CPU fallback)")
+    out = [torch.empty_like(vp) for _ in range(3)]
+    with torch.cuda.device(vp.device):
+        _lib.check(_lib.load().mifwi_elastic_gradient_parametrization(
+            vp.device.index or 0, int(mode), _lib.ptr(vp), _lib.ptr(vs), _lib.ptr(rho), _lib.ptr(gv), _lib.ptr(gs),
+            _lib.ptr(gr), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), vp.numel(), _stream()))
+    return tuple(out)
+
+
 def staggered_materials(vp, vs, rho, dt, h, free_surface=False):
     """[5, nz, nx] = lambda dt/h, (lambda+2mu) dt/h, mu_xz dt/h, dt/(h rho_x), dt/(h rho_z).
     With ``free_surface`` row 0 of the first two planes is put in the effective form the

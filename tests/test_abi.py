@@ -32,7 +32,7 @@ def test_header_symbols_exported_and_bound():
         assert len(_lib.SIGNATURES[name][1]) == nargs, name
     for name in _lib.SIGNATURES:
         assert name in decl, "%s bound but not declared in mifwi.h" % name
-    assert lib.mifwi_version() == 6
+    assert lib.mifwi_version() == 7
 
 
 def test_struct_layouts_match_header(tmp_path):

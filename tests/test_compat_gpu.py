@@ -112,6 +112,83 @@ def test_denise_grad_protocol_and_directional_derivative(tmp_path, monkeypatch):
         d5.grad(model, src, rec)
 
 
+def test_denise_impedance_and_lame_parameterisations(tmp_path, monkeypatch):
+    """models/networks.py:10899-11110 (AutoElMarmousiMarZp22_Net.prop): the attribute assignments of that prop() re-typed,
+    `d.INVMAT1 = 2` among them, then `d.grad`, `np.loadtxt('loss_curve_grad.out')`, `d.get_fwi_gradients(['seis'])` with
+    grads[1] / grads[2] read as the "vp" / "vs" gradients - which in that parameterisation are the gradients with respect
+    to Zp = rho Vp and Zs = rho Vs.  Checked: (1) composition - they equal the Vp / Vs / rho gradients pushed through the
+    3 x 3 Jacobian of the change of variables in float64; (2) they ARE the derivative of the objective along a
+    perturbation of Zp at fixed Zs, rho (central difference of d.grad's own loss); (3) the same for INVMAT1 = 3
+    (lambda, mu, rho), water cells included (mu has no Vs term there)."""
+    api, d, (vp, vs, rho), dx, src, rec = _denise_setup(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    d.verbose = 0
+    d.VPUPPERLIM, d.VPLOWERLIM, d.VSUPPERLIM, d.VSLOWERLIM = 4509.0, 1500.0, 2603.0, 0.0      # networks.py:11035-11040
+    d.RHOUPPERLIM, d.RHOLOWERLIM = 2589.0, 1009.0
+    d.SWS_TAPER_GRAD_HOR = 0
+    true = api.Model(np.flipud(vp * 1.03), np.flipud(vs * 0.98), np.flipud(rho * 1.01), dx)
+    ox, oy = d.forward(true, src, rec)
+    obs = (np.transpose(ox, (0, 2, 1)), np.transpose(oy, (0, 2, 1)))
+    d.set_observed(*obs)
+    d.fwi_stages = []
+    d.add_fwi_stage(fc_low=0.0, fc_high=10.0)
+    model = api.Model(np.flipud(vp), np.flipud(vs), np.flipud(rho), dx)
+    os.system("rm -rf loss_curve_grad.out")
+    d.grad(model, src, rec)
+    loss1 = float(np.loadtxt("loss_curve_grad.out"))
+    assert loss1 > 0 and np.isclose(loss1, d.loss, rtol=1e-5)
+    g_rho, g_vp, g_vs = (np.flipud(np.array(g)).astype(np.float64) for g in d.get_fwi_gradients(["seis"]))
+    P, Q, R = vp.astype(np.float64), vs.astype(np.float64), rho.astype(np.float64)
+
+    def run(mode, m=None):
+        dd = api.Denise(None, 0)
+        for k in ("TIME", "DT", "FREE_SURF", "FW", "FPML", "DAMPING", "PHYSICS", "ITERMAX"):
+            setattr(dd, k, getattr(d, k))
+        dd.INVMAT1 = mode
+        dd.set_observed(*obs)
+        dd.add_fwi_stage(fc_low=0.0, fc_high=10.0)
+        loss = dd.grad(model if m is None else api.Model(*[np.flipud(a.astype(np.float32)) for a in m], dx), src, rec)
+        grads, names = dd.get_fwi_gradients(["seis"], return_filenames=True)
+        assert [n.split("_")[-1] for n in names] == ["rho.bin", "vp.bin", "vs.bin"]
+        return loss, [np.flipud(np.array(g)).astype(np.float64) for g in grads]
+
+    # (1) impedances: the same loss, gradients = J^T of (Zp, Zs, rho) -> (Vp, Vs, rho)
+    loss2, (z_rho, z_p, z_s) = run(2)
+    assert loss2 == d.loss                       # the same objective, bit for bit: only the gradients change variables
+    assert rel_l2(z_p, g_vp / R) < 2e-6 and rel_l2(z_s, g_vs / R) < 2e-6
+    assert rel_l2(z_rho, g_rho - (P * g_vp + Q * g_vs) / R) < 2e-5
+    # (2) ... and the derivative of the objective along dZp at fixed Zs, rho: Vp changes by dZp / rho
+    dz = np.zeros_like(P)
+    dz[20:40, 30:60] = 6.0e4
+    eps = 0.5
+    lin = float(np.sum(z_p * dz))
+    fd = (run(2, (P + eps * dz / R, Q, R))[0] - run(2, (P - eps * dz / R, Q, R))[0]) / (2 * eps)
+    assert abs(fd - lin) <= 0.03 * abs(fd), (fd, lin)
+    # density at fixed impedances: Vp = Zp / rho and Vs = Zs / rho move with it
+    dr = np.zeros_like(P)
+    dr[22:38, 32:58] = 40.0
+    lin = float(np.sum(z_rho * dr))
+    fd = (run(2, (P * R / (R + eps * dr), Q * R / (R + eps * dr), R + eps * dr))[0]
+          - run(2, (P * R / (R - eps * dr), Q * R / (R - eps * dr), R - eps * dr))[0]) / (2 * eps)
+    assert abs(fd - lin) <= 0.05 * abs(fd), (fd, lin)
+    # (3) Lame parameters, water included (Vs = 0 on the first eight rows)
+    _, (l_rho, l_lam, l_mu) = run(3)
+    qs = np.where(Q == 0, 1.0, Q)
+    assert rel_l2(l_lam, g_vp / (2 * R * P)) < 2e-6
+    assert rel_l2(l_mu, g_vp / (R * P) + np.where(Q == 0, 0.0, g_vs / (2 * R * qs))) < 2e-6
+    assert rel_l2(l_rho, g_rho - (P * g_vp + Q * g_vs) / (2 * R)) < 2e-5
+    assert np.isfinite(l_mu).all() and np.abs(l_mu[:8]).max() > 0
+    # what the shim does not serve is refused, not ignored
+    with pytest.raises(api.MifwiError):
+        d.INVMAT1 = 4
+        d.grad(model, src, rec)
+    d.INVMAT1 = 1
+    with pytest.raises(AttributeError):
+        d.INVMAT_1 = 2                           # a typo is not a parameter
+    with pytest.raises(api.MifwiError):
+        d.TIMEWIN = 1                            # changes the gradient, not built
+
+
 def test_denise_free_surface_default_runs(oracle32, tmp_path):
     """pyapi default FREE_SURF=1 (what networks.py:7698-7731 leaves untouched, SEAM sets it at 9811)."""
     api, d, (vp, vs, rho), dx, src, rec = _denise_setup(tmp_path)

@@ -8,3 +8,39 @@ def test_fd_order_default_is_the_upstream_one():
     d = api.Denise("/nonexistent", verbose=0)
     assert d.FD_ORDER == 2
     assert d.PHYSICS == 1 and d.QUELLART == 1 and d.QUELLTYP == 1 and d.SEISMO == 1
+
+
+def test_assignments_are_classified_not_swallowed():
+    """`d.NAME = value` on the shim: served parameters are stored, DENISE parameters without effect on one gradient
+    evaluation are stored with ONE warning, parameters that would change the result accept their neutral value only,
+    anything else (a typo) raises - the reference configures DENISE by assignment alone (networks.py:11011-11043)."""
+    import warnings
+    import pytest
+    import physicsbasedfwi2_amd.compat.pyapi_denise as api
+    d = api.Denise(None, 0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # the constructor's own defaults warn about nothing
+        d2 = api.Denise(None, 0)
+        d2.PHYSICS, d2.ITERMAX, d2.TIME, d2.INVMAT1, d2.FD_ORDER = 1, 1, 5.0, 2, 4
+        d2.fwi_stages = []
+        d2.add_fwi_stage(fc_low=0.0, fc_high=5.0)
+    assert d2.INVMAT1 == 2 and d2.NPROCX == 1
+    api._warned.discard("NPROCX")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        d.NPROCX = 6
+        d.NPROCX = 5                                        # once per name
+    assert d.NPROCX == 5 and len([x for x in w if "NPROCX" in str(x.message)]) == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        d.VPUPPERLIM, d.SEIS_FILE_VX, d.JACOBIAN = 4509.0, "su/seis_x.su", "jacobian/jacobian_Test"
+    assert d.VPUPPERLIM == 4509.0
+    d.TIMEWIN = 0
+    with pytest.raises(api.MifwiError):
+        d.TIMEWIN = 1
+    with pytest.raises(api.MifwiError):
+        d.SWS_TAPER_GRAD_SOURCES = 1
+    for typo in ("INVMAT_1", "FREESURF", "Physics", "QUELART"):
+        with pytest.raises(AttributeError):
+            setattr(d, typo, 1)
+    d._private_note = 3                                     # the shim's own state
