@@ -86,6 +86,7 @@ struct ElParams {
     int tiles_z;
     int walk_rows;               // el_adj_walk: rows of a column chunk (a multiple of 14)
     float *trash;                // el_adj_walk: 1024 floats that lanes without an owned cell store to (stores stay branch-free)
+    long long *walk_trace;       // -DMIFWI_ABLATIONS builds: [block][8] cycles per phase (tools/walk_trace.sh)
     int walk_dbg;                // -DMIFWI_ABLATIONS builds: streams switched off for traffic / timing experiments (wrong results)
     int xcd;                     // 1: XCD-contiguous tile order (xcd_tile)
     FdK K;                       // stencil weights
@@ -2011,8 +2012,36 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
 #endif
             const int ex = want_f ? mifwi::ceil_div(mifwi::ceil_div(ps.gs * ps.nsmp, kThreads), tx) : 0;
             const size_t lds = walk_lds_bytes(ps.gs);
+#ifdef MIFWI_ABLATIONS
+            const char *trace_path = getenv("MIFWI_WALK_TRACE");
+            const size_t trace_n = (size_t)tx * pl->walk_chunks * cg * 8;
+            ps.walk_trace = nullptr;
+            if (trace_path && *trace_path && n == n_lo) {          // the last step of the range: caches warm
+                MIFWI_HIP_TRY(hipMalloc(&ps.walk_trace, trace_n * sizeof(long long)));
+                MIFWI_HIP_TRY(hipMemsetAsync(ps.walk_trace, 0, trace_n * sizeof(long long), st));
+            }
+#endif
             if (pl->snap_bf16) hipLaunchKernelGGL(el_adj_walk<true>, dim3(tx, pl->walk_chunks + ex, cg), dim3(kThreads), lds, st, ps);
             else hipLaunchKernelGGL(el_adj_walk<false>, dim3(tx, pl->walk_chunks + ex, cg), dim3(kThreads), lds, st, ps);
+#ifdef MIFWI_ABLATIONS
+            if (ps.walk_trace) {
+                std::vector<long long> h(trace_n);
+                MIFWI_HIP_TRY(hipStreamSynchronize(st));
+                MIFWI_HIP_TRY(hipMemcpy(h.data(), ps.walk_trace, trace_n * sizeof(long long), hipMemcpyDeviceToHost));
+                MIFWI_HIP_TRY(hipFree(ps.walk_trace));
+                double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (size_t i = 0; i < trace_n; ++i) sum[i & 7] += (double)h[i];
+                if (FILE *fp = fopen(trace_path, "a")) {
+                    // per item, mean over workgroups: A | barrier | B | barrier | C | barrier ; items ; whole kernel per workgroup
+                    const double items = sum[6] > 0 ? sum[6] : 1.0, wgs = (double)(trace_n / 8);
+                    fprintf(fp, "el_adj_walk wgs %.0f items/wg %.1f cycles/item: A %.0f bar %.0f B %.0f bar %.0f C %.0f bar %.0f | kernel cycles/wg %.0f\n",
+                            wgs, items / wgs, sum[0] / items, sum[1] / items, sum[2] / items, sum[3] / items, sum[4] / items,
+                            sum[5] / items, sum[7] / wgs);
+                    fclose(fp);
+                }
+                ps.walk_trace = nullptr;
+            }
+#endif
             continue;
         }
         if (pl->fused_adj) {

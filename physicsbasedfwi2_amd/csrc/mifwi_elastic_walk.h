@@ -82,8 +82,10 @@ __device__ __forceinline__ Row8 wk_row8(const float *plane, const WLane &L, int 
 
 #ifdef MIFWI_ABLATIONS
 #define WK_DBG(bit) (p.walk_dbg & (bit))      // 1: no snapshot loads, 2: no accumulator traffic, 4: no sigma_bar loads,
+#define WK_STAMP(i) do { if (p.walk_trace) { const long long now_ = __builtin_amdgcn_s_memtime(); tr_[i] += now_ - tr_t; tr_t = now_; } } while (0)
 #else                                          // 8: no v_bar loads, 16: no state stores, 32: no material loads
 #define WK_DBG(bit) 0
+#define WK_STAMP(i) do { } while (0)
 #endif
 template <bool BF16>
 __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const ElParams p)
@@ -126,6 +128,10 @@ __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const 
     const int z0 = by * p.walk_rows, z1 = min(p.nz, z0 + p.walk_rows);
     const int nk = (z1 - z0 + WTZ - 1) / WTZ;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef MIFWI_ABLATIONS
+    long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = 0, tr_0 = 0;
+    if (p.walk_trace) tr_0 = __builtin_amdgcn_s_memtime();
+#endif
     const long long acc_group = (long long)(p.s0 / p.gs + bz) * 5 * ncell;
     const int sfirst = p.s0 + bz * p.gs;
     const int ns = min(p.gs, p.nshot - sfirst);
@@ -205,6 +211,9 @@ __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const 
             float *fout = p.fields_out + (long long)s * p.shot_stride;
             float *cs = carry + si * kWCarry;
             const bool last = si + 1 == ns;
+#ifdef MIFWI_ABLATIONS
+            if (p.walk_trace) { tr_t = __builtin_amdgcn_s_memtime(); tr_[6] += 1; }
+#endif
             // ---- operands of phase B: requested now, used behind the first barrier; those of phase A were requested
             //      during the item before, in front of its stores ------------------------------------------------------
             request_B(s, snap_cell(p, min(max(rowB, 0), p.nz - 1), go), ooB);
@@ -232,7 +241,9 @@ __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const 
                     sts4(work + kWE1 + L.cx + (iA - 2) * L.cstr, e1); sts4(work + kWE4 + L.cx + (iA - 2) * L.cstr, e4);
                 }
             }
+            WK_STAMP(0);
             __syncthreads();
+            WK_STAMP(1);
             // ---- B: v_bar', gradients, D of rows z0 + 14k + 2 .. + 15 ------------------------------------------------
             if (k >= 0 && cp_on) sts4(work + kWD2 + cp_rest, lds4(cs + kWCarryHalf + cp_car));
             float4 nx4, nz4;
@@ -294,7 +305,9 @@ __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const 
                 st4(wk_at(fout + F_VX * fs, o), nx4);
                 st4(wk_at(fout + F_VZ * fs, o), nz4);
             }
+            WK_STAMP(2);
             __syncthreads();
+            WK_STAMP(3);
             // ---- C: sigma_bar' of rows z0 + 14k .. + 13; the planes' last rows go to the carry area -------------------
             if (cp_on) {
                 sts4(cs + cp_car, lds4(work + cp_save));
@@ -334,7 +347,9 @@ __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const 
                 st4(wk_at(fout + F_SZZ * fs, o), make_float4(nzz[0], nzz[1], nzz[2], nzz[3]));
                 st4(wk_at(fout + F_SXZ * fs, o), make_float4(nxz[0], nxz[1], nxz[2], nxz[3]));
             }
+            WK_STAMP(4);
             __syncthreads();          // the work planes are reused by the next item
+            WK_STAMP(5);
         }
         if (!WK_DBG(2)) {
 #pragma unroll
@@ -344,4 +359,11 @@ __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const 
             }
         }
     }
+#ifdef MIFWI_ABLATIONS
+    if (p.walk_trace && t == 0) {
+        long long *o = p.walk_trace + 8 * ((long long)bx + (long long)gridDim.x * (by + (long long)p.tiles_z * bz));
+        tr_[7] = __builtin_amdgcn_s_memtime() - tr_0;
+        for (int i = 0; i < 8; ++i) o[i] = tr_[i];
+    }
+#endif
 }
