@@ -157,9 +157,9 @@ class AcousticMarmousi:
         import physicsbasedfwi2_amd.compat.deepwave as deepwave
         from physicsbasedfwi2_amd import misfit
         self.torch, self.deepwave, self.dev, self.misfit = torch, deepwave, dev, misfit
-        # absorbing="cpml" (or BENCH_ABSORBING=cpml): the deepwave-shaped shim's second-order C-PML - `pml_width` is then
-        # what it is in deepwave, the width of a PML - instead of the reference's in-tree sponge
-        self.absorbing = absorbing or os.environ.get("BENCH_ABSORBING", "sponge")
+        # absorbing="cpml" (the shim's default): `pml_width` is what it is in deepwave, the width of a PML (second-order
+        # C-PML); "sponge" (or BENCH_ABSORBING=sponge): the reference's in-tree damping layer, the shim's opt-out
+        self.absorbing = absorbing or os.environ.get("BENCH_ABSORBING", "cpml")
         if os.environ.get("BENCH_PML_WIDTH"):
             self.pml = int(os.environ["BENCH_PML_WIDTH"])
         self.full_nt = type(self).nt
@@ -174,8 +174,7 @@ class AcousticMarmousi:
             ns = hi - lo
         if grid or shots or nt or span:
             self.name = "acoustic_%dx%d_%dshots_%dsteps" % (self.nz, self.nx, total if span else ns, self.nt)
-        if self.absorbing != "sponge":
-            self.name += "_%s%d" % (self.absorbing.replace("-", ""), self.pml)
+        self.name += "_%s%d" % (self.absorbing.replace("-", ""), self.pml)
         self.ns = ns
         xs_all = np.linspace(0.0, (self.nx - 1) * self.h, total)
         xs = xs_all[lo:lo + ns]
@@ -198,7 +197,7 @@ class AcousticMarmousi:
 
     @property
     def profile_key(self):
-        return "acoustic_%dx%d" % (self.nz, self.nx) + ("" if self.absorbing == "sponge" else "_" + self.absorbing)
+        return "acoustic_%dx%d" % (self.nz, self.nx) + ("" if self.absorbing == "sponge" else "_" + self.absorbing)   # keys of profiles/*.json
 
     @property
     def interior_cells(self):
@@ -279,7 +278,7 @@ class AcousticMarmousi:
 
         cpml = self.absorbing == "cpml"
         if cpml:                                   # the layer the GPU path runs: oracle/acoustic_cpml.c, same tables
-            vmax, fpml = float(vp.max()), 0.25 / dt / 5.0
+            vmax, fpml = 50.0 * np.ceil(float(vp.max()) / 50.0 - 1e-9), 0.25 / dt / 5.0      # scalar._pml_velocity
             ab0 = np.stack(H.cpml_profiles(N0, P, h, dt, vmax, fpml)[:2])
             ab1 = np.stack(H.cpml_profiles(N1, P, h, dt, vmax, fpml)[:2])
 

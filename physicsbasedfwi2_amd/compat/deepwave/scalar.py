@@ -7,18 +7,20 @@
 Conventions kept from deepwave: locations are physical units in the model tensor's dimension
 order (z, x); cell = trunc(loc/dx); the source term is scaled by vp^2 dt^2; the internal time
 step is dt/ceil(dt/dt_max) with band-limited resampling of the wavelet and decimation of the
-traces.  Conventions that are this library's own (deepwave's binaries are not available to
-pin against): the absorbing layer is the reference's in-tree sponge
-(seisgan/fwi/pde/seismic/model.py:6-29), `pml_width` cells wide (default 20), the model is
-edge-replicated into it, and rec[n] samples the field before step n.
+traces; ``pml_width`` is the width of a PML (default 20 cells), the model edge-replicated into it.
+deepwave's own PML arithmetic cannot be pinned (its binaries are not available): the layer
+is the published second-order convolutional PML inside the same scalar scheme (memory variables psi, zeta on the
+layer's cells only; exact transposed adjoint; csrc/mifwi_acoustic_cpml.h, oracle/acoustic_cpml.c), and rec[n]
+samples the field before step n.  The 20-cell layer returns 1.6e-4 of the direct wave
+(tests/test_acoustic_cpml_oracle.py); inside the model the scheme is the undamped one bit for bit.  Both kernel
+families carry it.  ``pml_freq`` (Hz) sets the frequency shift of the layer (default: a fifth of the source band's
+upper end, 0.25 / dt / 5); the damping profile scales with the model's maximum velocity rounded UP to the next
+50 m/s (or ``vpmax`` when given), so that the layer does not change from one FWI iteration to the next with the
+last digits of the model.
 
-``Propagator(..., absorbing="cpml")`` makes ``pml_width`` what it is in deepwave - the width of a PML: a second-order
-convolutional PML inside the same scalar scheme (memory variables psi, zeta on the layer's cells only; exact
-transposed adjoint; csrc/mifwi_acoustic_cpml.h, oracle/acoustic_cpml.c).  The 20-cell layer returns 1.6e-4 of the
-direct wave where the 20-cell sponge returns 4e-2 (tests/test_acoustic_cpml_oracle.py); inside the model the two
-modes are the same scheme bit for bit.  Both kernel families carry it (2.6-4.3x the sponge's time
-on Marmousi-sized grids); the sponge stays the default because it is the reference's in-tree absorbing layer.
-``pml_freq`` (Hz) sets the frequency shift of the layer (default: a fifth of the source band's upper end, 0.25 / dt / 5).
+``Propagator(..., absorbing="sponge")`` is the opt-out: the reference's in-tree damping layer
+(seisgan/fwi/pde/seismic/model.py:6-29) instead of a PML - 2.6-4.3x faster on Marmousi-sized grids (DESIGN.md
+section 3), but it returns 4e-2 of the direct wave at 20 cells.  (Until round 3 it was the default.)
 
 ``absorbing="cpml-staggered"`` (round 2's C-PML) advances the scalar equation as the first-order pressure-velocity
 system on the staggered grid - the P-SV solver of this library in a fluid (Vs = 0, rho = 1) with its C-PML on every
@@ -161,13 +163,19 @@ def _sponge(n, width, d, h, dt, device):
 
 
 @functools.lru_cache(maxsize=32)
-def _cpml_ab(n, width, d, dt, vmax, fpml):
-    """a and b profiles of one axis of the second-order C-PML: [2, n], zero outside the layer."""
-    return torch.from_numpy(profiles.cpml_tables(n, width, d, dt, vmax, fpml)[:2].copy()).float()
+def _cpml_ab(n, width, d, dt, vkey, fpml, device):
+    """a and b profiles of one axis of the second-order C-PML as a device tensor: [2, n], zero outside the layer.
+    `vkey`: the velocity the damping scales with (_pml_velocity): the cache hits from one iteration to the next."""
+    return torch.from_numpy(profiles.cpml_tables(n, width, d, dt, vkey, fpml)[:2].copy()).float().to(device)
+
+
+def _pml_velocity(vmax):
+    """Velocity the C-PML damping profile scales with: the model's maximum rounded up to the next 50 m/s."""
+    return 50.0 * math.ceil(vmax / 50.0 - 1e-9)
 
 
 class Propagator(torch.nn.Module):
-    def __init__(self, model, dx, pml_width=None, survey_pad=None, vpmax=None, absorbing="sponge", pml_freq=None,
+    def __init__(self, model, dx, pml_width=None, survey_pad=None, vpmax=None, absorbing="cpml", pml_freq=None,
                  cfl="stability"):
         super().__init__()
         if absorbing not in ("sponge", "cpml", "cpml-staggered"):
@@ -252,7 +260,8 @@ class Propagator(torch.nn.Module):
         rc, rw = _cells(receiver_locations, self.spacing, P, n1, dev)
         if self.absorbing == "cpml" and P > 0:
             fpml = float(self.pml_freq) if self.pml_freq is not None else 0.25 / abs(dt) / 5.0
-            ab0, ab1 = _cpml_ab(n0, P, dz, dti, vmax, fpml), _cpml_ab(n1, P, dx, dti, vmax, fpml)
+            vkey = float(self.vpmax) if self.vpmax is not None else _pml_velocity(vmax)
+            ab0, ab1 = _cpml_ab(n0, P, dz, dti, vkey, fpml, str(dev)), _cpml_ab(n1, P, dx, dti, vkey, fpml, str(dev))
             rec = acoustic.propagate(r, f, ab0, ab1, sc, sw, rc, rw, (h / dz) ** 2, (h / dx) ** 2,
                                      shots_per_group=self.shots_per_group, cpml_width=P)
             return rec[::ratio] if ratio > 1 else rec

@@ -88,7 +88,7 @@ struct ElParams {
     float *trash;                // el_adj_walk: 1024 floats that lanes without an owned cell store to (stores stay branch-free)
     long long *walk_trace;       // -DMIFWI_ABLATIONS builds: [block][8] cycles per phase (tools/walk_trace.sh)
     int walk_dbg;                // -DMIFWI_ABLATIONS builds: streams switched off for traffic / timing experiments (wrong results)
-    int xcd;                     // 1: XCD-contiguous tile order (xcd_tile)
+    int xcd;                     // XCD-aware tile order (xcd_tile): 1 contiguous runs per shot, 2 whole shots, 3 tile-major over the shots
     FdK K;                       // stencil weights
 };
 
@@ -218,7 +218,18 @@ __device__ __forceinline__ void xcd_tile(const ElParams &p, int &bx, int &by, in
     const unsigned gx = gridDim.x, n2 = gx * gridDim.y;
     const unsigned z8 = gridDim.z & ~7u;          // p.xcd == 2: whole slices per XCD
     unsigned T;
-    if (p.xcd == 2 && blockIdx.z < z8) {
+    if (p.xcd == 3) {
+        // tile-major, slice-minor: the sequence (tile 0: slices 0 .. gz-1), (tile 1: ...), ... is cut into eight
+        // contiguous pieces, one per XCD - all shots of the launch pass through a tile back to back on ONE XCD, so the
+        // tile's material planes come from memory once per launch, not once per shot (grids whose five planes outgrow the
+        // L2s: 60 MB at 1000x3000), and neighbouring tiles still follow each other on that XCD
+        const unsigned gz = gridDim.z, total = n2 * gz;
+        const unsigned L = blockIdx.x + gx * blockIdx.y + n2 * blockIdx.z;
+        const unsigned c = L & 7u, idx = L >> 3, q = total >> 3, r = total & 7u;
+        const unsigned e = c * q + (c < r ? c : r) + idx;
+        T = e / gz;
+        bz = (int)(e - T * gz);
+    } else if (p.xcd == 2 && blockIdx.z < z8) {
         const unsigned L = blockIdx.x + gx * blockIdx.y + n2 * blockIdx.z;
         const unsigned c = L & 7u, idx = L >> 3, zl = idx / n2;
         T = idx - zl * n2;
@@ -1485,7 +1496,10 @@ int mifwi_elastic_plan_create(mifwi_elastic_plan **plan, int device, const mifwi
     }
     { const int v = env_int("MIFWI_EL_LX", 0); if (v == 16 || v == 32 || v == 64) pl->lx = v; }
     pl->rz = 1;
-    pl->xcd = env_int("MIFWI_EL_XCD", 1);
+    // 3: tile-major, shots of the launch back to back through every tile (xcd_tile); 1: every XCD walks one contiguous run of
+    // the tiles of each shot; 2: whole shots per XCD.  Measured (r04): 350x1700 x 6 shots forward 43.5 -> 40.5 us per step
+    // with 3 against 1, adjoint pair and the 1000x3000 passes (2-3 shots per launch) unchanged
+    pl->xcd = env_int("MIFWI_EL_XCD", 3);
     int gs = d->shots_per_group;
     if (gs <= 0) gs = env_int("MIFWI_EL_GS", 4);
     if (gs <= 0) gs = 1;

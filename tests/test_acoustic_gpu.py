@@ -136,7 +136,7 @@ def test_deepwave_shim_matches_oracle(oracle32):
     x_r[:, :, 1] = (torch.arange(nr).float() * 25.0)[None, :]
     wav = deepwave.wavelets.ricker(12.0, nt, dt, 1 / 12.0).reshape(-1, 1, 1).repeat(1, ns, 1)
     vp = torch.tensor(vp_np, device=dev, requires_grad=True)
-    prop = deepwave.scalar.Propagator({"vp": vp}, dx, pml_width=P)
+    prop = deepwave.scalar.Propagator({"vp": vp}, dx, pml_width=P, absorbing="sponge")
     rec = prop(wav.to(dev), x_s.to(dev), x_r.to(dev), dt)
     obs = torch.tensor(rng.standard_normal((nt, ns, nr)).astype(np.float32), device=dev)
     pmax, _ = rec.abs().max(dim=0, keepdim=True)
@@ -288,7 +288,7 @@ def test_deepwave_shim_substeps_when_dt_exceeds_the_stability_limit(oracle32):
     x_r = torch.zeros(ns, nr, 2); x_r[:, :, 1] = (torch.arange(nr).float() * 30.0)[None, :]; x_r[:, :, 0] = 20.0
     wav = deepwave.wavelets.ricker(6.0, nt, dt, 1 / 6.0).reshape(-1, 1, 1).repeat(1, ns, 1)
     vp = torch.tensor(vp_np, device=dev, requires_grad=True)
-    rec = deepwave.scalar.Propagator({"vp": vp}, dx, pml_width=P)(wav.to(dev), x_s.to(dev), x_r.to(dev), dt)
+    rec = deepwave.scalar.Propagator({"vp": vp}, dx, pml_width=P, absorbing="sponge")(wav.to(dev), x_s.to(dev), x_r.to(dev), dt)
     assert rec.shape == (nt, ns, nr)
     ratio = max(1, int(math.ceil(dt / (shim.CFL_SAFETY * profiles.scalar_cfl_limit([dx, dx], float(vp_np.max()))) - 1e-9)))
     assert ratio >= 2

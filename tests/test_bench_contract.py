@@ -220,12 +220,19 @@ def test_gpus_without_a_launcher_starts_the_ranks_and_fails_loudly_when_one_fail
 
 def test_xcd_tile_order_is_a_bijection_with_contiguous_runs():
     """The per-step kernels remap blockIdx so that neighbouring tiles share an XCD's L2 (csrc: xcd_tile; launch
-    order modulo 8 = XCD).  Same arithmetic here: a permutation of the launch grid for every shape; z slices in
-    full sets of eight go WHOLE to one XCD each, in row-major tile order; in the remaining slices each XCD walks
-    one contiguous run of tiles."""
-    def remap(gx, gy, gz, x, y, z):
+    order modulo 8 = XCD).  Same arithmetic here: a permutation of the launch grid for every shape.  Mode 2: z slices in
+    full sets of eight go WHOLE to one XCD each, in row-major tile order; in the remaining slices (and in mode 1) each
+    XCD walks one contiguous run of tiles.  Mode 3 (default): the sequence tile-major / slice-minor is cut into eight
+    contiguous pieces - every XCD takes all slices of a tile back to back, tile after tile."""
+    def remap(mode, gx, gy, gz, x, y, z):
         n2, z8 = gx * gy, gz & ~7
-        if z < z8:
+        if mode == 3:
+            total = n2 * gz
+            L = x + gx * y + n2 * z
+            c, idx, q, r = L & 7, L >> 3, total >> 3, total & 7
+            e = c * q + min(c, r) + idx
+            T, bz = e // gz, e % gz
+        elif mode == 2 and z < z8:
             L = x + gx * y + n2 * z
             c, idx = L & 7, L >> 3
             zl = idx // n2
@@ -235,17 +242,25 @@ def test_xcd_tile_order_is_a_bijection_with_contiguous_runs():
             c, idx, q, r = L & 7, L >> 3, n2 >> 3, n2 & 7
             T, bz = c * q + min(c, r) + idx, z
         return T % gx, T // gx, bz, c
-    for gx, gy, gz in ((1, 1, 1), (3, 7, 1), (12, 2, 3), (47, 63, 1), (27, 22, 8), (27, 23, 17), (5, 3, 16)):
-        seen, per_xcd = set(), {}
-        for z in range(gz):
-            for y in range(gy):
-                for x in range(gx):
-                    bx, by, bz, c = remap(gx, gy, gz, x, y, z)
-                    assert 0 <= bx < gx and 0 <= by < gy and 0 <= bz < gz
-                    seen.add((bx, by, bz))
-                    per_xcd.setdefault((c, z >= (gz & ~7), bz), []).append(by * gx + bx)
-        assert len(seen) == gx * gy * gz
-        for (c, tail, bz), ts in per_xcd.items():
-            assert ts == list(range(ts[0], ts[0] + len(ts)))          # row-major, contiguous
-            if not tail:
-                assert len(ts) == gx * gy and bz % 8 == c              # the whole slice on one XCD
+    for mode in (1, 2, 3):
+        for gx, gy, gz in ((1, 1, 1), (3, 7, 1), (12, 2, 3), (47, 63, 1), (27, 22, 8), (27, 23, 17), (5, 3, 16)):
+            seen, per_xcd, seq = set(), {}, {}
+            for z in range(gz):
+                for y in range(gy):
+                    for x in range(gx):
+                        bx, by, bz, c = remap(mode, gx, gy, gz, x, y, z)
+                        assert 0 <= bx < gx and 0 <= by < gy and 0 <= bz < gz
+                        seen.add((bx, by, bz))
+                        per_xcd.setdefault((c, mode == 2 and z >= (gz & ~7), bz), []).append(by * gx + bx)
+                        seq.setdefault(c, []).append((by * gx + bx) * gz + bz)
+            assert len(seen) == gx * gy * gz
+            if mode == 3:
+                for c, es in seq.items():
+                    assert es == list(range(es[0], es[0] + len(es)))       # one contiguous piece of the tile-major sequence
+                continue
+            for (c, tail, bz), ts in per_xcd.items():
+                if mode == 2 and not tail and bz < (gz & ~7):
+                    assert ts == list(range(ts[0], ts[0] + len(ts)))
+                    assert len(ts) == gx * gy and bz % 8 == c              # the whole slice on one XCD
+                elif mode == 1 or tail:
+                    assert ts == list(range(ts[0], ts[0] + len(ts)))      # row-major, contiguous
