@@ -74,8 +74,9 @@ def _profile_record(fname, workload, kernel):
     if doc.get("csrc_sha16") != csrc_sha16():
         return None, "%s describes other kernels (csrc %s, now %s)" % (fname, doc.get("csrc_sha16"), csrc_sha16())
     rec = doc.get(workload, {}).get(kernel)
-    # the GPU box has no .git: a summary measured and read in the same call names its kernel sources instead
-    return (rec, doc.get("commit") or "csrc " + doc["csrc_sha16"]) if rec else (None, "workload not in " + fname)
+    # the tag names the kernel sources the summary was measured on (their fingerprint, which is what was just compared) -
+    # not a commit: the commit that holds a summary is by construction not the one it was measured at
+    return (rec, "csrc " + doc["csrc_sha16"]) if rec else (None, "workload not in " + fname)
 
 
 def measured_traffic(workload, kernel):
@@ -147,12 +148,12 @@ class AcousticMarmousi:
     name = "acoustic_marmousi_174x500_29shots_2000steps"
     nz, nx, h, dt, nt, freq = 174, 500, 10.0, 0.001, 2000, 8.0
     shots_per_gpu = 29
-    pml = 20
+    pml = 10                                   # the width `Propagator({'vp': m}, dx)` gets (networks.py:5408: none passed)
     fwd_bytes, adj_bytes = 16.0, 20.0          # SURVEY.md 8d algorithmic B / cell-step, one launch per step
     # an LDS-resident time loop only has to move the snapshot stream (G^n, 4 B/cell-step out, 4 back in)
     resident_fwd_bytes, resident_adj_bytes = 4.0, 4.0
 
-    def __init__(self, dev, rank, world, nt=None, shots=None, grid=None, span=None, absorbing=None):
+    def __init__(self, dev, rank, world, nt=None, shots=None, grid=None, span=None, absorbing=None, pml=None):
         import torch
         import physicsbasedfwi2_amd.compat.deepwave as deepwave
         from physicsbasedfwi2_amd import misfit
@@ -160,6 +161,8 @@ class AcousticMarmousi:
         # absorbing="cpml" (the shim's default): `pml_width` is what it is in deepwave, the width of a PML (second-order
         # C-PML); "sponge" (or BENCH_ABSORBING=sponge): the reference's in-tree damping layer, the shim's opt-out
         self.absorbing = absorbing or os.environ.get("BENCH_ABSORBING", "cpml")
+        if pml:
+            self.pml = int(pml)
         if os.environ.get("BENCH_PML_WIDTH"):
             self.pml = int(os.environ["BENCH_PML_WIDTH"])
         self.full_nt = type(self).nt
@@ -675,13 +678,15 @@ def cross_check(wl, name, dev, kw):
             "gradient_rel_l2": gr}
 
 
-def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, warmup=None, nt=None, absorbing=None):
+def run_workload(name, args, dev, rank, world, want_cpu, grid=None, steps=None, warmup=None, nt=None, absorbing=None, pml=None):
     import copy
     import torch
     import torch.distributed as dist
     kw = {}
     if absorbing:
         kw["absorbing"] = absorbing
+    if pml:
+        kw["pml"] = pml
     if grid or args.grid:
         kw["grid"] = grid or tuple(int(v) for v in args.grid.lower().split("x"))
     if steps is not None:                   # secondary workloads may time fewer passes (stated in their entry)
@@ -1081,11 +1086,13 @@ def main():
     out = run_workload(primary, args, dev, rank, world, want_cpu)
     also = []
     if args.workload is None and not args.no_also:
-        # C2 as the reference means it: `pml_width` is a PML (deepwave's Propagator; second-order C-PML, 20 cells)
+        # C2 as the reference calls it: Propagator({'vp': m}, dx) - a PML of deepwave's default width (second-order C-PML,
+        # 10 cells per side)
         also.append(run_workload("acoustic_marmousi", args, dev, rank, world, want_cpu, absorbing="cpml"))
-        # ... and with the in-tree sponge of seisgan's model.py:6-29 (the opt-out of the deepwave-shaped shim)
+        # ... and with the in-tree sponge of seisgan's model.py:6-29, 20 cells (the opt-out of the deepwave-shaped shim;
+        # rounds 1-3 quoted C2 with it)
         also.append(run_workload("acoustic_marmousi", args, dev, rank, world, False, steps=min(args.steps, 5), warmup=1,
-                                 absorbing="sponge"))
+                                 absorbing="sponge", pml=20))
         # BASELINE names no elastic grid - the same survey on the 10 m Marmousi-II grid 350x1700, where
         # the per-step kernels run HBM-bound and the 3000 snapshots do not fit (time checkpointing); fewer passes
         also.append(run_workload("elastic_marmousi", args, dev, rank, world, want_cpu, grid=(350, 1700),
@@ -1095,7 +1102,7 @@ def main():
         # (time-checkpointed; profiles/<round>_c5_full_length.json)
         also.append(run_workload("elastic_seam", args, dev, rank, world, False, steps=min(args.steps, 3), warmup=1, nt=90))
         if rank == 0:
-            also[1]["note"] = "C2 with the reference's in-tree sponge instead of a PML (Propagator(..., absorbing='sponge'))"
+            also[1]["note"] = "C2 with the reference's in-tree sponge, 20 cells, instead of a PML (Propagator(..., pml_width=20, absorbing='sponge'))"
             also[2]["note"] = "snapshots of all shots do not fit at full length: see kernels_note for how the pass is cut"
             also[3]["note"] = ("90-step sample of the 5000-step configuration (snapshots resident): kernel rates of the "
                                "1000x3000 grid; the full-length pass is in profiles/%s_c5_full_length.json" % PROFILE_ROUND)

@@ -6,6 +6,7 @@ models/networks.py:5464/5491 and ``FWILoss`` does at seisgan/fwi/layers.py:158-1
 All arithmetic happens in libmifwi.so (HIP); there is no CPU path here.
 """
 import ctypes
+import os
 
 import torch
 
@@ -71,7 +72,16 @@ def _stream():
 # Geometries already built from the caller's four tap tensors, when those live on the device (weak references + versions:
 # an entry is used only while the very same, unmodified tensor objects are passed again).  A training loop passes the same
 # acquisition every iteration: the validation of the cells (a host round trip that stalls the launch queue) is paid once.
+# What the key can see: the tensor OBJECT, its version counter, its storage address and shape.  What it cannot see: a
+# write that bypasses autograd's version counter (`t.data[...] = `, a kernel of another library writing through the raw
+# pointer) - a caller that edits an acquisition in place that way must pass a new tensor, or set MIFWI_NO_GEOM_CACHE=1
+# (every call then rebuilds and re-validates its geometry).  Negative cells are inactive taps by convention (the
+# kernels skip them), so the validation bounds the cells from above only.
 _GEOMETRIES = []
+
+
+def _geom_key(t):
+    return (t._version, t.data_ptr(), tuple(t.shape))
 
 
 class _Geometry:
@@ -81,14 +91,15 @@ class _Geometry:
     def get(cls, src_cell, src_w, rec_cell, rec_w, device):
         import weakref
         given = (src_cell, src_w, rec_cell, rec_w)
-        if not all(t.is_cuda for t in given):      # host tensors may alias numpy buffers (no version counter there): rebuilt every call
+        # host tensors may alias numpy buffers (no version counter there): rebuilt every call
+        if not all(t.is_cuda for t in given) or os.environ.get("MIFWI_NO_GEOM_CACHE", "0") not in ("", "0"):
             return cls(src_cell, src_w, rec_cell, rec_w, device)
         for refs, versions, dev, geom in _GEOMETRIES:
-            if dev == device and all(r() is t for r, t in zip(refs, given)) and versions == tuple(t._version for t in given):
+            if dev == device and all(r() is t for r, t in zip(refs, given)) and versions == tuple(_geom_key(t) for t in given):
                 return geom
         geom = cls(src_cell, src_w, rec_cell, rec_w, device)
         _GEOMETRIES[:] = [e for e in _GEOMETRIES if all(r() is not None for r in e[0])][-15:]
-        _GEOMETRIES.append((tuple(weakref.ref(t) for t in given), tuple(t._version for t in given), device, geom))
+        _GEOMETRIES.append((tuple(weakref.ref(t) for t in given), tuple(_geom_key(t) for t in given), device, geom))
         return geom
 
     def check_cells(self, ncell, what):

@@ -7,11 +7,12 @@
 Conventions kept from deepwave: locations are physical units in the model tensor's dimension
 order (z, x); cell = trunc(loc/dx); the source term is scaled by vp^2 dt^2; the internal time
 step is dt/ceil(dt/dt_max) with band-limited resampling of the wavelet and decimation of the
-traces; ``pml_width`` is the width of a PML (default 20 cells), the model edge-replicated into it.
+traces; ``pml_width`` is the width of a PML (default 10 cells per side, deepwave's own default - SURVEY.md
+appendix C; the reference never passes one: models/networks.py:5408-5411), the model edge-replicated into it.
 deepwave's own PML arithmetic cannot be pinned (its binaries are not available): the layer
 is the published second-order convolutional PML inside the same scalar scheme (memory variables psi, zeta on the
 layer's cells only; exact transposed adjoint; csrc/mifwi_acoustic_cpml.h, oracle/acoustic_cpml.c), and rec[n]
-samples the field before step n.  The 20-cell layer returns 1.6e-4 of the direct wave
+samples the field before step n.  The layer returns 1.1e-3 (10 cells) / 1.6e-4 (20 cells) of the direct wave
 (tests/test_acoustic_cpml_oracle.py); inside the model the scheme is the undamped one bit for bit.  Both kernel
 families carry it.  ``pml_freq`` (Hz) sets the frequency shift of the layer (default: a fifth of the source band's
 upper end, 0.25 / dt / 5); the damping profile scales with the model's maximum velocity rounded UP to the next
@@ -35,6 +36,7 @@ dt = 1 ms) gets it; a number = that fraction of the stability limit.
 """
 import functools
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -42,7 +44,7 @@ import torch.nn.functional as F
 from ... import acoustic, elastic, profiles
 from ..._lib import MifwiError
 
-DEFAULT_PML_WIDTH = 20
+DEFAULT_PML_WIDTH = 10       # deepwave's default; until round 3: 20
 # deepwave's own safety factor (0.6/sqrt(sum 1/dx^2)) is tighter than the stability limit of
 # the 4th-order stencil; the true limit with a 10 % margin keeps dt = 1 ms, dx = 10 m stable
 # up to 4.9 km/s without sub-stepping.
@@ -108,15 +110,16 @@ _CELLS = []
 def _cells(loc, spacing, pad, n1, dev):
     import weakref
     key = (tuple(spacing), int(pad), int(n1))
-    if loc.is_cuda:
+    nocache = os.environ.get("MIFWI_NO_GEOM_CACHE", "0") not in ("", "0")     # acoustic._GEOMETRIES: what the key cannot see
+    if loc.is_cuda and not nocache:
         for ref, ver, k, out in _CELLS:
-            if ref() is loc and ver == loc._version and k == key:
+            if ref() is loc and ver == (loc._version, loc.data_ptr(), tuple(loc.shape)) and k == key:
                 return out
     cells, w = profiles.cells_truncate(loc.detach(), spacing, pad, n1)
     out = (cells.to(dev), w.to(dev))
-    if loc.is_cuda:
+    if loc.is_cuda and not nocache:
         _CELLS[:] = [e for e in _CELLS if e[0]() is not None][-15:]
-        _CELLS.append((weakref.ref(loc), loc._version, key, out))
+        _CELLS.append((weakref.ref(loc), (loc._version, loc.data_ptr(), tuple(loc.shape)), key, out))
     return out
 
 

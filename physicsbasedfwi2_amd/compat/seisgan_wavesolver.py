@@ -32,26 +32,11 @@ from .._lib import MifwiError
 
 
 class TimeAxis(object):
-    """source.py:18-69: exactly three of start / step / num / stop."""
+    """Uniform time axis given by three of start / step / num / stop (the reference's class of this name,
+    source.py:18-69); the arithmetic is :func:`physicsbasedfwi2_amd.profiles.time_axis_complete`."""
 
     def __init__(self, start=None, step=None, num=None, stop=None):
-        try:
-            if start is None:
-                start = step * (1 - num) + stop
-            elif step is None:
-                step = (stop - start) / (num - 1)
-            elif num is None:
-                num = int(np.ceil((stop - start + step) / step))
-                stop = step * (num - 1) + start
-            elif stop is None:
-                stop = step * (num - 1) + start
-            else:
-                raise ValueError("Only three of start, step, num and stop may be set")
-        except TypeError:
-            raise ValueError("Three of args start, step, num and stop may be set")
-        if not isinstance(num, int):
-            raise TypeError("input argument must be of type int")
-        self.start, self.stop, self.step, self.num = start, stop, step, num
+        self.start, self.step, self.num, self.stop = profiles.time_axis_complete(start, step, num, stop)
 
     def _rebuild(self):
         return TimeAxis(start=self.start, stop=self.stop, num=self.num)

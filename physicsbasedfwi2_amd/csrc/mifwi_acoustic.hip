@@ -21,6 +21,8 @@
 // -ffp-contract=off) so wavefields can be compared bitwise.
 #include "mifwi_common.h"
 
+#include <atomic>
+
 #include <type_traits>
 #include <vector>
 
@@ -1318,6 +1320,9 @@ void cluster_setup(mifwi_acoustic_plan *pl)
     pl->xbuf_elems = mifwi::round_up64(2LL * pl->d.nshot * pl->NW * 8 * pl->gp, 64) +
                      mifwi::round_up64((long long)pl->d.nshot * pl->NW, 64) + 64;
     pl->list_elems = mifwi::round_up64((long long)pl->d.nshot * pl->NW * (1 + (long long)pl->d.nrec), 64);
+    // 28 function attributes: once per device and process, not once per plan (a plan is created on every propagate call)
+    static std::atomic<unsigned> attr_done{0};
+    if (pl->device < 32 && (attr_done.load() >> pl->device & 1u)) return;
     for (const void *fn : {(const void *)ac_cluster<0, false, false>, (const void *)ac_cluster<1, false, false>,
                            (const void *)ac_cluster<2, false, false>, (const void *)ac_cluster<3, false, false>,
                            (const void *)ac_cluster<0, true, false>, (const void *)ac_cluster<1, true, false>,
@@ -1339,6 +1344,7 @@ void cluster_setup(mifwi_acoustic_plan *pl)
             pl->cluster = 0;
             return;
         }
+    if (pl->device < 32) attr_done.fetch_or(1u << pl->device);
 }
 
 ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const float *q0, const float *q1,
@@ -1359,6 +1365,9 @@ ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const flo
     // fat slabs nap long between poll passes, thin ones short (mifwi::poll_nap)
     c.nap = env_int("MIFWI_POLL_NAP", mifwi::ceil_div(pl->d.n0, pl->NW) >= 16 ? 48 : 1);
     c.pml_lds_floats = env_int("MIFWI_AC_PML_LDS", 1) ? pl->cl_lds / (int)sizeof(float) : 0;      // 0: every layer array through global memory
+    // tests: pretend the launch has this many KB less LDS, so that pml_place keeps only a prefix of its list in LDS (every
+    // partial placement must give the same bits)
+    c.pml_lds_floats = std::max(0, c.pml_lds_floats - 256 * env_int("MIFWI_AC_PML_LDS_SHRINK_KB", 0));
     return c;
 }
 
@@ -1502,9 +1511,11 @@ int mifwi_acoustic_plan_create(mifwi_acoustic_plan **plan, int device,
     pl->ng = mifwi::ceil_div(d->n1, 4);
     pl->gp = 4 * pl->ng;
     pl->pmlW = d->cpml_width;
-    pl->pml_persist = pl->pmlW > 0 ? d->nshot * pml_persist_per_shot(pl->pmlW, d->n0, pl->gp) : 0;
-    pl->pml_scratch = pl->pmlW > 0 ? d->nshot * pml_scratch_per_shot(pl->pmlW, d->n0, pl->gp) : 0;
-    pl->zq_elems = pl->pmlW > 0 ? mifwi::round_up64((long long)d->n0 + pl->gp, 64) : 0;
+    // every sub-buffer of `work` starts on a 16-byte boundary (the per-shot sizes are even, not multiples of four, when
+    // W * n0 is odd: an odd shot count would leave everything behind them on an 8-byte boundary)
+    pl->pml_persist = pl->pmlW > 0 ? mifwi::round_up64(d->nshot * pml_persist_per_shot(pl->pmlW, d->n0, pl->gp), 4) : 0;
+    pl->pml_scratch = pl->pmlW > 0 ? mifwi::round_up64(d->nshot * pml_scratch_per_shot(pl->pmlW, d->n0, pl->gp), 4) : 0;
+    pl->zq_elems = pl->pmlW > 0 ? mifwi::round_up64(mifwi::round_up64(d->n0, 4) + pl->gp, 64) : 0;
     // one halo group left, interior, two spare groups right, rounded to 128-B lines
     pl->pitch = (int)mifwi::round_up64(4 * (pl->ng + 3), 32);
     pl->shot_stride = (long long)(d->n0 + 4) * pl->pitch;
@@ -1625,7 +1636,7 @@ int mifwi_acoustic_forward(mifwi_acoustic_plan *pl, const float *r, const float 
     if (pl->pmlW > 0) {
         MIFWI_HIP_TRY(hipMemsetAsync(zq, 0, sizeof(float) * pl->zq_elems, st));
         pm = pml_params(pl, q0, q1, pml_persist, pml_scratch);
-        q0 = zq; q1 = zq + d.n0;
+        q0 = zq; q1 = zq + mifwi::round_up64(d.n0, 4);      // q1 is read with 16-byte loads
     }
     if (d.nsrc > 0)
         hipLaunchKernelGGL(points_bbox, dim3(d.nshot), dim3(kThreads), 0, st, src_cell,
@@ -1703,7 +1714,7 @@ int mifwi_acoustic_born(mifwi_acoustic_plan *pl, const float *r, const float *q0
     if (pl->pmlW > 0) {
         MIFWI_HIP_TRY(hipMemsetAsync(zq, 0, sizeof(float) * pl->zq_elems, st));
         pm = pml_params(pl, q0, q1, pml_persist, pml_scratch);
-        q0 = zq; q1 = zq + d.n0;
+        q0 = zq; q1 = zq + mifwi::round_up64(d.n0, 4);      // q1 is read with 16-byte loads
     }
     const long long snap_step = (long long)d.nshot * pl->coef_elems;
     if (pl->cluster && pl->pmlW == 0 && n_end > n_begin) {          // (the Born pass of a C-PML plan runs one launch per step)
@@ -1777,7 +1788,7 @@ int mifwi_acoustic_backward(mifwi_acoustic_plan *pl, const float *r, const float
     if (pl->pmlW > 0) {
         MIFWI_HIP_TRY(hipMemsetAsync(zq, 0, sizeof(float) * pl->zq_elems, st));
         pm = pml_params(pl, q0, q1, pml_persist, pml_scratch);
-        q0 = zq; q1 = zq + d.n0;
+        q0 = zq; q1 = zq + mifwi::round_up64(d.n0, 4);      // q1 is read with 16-byte loads
     }
     hipLaunchKernelGGL(points_bbox, dim3(d.nshot), dim3(kThreads), 0, st, rec_cell,
                        d.nrec * d.ntap, d.n1, bbox);

@@ -1317,6 +1317,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
     const int forced_adj = env_int("MIFWI_EL_ADJ_NW", forced);
     if (env_int("MIFWI_EL_CLUSTER_ADJ", 1) != 0 && pl->d.shots_per_group <= 0) {
         double best_adj = 1e30;
+        const int adj_skewed = pl->adj_PL;             // the candidate pitch (MIFWI_EL_PL_SKEW bit 1); pl->adj_PL = what the chosen slabs use
         for (int nw = 1; nw <= 32; ++nw) {
             if (forced_adj > 0 && nw != forced_adj) continue;
             if (pl->d.nz / nw < 4) break;
@@ -1329,9 +1330,16 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
                 const int nbot = std::max(0, r0 + R - std::max(r0, pl->d.nz - pl->W));
                 zmax = std::max(zmax, ntop + nbot);
             }
-            const long long lds = (4LL * (rows + 4) * pl->adj_PL + 6LL * pl->gp + 8LL * rows +
-                                   4LL * rows * pl->wx + 4LL * zmax * pl->gp +
-                                   (rows + 4) + 2LL * kEaRcvRows * pl->adj_PL) * sizeof(float);   // + row map, receiver rows
+            auto adj_lds = [&](int PLq) {
+                return (long long)((4LL * (rows + 4) * PLq + 6LL * pl->gp + 8LL * rows + 4LL * rows * pl->wx + 4LL * zmax * pl->gp +
+                                    (rows + 4) + 2LL * kEaRcvRows * PLq) * sizeof(float));   // + row map, receiver rows
+            };
+            int PLq = adj_skewed;
+            long long lds = adj_lds(PLq);
+            if (lds > kEaLdsLimit && PLq != PL_plain) {         // the wider rows do not fit this slab height: plain pitch
+                PLq = PL_plain;
+                lds = adj_lds(PLq);
+            }
             if (lds > kEaLdsLimit) continue;
             if ((long long)rows * pl->ng > 2 * kEcThreads || kEcRowFields * pl->gp > kEcGr * kEcThreads) continue;
             const int per_launch = 8 * (ncu / (8 * nw));
@@ -1339,7 +1347,7 @@ void el_cluster_setup(mifwi_elastic_plan *pl)
             const double cost = mifwi::ceil_div(pl->d.nshot, per_launch) * (4.8 + (double)rows * pl->ng / kEcThreads);
             if (cost < best_adj - 1e-9) {
                 best_adj = cost;
-                pl->cl_adj = 1; pl->adj_NW = nw; pl->adj_shots = per_launch; pl->adj_lds = (int)lds;
+                pl->cl_adj = 1; pl->adj_NW = nw; pl->adj_shots = per_launch; pl->adj_lds = (int)lds; pl->adj_PL = PLq;
                 pl->adj_ng = mifwi::ceil_div(rows * pl->ng, kEcThreads); pl->adj_zrows = zmax;
             }
         }

@@ -7,6 +7,7 @@ Stands where ``d.forward`` / ``d.grad`` of pyapi_denise stand in the reference
 with no mpirun and no files.  All wave arithmetic is in libmifwi.so; there is no CPU path.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -15,7 +16,9 @@ from . import _lib
 from ._lib import MifwiError
 from .acoustic import _Geometry, _require_cuda, _stream
 
-DEFAULT_SNAPSHOT_BUDGET = 96 << 30
+# bytes of snapshot planes + time checkpoints a call may hold (288 GB of HBM per GPU; the rest is left to the caller's
+# network and data); MIFWI_EL_SNAPSHOT_BUDGET_GB overrides it (measurements of the checkpointed path on short runs)
+DEFAULT_SNAPSHOT_BUDGET = int(float(os.environ.get("MIFWI_EL_SNAPSHOT_BUDGET_GB", "96")) * (1 << 30))
 
 
 SNAPSHOT_FORMATS = {"f32": _lib.SNAPSHOT_F32, "bf16": _lib.SNAPSHOT_BF16}

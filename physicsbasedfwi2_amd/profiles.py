@@ -64,6 +64,27 @@ def time_axis(start, stop, step):
     return num, step * (num - 1) + start
 
 
+def time_axis_complete(start=None, step=None, num=None, stop=None):
+    """The four quantities of a uniform time axis from any three of them (seisgan TimeAxis, source.py:36-58):
+    stop = start + step (num - 1).  With `num` missing it is derived as :func:`time_axis` derives it (and the stop
+    value follows from it); given all four, or fewer than three, there is nothing to solve for."""
+    missing = [k for k, v in (("start", start), ("step", step), ("num", num), ("stop", stop)) if v is None]
+    if len(missing) != 1:
+        raise ValueError("exactly three of start, step, num and stop must be given (missing: %s)"
+                         % (", ".join(missing) or "none"))
+    if missing[0] == "num":
+        num, stop = time_axis(start, stop, step)
+    elif missing[0] == "start":
+        start = stop - step * (num - 1)
+    elif missing[0] == "step":
+        step = (stop - start) / (num - 1)
+    else:
+        stop = start + step * (num - 1)
+    if not isinstance(num, int):
+        raise TypeError("num must be an int, got %s" % type(num).__name__)
+    return start, step, num, stop
+
+
 # -------------------------------------------------------------------------------- wavelets --
 def ricker_seisgan(f0, t):
     """(1 - 2 r^2) exp(-r^2), r = pi f0 (t - 2/f0); t and 1/f0 in the same unit."""

@@ -340,6 +340,8 @@ def _run_cpml(c, budget=None, need_f=True):
 @pytest.mark.parametrize("kw", [
     dict(),
     dict(n0=41, n1=53, w=6, ns=2, nrec=9),                 # ragged sizes
+    dict(n0=43, n1=57, w=7, ns=3, nrec=9),                 # N0 = 57 = 1 mod 4, odd width, odd shot count: the sub-buffers of the
+                                                           # work area behind the layer's arrays (q1: float4 loads) stay 16-byte aligned
     dict(n0=60, n1=300, w=20, ns=2, nrec=40, nt=90),       # the reference's layer width, several tiles
     dict(ntap=4, nrec=9),                                  # bilinear taps
     dict(h=(10.0, 15.0)),                                  # anisotropic spacing: c0 != c1 in the layer's term
@@ -407,6 +409,35 @@ def test_cpml_born_is_the_transpose_partner_of_the_gradient(oracle32):
         a = acoustic.propagate(r + eps * dr, f, t("ab0"), t("ab1"), t("sc"), t("sw"), t("rc"), t("rw"), c["c0"], c["c1"], **kw)
         b = acoustic.propagate(r - eps * dr, f, t("ab0"), t("ab1"), t("sc"), t("sw"), t("rc"), t("rw"), c["c0"], c["c1"], **kw)
     assert rel_l2(drec.cpu().numpy(), ((a - b) / (2 * eps)).cpu().numpy()) < 2e-2
+
+
+def test_cpml_partial_lds_placements_give_the_same_bits(monkeypatch):
+    """pml_place keeps as many of a slab's layer arrays in LDS as fit behind its planes - a prefix of a fixed list (6
+    arrays forward, 10 adjoint; the axis-0 ones on the edge slabs only), the rest stays in global memory.  Which prefix
+    depends on the grid; here the launch pretends to have 0 .. 40 KB less LDS (MIFWI_AC_PML_LDS_SHRINK_KB), which walks
+    the cut through the list on edge and interior slabs alike, forward and adjoint: traces and gradients must be the same
+    bits as with every array in global memory.  Offsets are added to the cell index, never to an LDS base pointer
+    (a pointer biased below an LDS buffer leaves the LDS aperture)."""
+    monkeypatch.setenv("MIFWI_AC_CLUSTER", "1")
+    monkeypatch.setenv("MIFWI_AC_NW", "4")
+    c = _cpml_case(seed=29, n0=88, n1=150, w=12, nt=70, ns=2, nrec=30)
+    g = None
+    outs = {}
+    for shrink in (None, 0, 3, 6, 9, 12, 16, 20, 26, 32, 40):
+        if shrink is None:
+            monkeypatch.setenv("MIFWI_AC_PML_LDS", "0")
+        else:
+            monkeypatch.setenv("MIFWI_AC_PML_LDS", "1")
+            monkeypatch.setenv("MIFWI_AC_PML_LDS_SHRINK_KB", str(shrink))
+        r, f, rec = _run_cpml(c)
+        if g is None:
+            g = torch.sign(rec.detach()) + 0.25
+        rec.backward(g)
+        outs[shrink] = (rec.detach().clone(), r.grad.clone(), f.grad.clone())
+    assert float(outs[None][0].abs().max()) > 0 and float(outs[None][1].abs().max()) > 0
+    for shrink, o in outs.items():
+        for a, b in zip(o, outs[None]):
+            assert torch.equal(a, b), shrink
 
 
 def test_cpml_single_launch_and_per_step_families_agree(oracle32, monkeypatch):

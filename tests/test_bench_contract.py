@@ -43,8 +43,8 @@ def test_profile_summaries_are_quoted_only_for_the_kernels_they_describe(tmp_pat
     floor = {"csrc_sha16": sha, "commit": "abc1234",
              "elastic_100x300": {"adjoint+imaging": {"floor_s_per_step": 9.3e-6}}}
     (root / "profiles" / (bench.PROFILE_ROUND + "_latency_floor.json")).write_text(json.dumps(floor))
-    assert bench.measured_traffic("elastic_100x300", "adjoint+imaging") == (42.5, "abc1234")
-    assert bench.latency_floor("elastic_100x300", "adjoint+imaging") == (9.3e-6, "abc1234")
+    assert bench.measured_traffic("elastic_100x300", "adjoint+imaging") == (42.5, "csrc " + sha)
+    assert bench.latency_floor("elastic_100x300", "adjoint+imaging") == (9.3e-6, "csrc " + sha)
     assert bench.measured_traffic("no_such_workload", "x")[0] is None
     (root / "physicsbasedfwi2_amd" / "csrc" / "k.hip").write_bytes(b"kernel v2")
     assert bench.csrc_sha16() != sha
@@ -69,10 +69,10 @@ def test_roofline_objects_use_one_cell_convention_and_never_exceed_one(tmp_path,
     r = bench.roofline_of(kern, "adjoint+imaging", interior)
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["cells"] == "interior"
     assert abs(r["achieved"] - 20.0 * interior / 11.7e-6 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
-    assert r["frac"] < 1.0 and r["traffic"] == 42.5 * interior and r["traffic_profiled_at"] == "c0ffee0"
+    assert r["frac"] < 1.0 and r["traffic"] == 42.5 * interior and r["traffic_profiled_at"] == "csrc " + sha
     assert abs(r["streaming_equivalent_GBs"] - 80.0 * interior / 11.7e-6 / 1e9) < 1e-6
     lat = r["latency"]
-    assert lat["bound"] == "latency" and abs(lat["frac"] - 9.3 / 11.7) < 1e-9 and lat["floor_profiled_at"] == "c0ffee0"
+    assert lat["bound"] == "latency" and abs(lat["frac"] - 9.3 / 11.7) < 1e-9 and lat["floor_profiled_at"] == "csrc " + sha
     # per-step streaming family: SURVEY 8d bytes, no latency object
     k2 = {"adjoint+imaging": bench.kernel_report("elastic_350x1700", "adjoint+imaging", 323e-6, 350 * 1700 * 32, 80.0,
                                                  20.0, False)}
