@@ -732,8 +732,8 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
     own.m0 = own.m1 = own.m2 = halo.m0 = halo.m1 = halo.m2 = zero4;
     if (own_ok) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
-            acc[k] = ld4(p.acc + ((long long)(p.s0 / p.gs + bz) * 5 + k) * ncell + occ);
+        for (int k = 0; k < 5; ++k)          // accumulator planes share the snapshot planes' layout (snap_cell)
+            acc[k] = ld4(p.acc + ((long long)(p.s0 / p.gs + bz) * 5 + k) * p.splane + snap_cell(p, oj, og));
         own.m0 = ld4(p.mat + M_L * ncell + occ); own.m1 = ld4(p.mat + M_M * ncell + occ);
         own.m2 = ld4(p.mat + M_MU * ncell + occ);
     }
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
     if (own_ok) {
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            st4(p.acc + ((long long)(p.s0 / p.gs + bz) * 5 + k) * ncell + occ, acc[k]);
+            st4(p.acc + ((long long)(p.s0 / p.gs + bz) * 5 + k) * p.splane + snap_cell(p, oj, og), acc[k]);
     }
 }
 
@@ -1134,13 +1134,18 @@ __global__ void el_points_bbox(const int *cell, int npts_per_shot, int n1, int *
     }
 }
 
-// grad[k][cell] = sum over shot groups of acc[group][k][cell]
-__global__ void el_finalize(const float *acc, int ngroups, long long n5, float *grad)
+// grad[k][cell] = sum over shot groups of acc[group][k][cell]; grad is row-major [5][nz][gp] (the C-ABI's layout), the
+// accumulator planes are `aplane` floats apart and column-blocked when sblk (snap_cell)
+__global__ void el_finalize(const float *acc, int ngroups, int nz, int gp, long long aplane, int sblk, float *grad)
 {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n5) return;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, ncell = (long long)nz * gp;
+    if (idx >= 5 * ncell) return;
+    const int k = (int)(idx / ncell);
+    const long long c = idx - (long long)k * ncell;
+    const int j = (int)(c / gp), i = (int)(c - (long long)j * gp), g = i >> 2;
+    const long long off = sblk ? ((long long)(g >> 4) * nz + j) * 64 + 4 * (g & 15) + (i & 3) : c;
     float a = 0.f;
-    for (int gidx = 0; gidx < ngroups; ++gidx) a += acc[(long long)gidx * n5 + idx];
+    for (int gidx = 0; gidx < ngroups; ++gidx) a += acc[((long long)gidx * 5 + k) * aplane + off];
     grad[idx] = a;
 }
 
@@ -1665,7 +1670,7 @@ int mifwi_elastic_plan_layout(const mifwi_elastic_plan *pl, mifwi_elastic_layout
     // single-launch plans: room for a copy of a resumed call's input state (el_cluster_backup)
     out->work_forward_elems = out->state_elems + bbox + (pl->cluster ? pl->xbuf_elems + out->state_elems : 0) +
                               (pl->fused ? out->state_elems : 0);
-    const long long adj_state = pl->fields_elems + 2 * psi + 5LL * pl->ngroups * pl->coef_elems;
+    const long long adj_state = pl->fields_elems + 2 * psi + 5LL * pl->ngroups * pl->splane;
     out->work_backward_elems = adj_state + bbox + (pl->cl_adj ? pl->xbuf_elems + pl->list_elems + adj_state : 0) +
                                (pl->fused_adj ? pl->fields_elems : 0) + pl->tile_elems;
     return MIFWI_OK;
@@ -1859,7 +1864,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
     float *fields = work;
     float *psiA = work + pl->fields_elems, *psiB = psiA + psi;
     float *acc = psiB + psi;
-    const long long nacc = 5LL * pl->ngroups * pl->coef_elems;
+    const long long nacc = 5LL * pl->ngroups * pl->splane;          // accumulator planes: the snapshot planes' layout and size
     int *bbox = reinterpret_cast<int *>(acc + nacc);
     float *fieldsB = reinterpret_cast<float *>(bbox) + mifwi::round_up64(4LL * d.nshot, 64);   // fused adjoint only
     if (flags & MIFWI_ZERO_STATE) {
@@ -2099,7 +2104,7 @@ int mifwi_elastic_backward(mifwi_elastic_plan *pl, const float *mat, const float
     if (flags & MIFWI_FINALIZE) {
         const long long n5 = 5LL * pl->coef_elems;
         hipLaunchKernelGGL(el_finalize, dim3((unsigned)((n5 + 255) / 256)), dim3(256), 0, st, acc,
-                           pl->ngroups, n5, grad_mat);
+                           pl->ngroups, d.nz, pl->gp, pl->splane, pl->cl_adj ? 0 : pl->sblk, grad_mat);
     }
     MIFWI_HIP_TRY(hipGetLastError());
     return MIFWI_OK;

@@ -401,10 +401,10 @@ __global__ __launch_bounds__(kThreads, 3) void el_adj_fused(const ElParams p)
     float4 acc[5];
     {
         const FOwn o = f_own(p, t, tile_j, tile_g);
-        const long long acc_base = (long long)(p.s0 / p.gs + bz) * 5 * ncell + o.occ;
+        const long long acc_base = (long long)(p.s0 / p.gs + bz) * 5 * p.splane + snap_cell(p, o.oj, o.og);
         if (o.ok) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) acc[k] = ld4(p.acc + acc_base + (long long)k * ncell);
+            for (int k = 0; k < 5; ++k) acc[k] = ld4(p.acc + acc_base + (long long)k * p.splane);
         }
     }
     // margins of the LDS rows: zeros (they only ever feed lanes whose results are discarded)
@@ -574,10 +574,10 @@ __global__ __launch_bounds__(kThreads, 3) void el_adj_fused(const ElParams p)
     }
     {
         const FOwn o = f_own(p, f_opaque(t), tile_j, tile_g);
-        const long long acc_base = (long long)(p.s0 / p.gs + bz) * 5 * ncell + o.occ;
+        const long long acc_base = (long long)(p.s0 / p.gs + bz) * 5 * p.splane + snap_cell(p, o.oj, o.og);
         if (o.ok) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) st4(p.acc + acc_base + (long long)k * ncell, acc[k]);
+            for (int k = 0; k < 5; ++k) st4(p.acc + acc_base + (long long)k * p.splane, acc[k]);
         }
     }
 }

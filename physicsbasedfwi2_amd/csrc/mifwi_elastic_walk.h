@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const 
     long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = 0, tr_0 = 0;
     if (p.walk_trace) tr_0 = __builtin_amdgcn_s_memtime();
 #endif
-    const long long acc_group = (long long)(p.s0 / p.gs + bz) * 5 * ncell;
+    const long long acc_group = (long long)(p.s0 / p.gs + bz) * 5 * p.splane;
     const int sfirst = p.s0 + bz * p.gs;
     const int ns = min(p.gs, p.nshot - sfirst);
     // carry row of this lane (rows 0-3 E2/D2, 4-7 E3/D4, 8-9 E1/D1, 10-11 E4/D3): plane, saved row, restored row
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const 
         const bool mineC = own_g && rowC >= z0 && rowC < z1;
         const unsigned ooA = rowoff(rowA, gq), ooA1 = rowoff(rowA + WTZ, gq), ccA = celloff(rowA, gq);
         const unsigned ooB = rowoff(rowB, gq), ccB = celloff(rowB, gq);
-        const unsigned ccO = celloff(rowB, go), ooC = rowoff(rowC, go);
+        const unsigned ooC = rowoff(rowC, go);
         // materials of the iteration's rows (shared by the shots of the group); those of the next iteration fly meanwhile
         AdjIn inA;
         inA.m0 = inA.m1 = inA.m2 = zero4;
@@ -204,8 +204,9 @@ __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const 
             bxs = ld4(wk_at(p.mat + M_BX * ncell, ccB)); bzs = ld4(wk_at(p.mat + M_BZ * ncell, ccB));
         }
         float4 acc[5];
+        const unsigned scO = snap_cell(p, min(max(rowB, 0), p.nz - 1), go);        // snapshot and accumulator planes: one layout
 #pragma unroll
-        for (int q = 0; q < 5; ++q) acc[q] = WK_DBG(2) ? zero4 : ld4(wk_at(p.acc + acc_group + (long long)q * ncell, ccO));
+        for (int q = 0; q < 5; ++q) acc[q] = WK_DBG(2) ? zero4 : ld4(wk_at(p.acc + acc_group + (long long)q * p.splane, scO));
         for (int si = 0; si < ns; ++si) {
             const int s = sfirst + si;
             float *fout = p.fields_out + (long long)s * p.shot_stride;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const 
 #endif
             // ---- operands of phase B: requested now, used behind the first barrier; those of phase A were requested
             //      during the item before, in front of its stores ------------------------------------------------------
-            request_B(s, snap_cell(p, min(max(rowB, 0), p.nz - 1), go), ooB);
+            request_B(s, scO, ooB);
             float4 S1 = nS[0], S2 = nS[1], S3 = nS[2], S4 = nS[3], S5 = nS[4];
             BfPlanes packed = npk;
             inA.a = nxt.a; inA.b = nxt.b; inA.c = nxt.c;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(kThreads, MIFWI_WALK_WAVES) void el_adj_walk(const 
         if (!WK_DBG(2)) {
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
-                float *real = wk_at(p.acc + acc_group + (long long)q * ncell, ccO);
+                float *real = wk_at(p.acc + acc_group + (long long)q * p.splane, scO);
                 st4(mineB ? real : p.trash + 4 * f_opaque(t), acc[q]);
             }
         }
