@@ -97,6 +97,23 @@ __device__ __forceinline__ float comp(const float4 &v, int c)
     return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
 }
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// uniform base + 32-bit lane offset (in floats): selects the `global_* v_off, s[base]` addressing form - no 64-bit
+// vector address per plane and lane
+__device__ __forceinline__ const float *el_at(const float *base, unsigned off)
+{
+    return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + 4u * off);
+}
+__device__ __forceinline__ float *el_at(float *base, unsigned off)
+{
+    return reinterpret_cast<float *>(reinterpret_cast<char *>(base) + 4u * off);
+}
+// a per-lane value the compiler must treat as unknown here: what is derived from it is recomputed at the use instead of
+// being hoisted out of a loop and kept (or spilled) across it
+__device__ __forceinline__ int f_opaque(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
 __device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
 __device__ __forceinline__ float dfw(const FdK &K, float fm1, float f0, float f1, float f2)   // Dp at "0"
@@ -699,8 +716,11 @@ __global__ void el_build_tile_taps(const int *cell, int ntaps, int nx, int tx, i
 //       (p.tile_start set), or have been applied to the state by el_inject_adjsrc.
 // Every global load of a shot (own group, halo group, adjoint velocities, the five snapshot planes) is
 // requested before the first use: one memory round trip per shot instead of three.
+// Register budget pinned at three waves per SIMD (<= 168 VGPRs; 146 in use since the plane loads address as uniform
+// base + 32-bit lane offset and the C-PML branches derive their addresses from opaque indices - 207 before): three
+// workgroups per CU, 768 workgroup slots.  1000x3000 adjoint pair 885 -> 853-864 us per step.
 template <bool BF16>
-__global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
+__global__ __launch_bounds__(kThreads, 3) void el_adj_s(const ElParams p)
 {
     const FdK K = p.K;
     int bx, by, bz;
@@ -720,6 +740,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
     const bool own_ok = oj < p.nz && og < p.ng;
     const unsigned occ = (unsigned)oj * p.gp + 4 * og;
     const unsigned oo = (unsigned)(oj + 2) * p.pitch + 4 + 4 * og;
+    const unsigned osc = snap_cell(p, oj, og);          // snapshot and accumulator planes
     int hr = 0, hg = 0;
     if (t < kHalo) halo_item(t, hr, hg);
     const int hj = tile_j - 2 + hr, hgg = tile_g - 1 + hg;
@@ -733,13 +754,13 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
     if (own_ok) {
 #pragma unroll
         for (int k = 0; k < 5; ++k)          // accumulator planes share the snapshot planes' layout (snap_cell)
-            acc[k] = ld4(p.acc + ((long long)(p.s0 / p.gs + bz) * 5 + k) * p.splane + snap_cell(p, oj, og));
-        own.m0 = ld4(p.mat + M_L * ncell + occ); own.m1 = ld4(p.mat + M_M * ncell + occ);
-        own.m2 = ld4(p.mat + M_MU * ncell + occ);
+            acc[k] = ld4(el_at(p.acc + ((long long)(p.s0 / p.gs + bz) * 5 + k) * p.splane, osc));
+        own.m0 = ld4(el_at(p.mat + M_L * ncell, occ)); own.m1 = ld4(el_at(p.mat + M_M * ncell, occ));
+        own.m2 = ld4(el_at(p.mat + M_MU * ncell, occ));
     }
     if (halo_ok) {
-        halo.m0 = ld4(p.mat + M_L * ncell + hcc); halo.m1 = ld4(p.mat + M_M * ncell + hcc);
-        halo.m2 = ld4(p.mat + M_MU * ncell + hcc);
+        halo.m0 = ld4(el_at(p.mat + M_L * ncell, hcc)); halo.m1 = ld4(el_at(p.mat + M_M * ncell, hcc));
+        halo.m2 = ld4(el_at(p.mat + M_MU * ncell, hcc));
     }
     for (int si = 0; si < p.gs; ++si) {
         const int s = p.s0 + bz * p.gs + si;
@@ -751,12 +772,12 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
         packed.c = mifwi_u2{0u, 0u};
         own.a = own.b = own.c = halo.a = halo.b = halo.c = zero4;
         if (own_ok) {
-            own.a = ld4(fl + F_SXX * fs + oo); own.b = ld4(fl + F_SZZ * fs + oo); own.c = ld4(fl + F_SXZ * fs + oo);
+            own.a = ld4(el_at(fl + F_SXX * fs, oo)); own.b = ld4(el_at(fl + F_SZZ * fs, oo)); own.c = ld4(el_at(fl + F_SXZ * fs, oo));
         }
         if (halo_ok) {
-            halo.a = ld4(fl + F_SXX * fs + ho); halo.b = ld4(fl + F_SZZ * fs + ho); halo.c = ld4(fl + F_SXZ * fs + ho);
+            halo.a = ld4(el_at(fl + F_SXX * fs, ho)); halo.b = ld4(el_at(fl + F_SZZ * fs, ho)); halo.c = ld4(el_at(fl + F_SXZ * fs, ho));
         }
-        if (own_ok) { vxb = ld4(fl + F_VX * fs + oo); vzb = ld4(fl + F_VZ * fs + oo); }
+        if (own_ok) { vxb = ld4(el_at(fl + F_VX * fs, oo)); vzb = ld4(el_at(fl + F_VZ * fs, oo)); }
         // ---- adjoint sources of this tile (workgroup-uniform branch; E[0], E[1] are free until the staging) -----
         if (p.tile_start != nullptr) {
             const int ntiles = (int)gridDim.x * p.tiles_z, per = p.ninj * p.ntap_inj;
@@ -787,25 +808,25 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
         if (p.fsurf && hj == 0) halo.b = zero4;
         {
             float4 E1 = zero4, E2 = zero4, E3 = zero4, E4 = zero4;
-            if (own_ok) stage_E(p, s, oj, og, own, true, E1, E2, E3, E4);
+            if (own_ok) stage_E(p, s, f_opaque(oj), f_opaque(og), own, true, E1, E2, E3, E4);
             const int x = 4 * (ogrp + 1);
             st4(&E[0][orow + 2][x], E1); st4(&E[1][orow + 2][x], E2);
             st4(&E[2][orow + 2][x], E3); st4(&E[3][orow + 2][x], E4);
         }
         if (t < kHalo) {
             float4 E1 = zero4, E2 = zero4, E3 = zero4, E4 = zero4;
-            if (halo_ok) stage_E(p, s, hj, hgg, halo, false, E1, E2, E3, E4);
+            if (halo_ok) stage_E(p, s, f_opaque(hj), f_opaque(hgg), halo, false, E1, E2, E3, E4);
             st4(&E[0][hr][4 * hg], E1); st4(&E[1][hr][4 * hg], E2);
             st4(&E[2][hr][4 * hg], E3); st4(&E[3][hr][4 * hg], E4);
         }
         // the snapshot planes are only needed after the barrier: requested last, they do not delay the staging
         if (own_ok && !BF16) {
-            const float *Sp = p.S + (long long)s * p.snap_shot + snap_cell(p, oj, og);
+            const float *Sp = p.S + (long long)s * p.snap_shot;
             const long long sp = p.splane;
-            S1 = mifwi::ldnt4(Sp); S2 = mifwi::ldnt4(Sp + sp); S3 = mifwi::ldnt4(Sp + 2 * sp);
-            S4 = mifwi::ldnt4(Sp + 3 * sp); S5 = mifwi::ldnt4(Sp + 4 * sp);
+            S1 = mifwi::ldnt4(el_at(Sp, osc)); S2 = mifwi::ldnt4(el_at(Sp + sp, osc)); S3 = mifwi::ldnt4(el_at(Sp + 2 * sp, osc));
+            S4 = mifwi::ldnt4(el_at(Sp + 3 * sp, osc)); S5 = mifwi::ldnt4(el_at(Sp + 4 * sp, osc));
         } else if (own_ok) {
-            bf_request(p.S + (long long)s * p.snap_shot, p.splane, snap_cell(p, oj, og) >> 2, packed);
+            bf_request(p.S + (long long)s * p.snap_shot, p.splane, osc >> 2, packed);
         }
         __syncthreads();
         // ---- stencils from LDS + injection + gradient accumulation ---------------------------
@@ -829,8 +850,8 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
                 if (4 * og + c >= p.nx) { ax = 0.f; az = 0.f; }
                 nvx[c] = ax; nvz[c] = az;
             }
-            st4(fl + F_VX * fs + oo, make_float4(nvx[0], nvx[1], nvx[2], nvx[3]));
-            st4(fl + F_VZ * fs + oo, make_float4(nvz[0], nvz[1], nvz[2], nvz[3]));
+            st4(el_at(fl + F_VX * fs, oo), make_float4(nvx[0], nvx[1], nvx[2], nvx[3]));
+            st4(el_at(fl + F_VZ * fs, oo), make_float4(nvz[0], nvz[1], nvz[2], nvz[3]));
             // gradients (oracle order): Ms, Ls, mus from sigma_bar; bxs, bzs from the new v_bar
             if (BF16) {
                 bf_pin(packed);
@@ -854,7 +875,7 @@ __global__ __launch_bounds__(kThreads) void el_adj_s(const ElParams p)
     if (own_ok) {
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            st4(p.acc + ((long long)(p.s0 / p.gs + bz) * 5 + k) * p.splane + snap_cell(p, oj, og), acc[k]);
+            st4(el_at(p.acc + ((long long)(p.s0 / p.gs + bz) * 5 + k) * p.splane, osc), acc[k]);
     }
 }
 

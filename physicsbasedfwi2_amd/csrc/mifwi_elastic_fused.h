@@ -351,11 +351,6 @@ __device__ __forceinline__ void adj_v_update(const ElParams &p, int g, const flo
 // addresses alive across the whole step (and spills them).
 struct FOwn { int orow, ogrp, oj, og; bool ok; unsigned occ, oo; };
 struct FHalo { int r, g, j, gg; bool ok; unsigned cc, o; };
-__device__ __forceinline__ int f_opaque(int x)
-{
-    asm volatile("" : "+v"(x));
-    return x;
-}
 __device__ __forceinline__ FOwn f_own(const ElParams &p, int t, int tile_j, int tile_g)
 {
     FOwn o;
