@@ -10,6 +10,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,13 +27,18 @@ def main():
            "how": "bench.py --steps 3 --warmup 3 --timing-only with -DMIFWI_ABLATIONS, MIFWI_EL_CL_DBG=3 / MIFWI_AC_CL_DBG=3 "
                   "(no halo hand-off, no snapshot stores)"}
     for wl in ("elastic_marmousi", "acoustic_marmousi"):
-        env = dict(os.environ, MIFWI_LIB=lib, MIFWI_EL_CL_DBG="3", MIFWI_AC_CL_DBG="3")
+        # acoustic: the sponge plan (20 cells) - the entry bench.py looks up as "acoustic_174x500"; C-PML plans have no floor entry
+        env = dict(os.environ, MIFWI_LIB=lib, MIFWI_EL_CL_DBG="3", MIFWI_AC_CL_DBG="3", BENCH_ABSORBING="sponge",
+                   BENCH_PML_WIDTH="20")
+        detail = tempfile.NamedTemporaryFile(suffix=".json", delete=False).name
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", "3", "--warmup", "3",
-               "--no-cpu-baseline", "--no-also", "--timing-only"]
+               "--no-cpu-baseline", "--no-also", "--timing-only", "--detail", detail]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         if res.returncode != 0:
             raise SystemExit("ablation run of %s failed:\n%s" % (wl, res.stderr[-2000:]))
-        line = json.loads(res.stdout.strip().splitlines()[-1])
+        with open(detail) as fh:
+            line = json.load(fh)           # the full report: the stdout line no longer carries the per-kernel blocks
+        os.unlink(detail)
         key = "%s_%dx%d" % (wl.split("_")[0], *line["config"]["grid"])
         doc[key] = {lab: {"floor_s_per_step": k["avg_step_s"]} for lab, k in line["kernels"].items()
                     if k["lds_resident"]}

@@ -28,7 +28,7 @@ issue() {  # workload: one --pmc pass of the SQ instruction counters
     python tools/issue_counters.py $O/pmc_issue_$1 $O/${R}_issue_counters.json --workload $1 > /dev/null || return 1
     find $O/pmc_issue_$1 -name "*.csv" -size +200k -delete
 }
-issue elastic_marmousi && BENCH_ABSORBING=sponge issue acoustic_marmousi || exit 1
+issue elastic_marmousi && BENCH_ABSORBING=sponge BENCH_PML_WIDTH=20 issue acoustic_marmousi || exit 1
 # the acoustic single-launch kernels with the second-order C-PML (bench.py's `also` entry "..._cpml20")
 rm -rf $O/pmc_issue_cpml
 BENCH_ABSORBING=cpml timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/pmc_issue_cpml -- python bench.py --workload acoustic_marmousi --steps 1 --warmup 0 --no-cpu-baseline --no-also --no-verify > $O/pmc.log 2>&1 || { tail -5 $O/pmc.log; exit 1; }
@@ -36,7 +36,7 @@ python tools/issue_counters.py $O/pmc_issue_cpml $O/${R}_issue_counters.json --w
 find $O/pmc_issue_cpml -name "*.csv" -size +200k -delete
 cp $O/${R}_issue_counters.json profiles/${R}_issue_counters.json
 pmc el100 --workload elastic_marmousi -- --workload elastic_marmousi &&
-BENCH_ABSORBING=sponge pmc ac174 --workload acoustic_marmousi -- --workload acoustic_marmousi &&
+BENCH_ABSORBING=sponge BENCH_PML_WIDTH=20 pmc ac174 --workload acoustic_marmousi -- --workload acoustic_marmousi &&
 pmc el350 --workload elastic_marmousi --grid 350x1700 --nt 60 -- --workload elastic_marmousi --grid 350x1700 --nt 60 &&
 pmc seam --workload elastic_seam --nt 24 -- --workload elastic_seam --nt 24 || exit 1
 cp $O/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json
