@@ -22,6 +22,13 @@ def _configs():
         opt = dict(source_type=int(rng.integers(0, 3)), pressure=bool(rng.integers(0, 2)),
                    gs=int(rng.integers(0, 4)), cluster=str(int(rng.integers(0, 2))),
                    pass_shots=str(int(rng.integers(1, 4))), pass_groups=str(int(rng.integers(1, 3))))
+        # round 4 (drawn from a generator of their own: the configurations above stay the ones of rounds 1-3): the fused
+        # adjoint forms (1 tiles, 2 column walk; explosive sources without pressure receivers only - the plan ignores the
+        # switch otherwise), rows per column chunk of the walk, plane layout, tile -> XCD order, fused forward
+        r4 = np.random.default_rng(4000 + k)
+        opt.update(fused_adj=str(int(r4.choice([0, 1, 2, 2]))), walk_rows=str(int(r4.choice([14, 28, 42, 70]))),
+                   blocked=str(int(r4.integers(0, 2))), xcd=str(int(r4.choice([0, 1, 2, 3]))), fused=str(int(r4.integers(0, 2))),
+                   fmt=str(r4.choice(["f32", "f32", "bf16"])))
         out.append((k, cfg, opt))
     return out
 
@@ -33,6 +40,12 @@ def test_random_elastic_configuration(oracle32, monkeypatch, k, cfg, opt):
     monkeypatch.setenv("MIFWI_EL_CLUSTER_ADJ", opt["cluster"])
     monkeypatch.setenv("MIFWI_EL_PASS_SHOTS", opt["pass_shots"])
     monkeypatch.setenv("MIFWI_EL_PASS_GROUPS", opt["pass_groups"])
+    monkeypatch.setenv("MIFWI_EL_FUSED_ADJ", opt["fused_adj"])
+    monkeypatch.setenv("MIFWI_EL_WALK_ROWS", opt["walk_rows"])
+    monkeypatch.setenv("MIFWI_EL_SNAP_BLOCKED", opt["blocked"])
+    monkeypatch.setenv("MIFWI_EL_XCD", opt["xcd"])
+    monkeypatch.setenv("MIFWI_EL_FUSED", opt["fused"])
+    bf16 = opt["fmt"] == "bf16"
     case = elastic_case(seed=100 + k, **cfg)
     if opt["source_type"]:
         case["f"] = (case["f"] * 1e-3).astype(np.float32)
@@ -45,7 +58,7 @@ def test_random_elastic_configuration(oracle32, monkeypatch, k, cfg, opt):
     f = torch.tensor(case["f"], dtype=torch.float32, device=DEV, requires_grad=True)
     tg = [torch.tensor(case[n]) for n in ("pz", "px", "sc", "sw", "rc", "rw")]
     out = elastic.propagate(mat, f, *tg, case["fw"], shots_per_group=opt["gs"], free_surface=bool(fs),
-                            source_type=st, record_pressure=opt["pressure"])
+                            source_type=st, record_pressure=opt["pressure"], snapshot_format=opt["fmt"])
     scale = max(np.abs(ovx).max(), np.abs(ovz).max())
     assert scale > 0
     for h, r in zip(out, res[:2] + ((res[3],) if opt["pressure"] else ())):
@@ -56,8 +69,10 @@ def test_random_elastic_configuration(oracle32, monkeypatch, k, cfg, opt):
     torch.autograd.backward(list(out), [torch.tensor(g, device=DEV) for g in gs_ + ([gp] if gp is not None else [])])
     gm_o, gf_o = o.elastic_backward(case["mat"], case["pz"], case["px"], *geo, gs_[0], gs_[1], S, free_surface=fs,
                                     source_type=st, g_p=gp)
+    # bf16 snapshot planes (per-step kernels only; a single-launch plan keeps f32): the stated 4e-3 on the material gradients
+    tol = 4e-3 if bf16 and opt["cluster"] == "0" else 5e-5
     for j in range(5):
-        assert rel_l2(mat.grad[j].cpu().numpy(), gm_o[j]) <= 5e-5, (j, cfg, opt)
+        assert rel_l2(mat.grad[j].cpu().numpy(), gm_o[j]) <= tol, (j, cfg, opt)
     assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 5e-5, (cfg, opt)
 
 

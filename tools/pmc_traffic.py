@@ -63,12 +63,13 @@ def main():
     ap.add_argument("--grid", default="")
     ap.add_argument("--nt", type=int, default=0)
     ap.add_argument("--shots", type=int, default=0)
+    ap.add_argument("--suffix", default="", help="appended to the entry's key (\"_cpml\": the acoustic pass ran with the C-PML)")
     a, _ = ap.parse_known_args()            # tools/pmc_one.sh hands over the bench arguments as they are
     cls = bench.WORKLOADS[a.workload]
     nz, nx = (int(v) for v in a.grid.lower().split("x")) if a.grid else (cls.nz, cls.nx)
     nt, ns = a.nt or cls.nt, a.shots or cls.shots_per_gpu
     physics = a.workload.split("_")[0]
-    key = "%s_%dx%d%s" % (physics, nz, nx, "_fs" if getattr(cls, "free_surface", False) else "")
+    key = "%s_%dx%d%s" % (physics, nz, nx, "_fs" if getattr(cls, "free_surface", False) else "") + a.suffix
     fetch, write = totals(a.fetch_dir, "FETCH_SIZE"), totals(a.write_dir, "WRITE_SIZE")
     try:
         with open(a.out) as fh:

@@ -37,6 +37,7 @@ find $O/pmc_issue_cpml -name "*.csv" -size +200k -delete
 cp $O/${R}_issue_counters.json profiles/${R}_issue_counters.json
 pmc el100 --workload elastic_marmousi -- --workload elastic_marmousi &&
 BENCH_ABSORBING=sponge BENCH_PML_WIDTH=20 pmc ac174 --workload acoustic_marmousi -- --workload acoustic_marmousi &&
+pmc ac174c --workload acoustic_marmousi -- --workload acoustic_marmousi --suffix _cpml &&
 pmc el350 --workload elastic_marmousi --grid 350x1700 --nt 60 -- --workload elastic_marmousi --grid 350x1700 --nt 60 &&
 pmc seam --workload elastic_seam --nt 24 -- --workload elastic_seam --nt 24 || exit 1
 cp $O/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json
