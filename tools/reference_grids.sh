@@ -8,5 +8,5 @@ for C in "100x300 5" "100x300 6" "150x294 6" "170x396 6" "190x324 4" "100x300 32
 import json,sys
 d=json.loads(open('gpurun_out/refgrid.json').read().strip().splitlines()[-1])
 k=d['kernels']
-print('%-9s %2s shots | %7.1f Mcells*steps/s | fwd %6.2f us adj %6.2f us per step | %s | fallbacks %s verified %s' % (sys.argv[1], sys.argv[2], d['value'], k['forward+save']['avg_step_s']*1e6, k['adjoint+imaging']['avg_step_s']*1e6, d['config'].get('kernel_family','?'), d['check'].get('fallbacks'), d['check'].get('verified')))" $1 $2
+print('%-9s %2s shots | %7.1f Mcells*steps/s | fwd %6.2f us adj %6.2f us per step | %s | fallbacks %s verified %s' % (sys.argv[1], sys.argv[2], d['value'], k['forward+save']['us_per_step'], k['adjoint+imaging']['us_per_step'], d['config'].get('kernel_family','?'), d['check'].get('fallbacks'), d['check'].get('verified')))" $1 $2
 done
