@@ -5,7 +5,7 @@ one() {
   python -c "
 import json
 d=json.loads(open('gpurun_out/v.json').read().strip().splitlines()[-1])
-print('$1', round(d['value']), {k:round(v['avg_step_s']*1e6,2) for k,v in d['kernels'].items()}, d['check']['verified'], d['check']['bitwise_repeatable'])"
+print('$1', round(d['value']), {k:round(v['us_per_step'],2) for k,v in d['kernels'].items()}, d['check']['verified'], d['check']['bitwise_repeatable'])"
 }
 echo "== in-tree"; one elastic_marmousi && one acoustic_marmousi || exit 1
 for V in physicsbasedfwi2_amd/_variants/*.so; do

@@ -3,4 +3,4 @@ timeout -k 10 300 python bench.py --workload acoustic_marmousi --steps 5 --warmu
 python -c "
 import json
 d=json.loads(open('gpurun_out/c2.json').read().strip().splitlines()[-1])
-print(round(d['value']), d['ms_per_step'], {k:round(v['avg_step_s']*1e6,2) for k,v in d['kernels'].items()}, d['check'])"
+print(round(d['value']), d['ms_per_step'], {k:round(v['us_per_step'],2) for k,v in d['kernels'].items()}, d['check'])"

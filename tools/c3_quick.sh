@@ -4,5 +4,5 @@ timeout -k 10 300 python bench.py --workload elastic_marmousi --steps 5 --warmup
 python -c "
 import json
 d=json.loads(open('gpurun_out/c3.json').read().strip().splitlines()[-1])
-print(round(d['value']), {k:round(v['avg_step_s']*1e6,2) for k,v in d['kernels'].items()}, d['check'])"
+print(round(d['value']), {k:round(v['us_per_step'],2) for k,v in d['kernels'].items()}, d['check'])"
 if [ "$1" = trace ]; then bash tools/trace_c3.sh | tail -14; fi

@@ -11,7 +11,7 @@ for W in 10 20; do
     python -c "
 import json,sys
 d=json.loads(open('gpurun_out/pml_lds_${W}_${L}.json').read().strip().splitlines()[-1])
-print(d['value'], d['unit'], {k:(round(v['avg_step_s']*1e6,2), v.get('lds_resident')) for k,v in d['kernels'].items()}, d.get('check'))
+print(d['value'], d['unit'], {k:(round(v['us_per_step'],2), v.get('alg_B_per_cell')) for k,v in d['kernels'].items()}, d.get('check'))
 "
   done
 done
