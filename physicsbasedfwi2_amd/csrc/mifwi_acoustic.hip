@@ -372,6 +372,10 @@ __global__ void ac_finalize(const float *acc, int ngroups, int n0, int n1, int g
 // The arithmetic per cell is the same fmaf chain as ac_step (bitwise identical results).
 // ================================================================================================
 constexpr int kClThreads = 1024;
+#ifndef MIFWI_PML_RELOAD_R
+#define MIFWI_PML_RELOAD_R 1
+#endif
+constexpr bool kPmlReloadR = MIFWI_PML_RELOAD_R;
 constexpr int kClPmlLdsLimit = 160 * 1024 - 1024;    // dynamic LDS a C-PML launch may ask for (272 B of static LDS next to it)
 constexpr int kClMaxNG = 4;                  // groups of 4 cells a thread may own
 constexpr unsigned kClMaxSpin = 400000;
@@ -435,6 +439,7 @@ struct ClParams {
     int *xcc_tab;                        // [nshot][NW] XCC_ID + 1 of each slab's workgroup (mifwi::same_xcd)
     AcPml pml;                           // second-order C-PML (PML = true variants): strip / region arrays in global memory
     int pml_lds_floats;                  // dynamic LDS of the launch in floats: what a slab may carve layer arrays from (pml_place)
+    int pml_own;                         // edge slabs run the layer of axis 0 in the own-group form (pml_own_*) if its planes fit
 #ifdef MIFWI_ABLATIONS
     long long *trace;                    // phase time stamps of one workgroup (MIFWI_AC_CL_TRACE), see CL_STAMP
 #endif
@@ -577,10 +582,10 @@ __device__ __forceinline__ int cl_opaque(int x)
 // slab's own rows - the phases run before the hand-off poll.
 __device__ __forceinline__ void cl_pml_sync() { __syncthreads(); }
 template <class F>
-__device__ __forceinline__ void cl_pml_cells(const AcPml &m, int w, int NW, int r0, int R, int t, F f)
+__device__ __forceinline__ void cl_pml_cells(const AcPml &m, int w, int NW, int r0, int R, int t, bool skip0, F f)
 {
     const unsigned W2 = (unsigned)m.W + 2u, ng = (unsigned)m.gp / 4u;
-    if (w == 0 || w == NW - 1) {                       // axis 0: the W + 2 rows of this end of the grid, groups of four cells
+    if ((w == 0 || w == NW - 1) && !skip0) {                       // axis 0: the W + 2 rows of this end of the grid, groups of four cells
         const unsigned base = w == 0 ? 0u : W2 * ng;
         for (unsigned e = (unsigned)t; e < W2 * ng; e += kClThreads) f(pml_cell(m, base + e, 0), 0);
     }
@@ -614,15 +619,24 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     // others in global memory.  `m` is p.pml with the pointers of the LDS-resident arrays redirected to the slab's own
     // part of each array; m.lds / m.f* tell the cell functions which index that part starts at (pml_off).
     AcPml m = p.pml;
+    bool own = false;                             // edge slab in the own-group form; its planes (Psi | P, Q)
+    float *plP = nullptr, *plQ = nullptr;
     if (PML) {
         const long long W = m.W, W2 = m.W + 2;
         const bool edge = w == 0 || w == p.NW - 1;
-        const long long base = 2LL * LR * PL + p.gp + ((R + 3) & ~3);
+        long long base = 2LL * LR * PL + p.gp + ((R + 3) & ~3);
         long long used = 0;
-        m.lds = pml_place(adj, edge, R, m.W, m.gp, (long long)p.pml_lds_floats - base, &used);
+        float *q = ldq0 + ((R + 3) & ~3);
+        // edge slabs: the own-group form of the layer of axis 0 (mifwi_acoustic_cpml.h) if its planes fit behind the field planes
+        own = edge && p.pml_own && R == m.W + 2 && base + pml_own_floats(adj, R, PL) <= (long long)p.pml_lds_floats;
+        if (own) {
+            plP = q; plQ = q + (adj ? LR * PL : 0);
+            q += pml_own_floats(adj, R, PL); base += pml_own_floats(adj, R, PL);
+            for (int e = t; e < (int)pml_own_floats(adj, R, PL); e += kClThreads) plP[e] = 0.f;
+        }
+        m.lds = pml_place(adj, edge, R, m.W, m.gp, (long long)p.pml_lds_floats - base, &used, own);
         m.f0s = w == 0 ? 0 : W * m.gp; m.f0r = w == 0 ? 0 : W2 * m.gp;      // first index of this slab's part
         m.f1s = (long long)r0 * 2 * W; m.f1r = (long long)r0 * 2 * W2;
-        float *q = ldq0 + ((R + 3) & ~3);
         auto take = [&](int bit, float *&ptr) {
             if (m.lds & (unsigned)bit) { ptr = q; q += pml_lds_floats(bit, R, m.W, m.gp); }
         };
@@ -639,6 +653,14 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         };
         copy(PML_A1, m.A1, p.pml.A1, m.f1s, 2 * W * R, m.s1); copy(PML_B1, m.B1, p.pml.B1, m.f1s, 2 * W * R, m.s1);
         if (edge) { copy(PML_A0, m.A0, p.pml.A0, m.f0s, W * m.gp, m.s0); copy(PML_B0, m.B0, p.pml.B0, m.f0s, W * m.gp, m.s0); }
+        if (own && !adj) {                   // Psi of the strip's rows into its plane (the zeroing above is by the same threads... not: barrier)
+            __syncthreads();
+            const float *src = p.pml.A0 + (long long)s * m.s0 + m.f0s;
+            for (int e = t; e < (int)(W * m.gp); e += kClThreads) {
+                const int row = e / m.gp, col = e - row * m.gp;
+                plP[(row + (w == 0 ? 0 : 2) + 2) * PL + 4 + col] = src[e];
+            }
+        }
     }
     const int ngrp = R * p.ng;
     // row order with the four boundary rows first, so that a thread's slot 0 covers every group the
@@ -688,7 +710,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             const int lrw = row_of(kr), j = r0 + lrw;
             loff[i] = (lrw + 2) * PL + 4 + 4 * g;
             jg[i] = (j << 12) | g;
-            rr[i] = *reinterpret_cast<const float4 *>(p.r + (long long)j * p.gp + 4 * g);
+            if (!(PML && adj && kPmlReloadR)) rr[i] = *reinterpret_cast<const float4 *>(p.r + (long long)j * p.gp + 4 * g);
             const float4 q1 = *reinterpret_cast<const float4 *>(p.q1 + 4 * g);
             const float q0 = p.q0[j];
             if (PML ? pml_layer_group(m, j, g) : (q0 != 0.f || q1.x != 0.f || q1.y != 0.f || q1.z != 0.f || q1.w != 0.f))
@@ -917,22 +939,48 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         CL_STAMP(1);
         if (PML) {
             const float *ul = cur + (2 - r0) * PL + 4;             // ul[i0 * PL + i1] = the current field at grid cell (i0, i1)
+            // edge slabs in the own-group form: axis 0 by the owner of each group (phase 0 / 1; e0 inside the update)
+            auto own_phase = [&](int ph) {
+#pragma unroll
+                for (int i = 0; i < kClMaxNG; ++i)
+                    if (i < nown) {
+                        const int lo_i = cl_opaque(loff[i]), jg_i = cl_opaque(jg[i]);
+                        const int j = jg_i >> 12, g = jg_i & 4095;
+                        if (!adj) pml_own_fwd_psi(m, w == 0, j - r0, j, cur + lo_i, plP + lo_i, PL);
+                        else if (ph == 0) pml_own_adj_a(m, s, w == 0, j - r0, j, g, cur + lo_i, plP + lo_i);
+                        else pml_own_adj_b(m, s, w == 0, j - r0, j, g, cur + lo_i, plP + lo_i, plQ + lo_i, PL);
+                    }
+            };
             if (!adj) {
-                cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_fwd_psi_cell(m, s, ax, c, ul, PL); });
+                if (own) own_phase(0);
+                cl_pml_cells(m, w, p.NW, r0, R, t, own, [&](const PmlCell &c, int ax) { ac_pml_fwd_psi_cell(m, s, ax, c, ul, PL); });
                 CL_STAMP(11);
                 cl_pml_sync();
                 CL_STAMP(12);
-                cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_fwd_zeta_cell(m, s, ax, c, ul, PL); });
+                cl_pml_cells(m, w, p.NW, r0, R, t, own, [&](const PmlCell &c, int ax) { ac_pml_fwd_zeta_cell(m, s, ax, c, ul, PL); });
                 CL_STAMP(13);
             } else {
-                cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_adj_a_cell(m, s, ax, c, ul, PL); });
+                if (own) own_phase(0);
+                cl_pml_cells(m, w, p.NW, r0, R, t, own, [&](const PmlCell &c, int ax) { ac_pml_adj_a_cell(m, s, ax, c, ul, PL); });
+                CL_STAMP(11);
                 cl_pml_sync();
-                cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_adj_b_cell(m, s, ax, c, ul, PL); });
+                CL_STAMP(12);
+                if (own) own_phase(1);
+                cl_pml_cells(m, w, p.NW, r0, R, t, own, [&](const PmlCell &c, int ax) { ac_pml_adj_b_cell(m, s, ax, c, ul, PL); });
+                CL_STAMP(13);
                 cl_pml_sync();
-                cl_pml_cells(m, w, p.NW, r0, R, t, [&](const PmlCell &c, int ax) { ac_pml_adj_c_cell(m, s, ax, c, ul, PL); });
+                CL_STAMP(15);
+                cl_pml_cells(m, w, p.NW, r0, R, t, own, [&](const PmlCell &c, int ax) { ac_pml_adj_c_cell(m, s, ax, c, ul, PL); });
             }
             cl_pml_sync();
             CL_STAMP(14);
+        }
+        // C-PML variants: the model coefficients of the own groups are not kept over the layer's phases (16 registers the
+        // phases need): read again here, from L2, for the update that follows
+        if (PML && adj && kPmlReloadR) {
+#pragma unroll
+            for (int i = 0; i < kClMaxNG; ++i)
+                if (i < nown) rr[i] = *reinterpret_cast<const float4 *>(p.r + goff_of(cl_opaque(jg[i])));
         }
         // ---- stencil: new field overwrites prv in place (prv is only read at the own cell) --
         float *Gn = (MODE == 1) ? p.G + (long long)(n - p.g_first) * p.g_step + plane : nullptr;
@@ -954,7 +1002,16 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 }
                 float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
                 // the layer's term of the group's four cells (an exact zero for the groups away from the layer: not read)
-                if (PML && ((dampmask >> i) & 1u)) pe = pml_term(m, s, jg_i >> 12, jg_i & 4095, adj, (dampmask >> (4 + i)) & 1u);
+                if (PML && ((dampmask >> i) & 1u)) {
+                    if (own) {
+                        const int j = jg_i >> 12;
+                        const float4 e0 = adj ? pml_own_adj_e0(plP + lo_i, plQ + lo_i, PL)
+                                              : pml_own_fwd_e0(m, s, w == 0, j - r0, j, jg_i & 4095, cur + lo_i, plP + lo_i, PL);
+                        pe = pml_term(m, s, j, jg_i & 4095, adj, (dampmask >> (4 + i)) & 1u, &e0);
+                    } else {
+                        pe = pml_term(m, s, jg_i >> 12, jg_i & 4095, adj, (dampmask >> (4 + i)) & 1u);
+                    }
+                }
                 cl_update<MODE == 1, PML>(cur + lo_i, prv + lo_i, PL, rr[i], q0, q1, damped, p.c0, p.c1,
                                           p.n1 - 4 * (jg_i & 4095), un, gk, pe);
                 if (!adj && !slow_sparse && i == src_slot) {
@@ -1131,6 +1188,13 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         };
         back(PML_A1, p.pml.A1, m.A1, m.f1s, 2 * W * R, m.s1); back(PML_B1, p.pml.B1, m.B1, m.f1s, 2 * W * R, m.s1);
         if (edge) { back(PML_A0, p.pml.A0, m.A0, m.f0s, W * m.gp, m.s0); back(PML_B0, p.pml.B0, m.B0, m.f0s, W * m.gp, m.s0); }
+        if (own && !adj) {                   // Psi: the strip's rows of the plane
+            float *dst = p.pml.A0 + (long long)s * m.s0 + m.f0s;
+            for (int e = t; e < (int)(W * m.gp); e += kClThreads) {
+                const int row = e / m.gp, col = e - row * m.gp;
+                dst[e] = plP[(row + (w == 0 ? 0 : 2) + 2) * PL + 4 + col];
+            }
+        }
     }
     // ---- write the state (own rows of both levels) and the accumulators back --------------------
     const int parE = adj ? ((p.nt - 1 - (p.n_last - 1)) & 1) : (p.n_last & 1);
@@ -1296,9 +1360,13 @@ void cluster_setup(mifwi_acoustic_plan *pl)
                 for (int cls = 0; cls < 2; ++cls)
                     for (int adjm = 0; adjm < 2; ++adjm) {
                         const int rws = cls == 0 ? rt : rows_int;
-                        const long long base = 2LL * (rws + 4) * pl->PL + pl->gp + ((rws + 3) & ~3);
+                        long long base = 2LL * (rws + 4) * pl->PL + pl->gp + ((rws + 3) & ~3);
                         long long used = 0;
-                        pml_place(adjm != 0, cls == 0, rws, pl->pmlW, pl->gp, cap - base, &used);
+                        // (the kernel's own decision, from the same numbers: ac_cluster, `own`)
+                        const bool own = cls == 0 && env_int("MIFWI_AC_PML_OWN", 1) != 0 &&
+                                         base + pml_own_floats(adjm != 0, rws, pl->PL) <= cap;
+                        if (own) base += pml_own_floats(adjm != 0, rws, pl->PL);
+                        pml_place(adjm != 0, cls == 0, rws, pl->pmlW, pl->gp, cap - base, &used, own);
                         need = std::max(need, base + used);
                     }
                 lds = std::min<long long>(need, cap) * (long long)sizeof(float);
@@ -1368,6 +1436,7 @@ ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const flo
     // tests: pretend the launch has this many KB less LDS, so that pml_place keeps only a prefix of its list in LDS (every
     // partial placement must give the same bits)
     c.pml_lds_floats = std::max(0, c.pml_lds_floats - 256 * env_int("MIFWI_AC_PML_LDS_SHRINK_KB", 0));
+    c.pml_own = env_int("MIFWI_AC_PML_OWN", 1);
     return c;
 }
 

@@ -61,7 +61,9 @@ __host__ __device__ inline long long pml_lds_floats(int bit, int rows, int W, in
     }
     return (n + 3) & ~3LL;
 }
-__host__ __device__ inline unsigned pml_place(bool adjoint, bool edge, int rows, int W, int gp, long long free_floats, long long *used)
+// own = the edge slab runs the layer of axis 0 in the own-group form below (pml_own_*): its arrays are not placed here
+__host__ __device__ inline unsigned pml_place(bool adjoint, bool edge, int rows, int W, int gp, long long free_floats, long long *used,
+                                              bool own = false)
 {
     const int fwd[6] = {PML_A1, PML_E1, PML_A0, PML_E0, PML_B1, PML_B0};
     const int adj[10] = {PML_P1, PML_Q1, PML_E1, PML_P0, PML_Q0, PML_E0, PML_A1, PML_B1, PML_A0, PML_B0};
@@ -70,7 +72,7 @@ __host__ __device__ inline unsigned pml_place(bool adjoint, bool edge, int rows,
     for (int k = 0; k < (adjoint ? 10 : 6); ++k) {
         const int bit = adjoint ? adj[k] : fwd[k];
         const bool axis0 = bit & (PML_A0 | PML_B0 | PML_P0 | PML_Q0 | PML_E0);
-        if (axis0 && !edge) continue;
+        if (axis0 && (!edge || own)) continue;
         const long long n = pml_lds_floats(bit, rows, W, gp);
         if (u + n <= free_floats) { mask |= (unsigned)bit; u += n; }
     }
@@ -324,14 +326,16 @@ __device__ __forceinline__ bool pml_layer_group(const AcPml &m, int j, int g)
 // ac_cluster<PML> add to their Laplacian): forward fma(c0, e0, c1 e1), adjoint e0 + e1.  Branch-free loads.
 // in1 = false: the caller knows that none of the group's cells lies in the region of axis 1 (only the two short runs at
 // the ends of a row do): e1 is an exact zero there and is not read
-__device__ __forceinline__ float4 pml_term(const AcPml &m, int s, int j, int g, bool adjoint, bool in1 = true)
+// (e0own != nullptr: the caller holds e0 of the four cells - the own-group form of the edge slabs, where every row lies
+// in the region of axis 0 - and the region array of axis 0 is not read)
+__device__ __forceinline__ float4 pml_term(const AcPml &m, int s, int j, int g, bool adjoint, bool in1 = true, const float4 *e0own = nullptr)
 {
     const int W2 = m.W + 2;
     const bool rlo = j < W2, rhi = j >= m.n0 - W2;
     int l0 = rlo ? j : W2 + j - (m.n0 - W2);
     l0 = l0 < 0 ? 0 : (l0 > 2 * W2 - 1 ? 2 * W2 - 1 : l0);
-    const float4 e0v = pml_ld4(m.e0 + (pml_off(m, PML_E0, s) + (l0 * m.gp + 4 * g)));
-    const bool ok0 = rlo || rhi;
+    const float4 e0v = e0own ? *e0own : pml_ld4(m.e0 + (pml_off(m, PML_E0, s) + (l0 * m.gp + 4 * g)));
+    const bool ok0 = e0own ? true : (rlo || rhi);
     float e1v[4] = {0.f, 0.f, 0.f, 0.f};
     if (in1) {
         const float *pe1 = m.e1 + (pml_off(m, PML_E1, s) + j * 2 * W2);
@@ -352,6 +356,103 @@ __device__ __forceinline__ float4 pml_term(const AcPml &m, int s, int j, int g, 
         ev[c] = adjoint ? e0 + e1v[c] : fmaf(m.c0, e0, m.c1 * e1v[c]);
     }
     return make_float4(ev[0], ev[1], ev[2], ev[3]);
+}
+
+// ---- the own-group form of the edge slabs (single-launch kernels) -----------------------------------------------------
+// An edge slab holds exactly the W + 2 rows of its end of the grid: every group a thread updates there is a region cell of
+// axis 0, so the thread that owns a group runs the layer's recursions of axis 0 on it - no thread map, no index
+// arithmetic.  The exchanged variables (Psi forward; P, Q adjoint) live in LDS planes shaped like the slab's field planes
+// ([R + 4][PL], own row l at plane row l + 2, zero outside the strip: halo and beyond-the-strip reads need no clamp and no
+// select), so a neighbour's value is the own address +- k PL.  The pointwise memory variables (Z forward; Zb, Pb adjoint)
+// stay in the global state arrays.  e0 is computed where it is used, inside the field update of the same thread.  Same
+// operations in the same order as the cell functions above: the same bits.
+//   top = the slab at row 0 (strip = own rows l < W), else the slab at the last row (strip = l >= 2);  j = the grid row,
+//   u / P / Q / Psi = the plane's element of the group's first cell
+__host__ __device__ inline long long pml_own_floats(bool adjoint, int rows, int PL) { return (adjoint ? 2LL : 1LL) * (rows + 4) * PL; }
+__device__ __forceinline__ bool pml_own_strip(const AcPml &m, bool top, int l) { return top ? l < m.W : l >= 2; }
+__device__ __forceinline__ long long pml_own_idx(const AcPml &m, int s, bool top, int l, int g)
+{
+    return (long long)s * m.s0 + ((top ? l : m.W + l - 2) * m.gp + 4 * g);
+}
+__device__ __forceinline__ void pml_own_fwd_psi(const AcPml &m, bool top, int l, int j, const float *u, float *Psi, int PL)
+{
+    if (!pml_own_strip(m, top, l)) return;
+    const float4 m2 = pml_ld4(u - 2 * PL), m1 = pml_ld4(u - PL), p1 = pml_ld4(u + PL), p2 = pml_ld4(u + 2 * PL);
+    const float4 a4 = pml_ld4(Psi);
+    const float a = m.ab0[j], b = m.ab0[m.n0 + j];
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = fmaf(b, comp(a4, q), a * pml_d1(comp(m2, q), comp(m1, q), comp(p1, q), comp(p2, q)));
+    pml_st4(Psi, o);
+}
+// forward, inside the update: Z on the strip, e0 = D1 Psi + Z on the region
+__device__ __forceinline__ float4 pml_own_fwd_e0(const AcPml &m, int s, bool top, int l, int j, int g, const float *u, const float *Psi, int PL)
+{
+    const bool strip = pml_own_strip(m, top, l);
+    const float4 am2 = pml_ld4(Psi - 2 * PL), am1 = pml_ld4(Psi - PL), ap1 = pml_ld4(Psi + PL), ap2 = pml_ld4(Psi + 2 * PL);
+    float dp[4], z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dp[q] = pml_d1(comp(am2, q), comp(am1, q), comp(ap1, q), comp(ap2, q));
+    if (strip) {
+        float *B = m.B0 + pml_own_idx(m, s, top, l, g);
+        const float4 b4 = pml_ld4(B);
+        const float a = m.ab0[j], b = m.ab0[m.n0 + j];
+        const float4 m2 = pml_ld4(u - 2 * PL), m1 = pml_ld4(u - PL), uc = pml_ld4(u), p1 = pml_ld4(u + PL), p2 = pml_ld4(u + 2 * PL);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            z[q] = fmaf(b, comp(b4, q), a * (pml_d2(comp(m2, q), comp(m1, q), comp(uc, q), comp(p1, q), comp(p2, q)) + dp[q]));
+        pml_st4(B, z);
+    }
+    return make_float4(dp[0] + z[0], dp[1] + z[1], dp[2] + z[2], dp[3] + z[3]);
+}
+__device__ __forceinline__ void pml_own_adj_a(const AcPml &m, int s, bool top, int l, int j, int g, const float *u, float *P)
+{
+    if (!pml_own_strip(m, top, l)) return;
+    float *B = m.B0 + pml_own_idx(m, s, top, l, g);
+    const float4 w4 = pml_ld4(u), b4 = pml_ld4(B);
+    const float a = m.ab0[j], b = m.ab0[m.n0 + j];
+    float Pv[4], Z[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float t = fmaf(m.c0, comp(w4, q), comp(b4, q));
+        Pv[q] = a * t; Z[q] = b * t;
+    }
+    pml_st4(P, Pv);
+    pml_st4(B, Z);
+}
+__device__ __forceinline__ void pml_own_adj_b(const AcPml &m, int s, bool top, int l, int j, int g, const float *u, const float *P, float *Q, int PL)
+{
+    if (!pml_own_strip(m, top, l)) return;
+    float *A = m.A0 + pml_own_idx(m, s, top, l, g);
+    float4 w[4], pp[4];
+    const int off[4] = {-2, -1, 1, 2};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { w[o] = pml_ld4(u + off[o] * PL); pp[o] = pml_ld4(P + off[o] * PL); }
+    const float4 a4 = pml_ld4(A);
+    const float a = m.ab0[j], b = m.ab0[m.n0 + j];
+    float Qv[4], T[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float v0 = fmaf(m.c0, comp(w[0], q), comp(pp[0], q)), v1 = fmaf(m.c0, comp(w[1], q), comp(pp[1], q));
+        const float v2 = fmaf(m.c0, comp(w[2], q), comp(pp[2], q)), v3 = fmaf(m.c0, comp(w[3], q), comp(pp[3], q));
+        const float t = comp(a4, q) - pml_d1(v0, v1, v2, v3);
+        Qv[q] = a * t; T[q] = b * t;
+    }
+    pml_st4(Q, Qv);
+    pml_st4(A, T);
+}
+// adjoint, inside the update: e0 = D2 P - D1 Q on the region
+__device__ __forceinline__ float4 pml_own_adj_e0(const float *P, const float *Q, int PL)
+{
+    float4 pv[5], qv[5];
+#pragma unroll
+    for (int o = 0; o < 5; ++o) { pv[o] = pml_ld4(P + (o - 2) * PL); if (o != 2) qv[o] = pml_ld4(Q + (o - 2) * PL); }
+    float e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        e[q] = pml_d2(comp(pv[0], q), comp(pv[1], q), comp(pv[2], q), comp(pv[3], q), comp(pv[4], q)) -
+               pml_d1(comp(qv[0], q), comp(qv[1], q), comp(qv[3], q), comp(qv[4], q));
+    return make_float4(e[0], e[1], e[2], e[3]);
 }
 
 // ---- the thin launches of the one-launch-per-step family: one thread per cell (group), u = the global wavefield -------

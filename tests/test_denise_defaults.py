@@ -44,3 +44,23 @@ def test_assignments_are_classified_not_swallowed():
         with pytest.raises(AttributeError):
             setattr(d, typo, 1)
     d._private_note = 3                                     # the shim's own state
+
+
+def test_deepwave_shim_defaults_to_a_pml_of_the_references_width_and_never_runs_on_the_cpu():
+    """`deepwave.scalar.Propagator({'vp': model}, dx)` as models/networks.py:3360 constructs it (no pml_width: deepwave's
+    own default, 10 cells each side - SURVEY.md appendix C) gets a PML, not the sponge; the sponge is an explicit
+    opt-out; unknown modes and CPU models fail loudly (the product has no CPU path)."""
+    import pytest
+    import torch
+    from physicsbasedfwi2_amd import MifwiError
+    from physicsbasedfwi2_amd.compat.deepwave import scalar
+    vp = torch.full((20, 30), 2000.0)
+    p = scalar.Propagator({"vp": vp}, 10.0)
+    assert p.absorbing == "cpml" and p.pml_width == scalar.DEFAULT_PML_WIDTH == 10 and tuple(p.spacing) == (10.0, 10.0)
+    assert scalar.Propagator({"vp": vp}, 10.0, pml_width=25, absorbing="sponge").pml_width == 25
+    with pytest.raises(MifwiError):
+        scalar.Propagator({"vp": vp}, 10.0, absorbing="none")
+    with pytest.raises(MifwiError):
+        scalar.Propagator({"rho": vp}, 10.0)
+    with pytest.raises(MifwiError, match="no CPU fallback"):
+        p(torch.zeros(8, 1, 1), torch.zeros(1, 1, 2), torch.zeros(1, 1, 2), 1e-3)

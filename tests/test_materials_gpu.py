@@ -87,3 +87,37 @@ def test_fused_acoustic_coefficients_match_the_torch_expression(nz, nx, pad):
     a2 = vp0.clone().requires_grad_(True)
     scalar._Coefficients.apply(a2, pad, c).backward(g)
     assert torch.equal(a2.grad, a.grad)
+
+
+@pytest.mark.parametrize("mode", [elastic.PARAM_VELOCITY, elastic.PARAM_IMPEDANCE, elastic.PARAM_LAME])
+def test_gradient_parametrization_is_the_jacobian_of_the_change_of_variables(mode):
+    """mifwi_elastic_gradient_parametrization (DENISE's INVMAT1, models/networks.py:11025) against float64 autograd of
+    the change of variables itself: (Zp, Zs, rho) -> (Zp / rho, Zs / rho, rho) and (lambda, mu, rho) ->
+    (sqrt((lambda + 2 mu) / rho), sqrt(mu / rho), rho), a random cotangent pulled back.  Water cells (Vs = 0) take no
+    Vs term in the Lame form (the kernel's convention: the shear gradient is 0 there anyway - mu_xz = 0)."""
+    dev = torch.device("cuda:0")
+    vp, vs, rho = _models(41, 67, 11, 5)
+    rng = np.random.default_rng(12)
+    g = [torch.tensor(rng.standard_normal(vp.shape), dtype=torch.float32) for _ in range(3)]
+    g[1][vs == 0] = 0.0
+    out = elastic.gradient_parametrization([t.to(dev) for t in (vp, vs, rho)], [t.to(dev) for t in g], mode)
+    P, Q, R = (t.double() for t in (vp, vs, rho))
+    if mode == elastic.PARAM_VELOCITY:
+        new = [P.clone().requires_grad_(True), Q.clone().requires_grad_(True), R.clone().requires_grad_(True)]
+        old = new
+    elif mode == elastic.PARAM_IMPEDANCE:
+        new = [(R * P).requires_grad_(True), (R * Q).requires_grad_(True), R.clone().requires_grad_(True)]
+        old = [new[0] / new[2], new[1] / new[2], new[2]]
+    else:
+        mu = R * Q * Q
+        new = [(R * P * P - 2 * mu).requires_grad_(True), mu.requires_grad_(True), R.clone().requires_grad_(True)]
+        wet = Q == 0
+        shear = torch.where(wet, torch.zeros_like(mu), torch.sqrt(torch.where(wet, torch.ones_like(mu), new[1]) / new[2]))
+        old = [torch.sqrt((new[0] + 2 * new[1]) / new[2]), shear, new[2]]
+    sum((o * c.double()).sum() for o, c in zip(old, g)).backward()
+    for k in range(3):
+        want = new[k].grad
+        got = out[k].cpu().double()
+        assert float((got - want).abs().max()) <= 4e-6 * float(want.abs().max()), (mode, k)
+    if mode == elastic.PARAM_VELOCITY:
+        assert all(torch.equal(o.cpu(), c) for o, c in zip(out, g))
