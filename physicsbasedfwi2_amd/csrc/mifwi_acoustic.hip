@@ -372,10 +372,7 @@ __global__ void ac_finalize(const float *acc, int ngroups, int n0, int n1, int g
 // The arithmetic per cell is the same fmaf chain as ac_step (bitwise identical results).
 // ================================================================================================
 constexpr int kClThreads = 1024;
-#ifndef MIFWI_PML_RELOAD_R
-#define MIFWI_PML_RELOAD_R 1
-#endif
-constexpr bool kPmlReloadR = MIFWI_PML_RELOAD_R;
+
 constexpr int kClPmlLdsLimit = 160 * 1024 - 1024;    // dynamic LDS a C-PML launch may ask for (272 B of static LDS next to it)
 constexpr int kClMaxNG = 4;                  // groups of 4 cells a thread may own
 constexpr unsigned kClMaxSpin = 400000;
@@ -710,7 +707,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             const int lrw = row_of(kr), j = r0 + lrw;
             loff[i] = (lrw + 2) * PL + 4 + 4 * g;
             jg[i] = (j << 12) | g;
-            if (!(PML && adj && kPmlReloadR)) rr[i] = *reinterpret_cast<const float4 *>(p.r + (long long)j * p.gp + 4 * g);
+            rr[i] = *reinterpret_cast<const float4 *>(p.r + (long long)j * p.gp + 4 * g);
             const float4 q1 = *reinterpret_cast<const float4 *>(p.q1 + 4 * g);
             const float q0 = p.q0[j];
             if (PML ? pml_layer_group(m, j, g) : (q0 != 0.f || q1.x != 0.f || q1.y != 0.f || q1.z != 0.f || q1.w != 0.f))
@@ -974,13 +971,6 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             }
             cl_pml_sync();
             CL_STAMP(14);
-        }
-        // C-PML variants: the model coefficients of the own groups are not kept over the layer's phases (16 registers the
-        // phases need): read again here, from L2, for the update that follows
-        if (PML && adj && kPmlReloadR) {
-#pragma unroll
-            for (int i = 0; i < kClMaxNG; ++i)
-                if (i < nown) rr[i] = *reinterpret_cast<const float4 *>(p.r + goff_of(cl_opaque(jg[i])));
         }
         // ---- stencil: new field overwrites prv in place (prv is only read at the own cell) --
         float *Gn = (MODE == 1) ? p.G + (long long)(n - p.g_first) * p.g_step + plane : nullptr;

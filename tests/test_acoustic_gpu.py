@@ -414,21 +414,25 @@ def test_cpml_born_is_the_transpose_partner_of_the_gradient(oracle32):
 def test_cpml_partial_lds_placements_give_the_same_bits(monkeypatch):
     """pml_place keeps as many of a slab's layer arrays in LDS as fit behind its planes - a prefix of a fixed list (6
     arrays forward, 10 adjoint; the axis-0 ones on the edge slabs only), the rest stays in global memory.  Which prefix
-    depends on the grid; here the launch pretends to have 0 .. 40 KB less LDS (MIFWI_AC_PML_LDS_SHRINK_KB), which walks
-    the cut through the list on edge and interior slabs alike, forward and adjoint: traces and gradients must be the same
-    bits as with every array in global memory.  Offsets are added to the cell index, never to an LDS base pointer
+    depends on the grid; here the launch pretends to have 0 .. 80 KB less LDS (MIFWI_AC_PML_LDS_SHRINK_KB), which walks
+    the cut through the list on edge and interior slabs alike, forward and adjoint - and takes the edge slabs from the
+    own-group form of axis 0 (Psi / P, Q in LDS planes shaped like the field planes, e0 inside the update) to the generic
+    one when the planes no longer fit: traces and gradients must be the same bits as with every array in global memory.  Offsets are added to the cell index, never to an LDS base pointer
     (a pointer biased below an LDS buffer leaves the LDS aperture)."""
     monkeypatch.setenv("MIFWI_AC_CLUSTER", "1")
     monkeypatch.setenv("MIFWI_AC_NW", "4")
     c = _cpml_case(seed=29, n0=88, n1=150, w=12, nt=70, ns=2, nrec=30)
     g = None
     outs = {}
-    for shrink in (None, 0, 3, 6, 9, 12, 16, 20, 26, 32, 40):
+    for shrink in (None, 0, "generic", 3, 6, 9, 12, 16, 20, 26, 32, 40, 60, 80):
+        # "generic": the edge slabs' layer of axis 0 through the thread maps and compact arrays (MIFWI_AC_PML_OWN=0) instead
+        # of the own-group form with its LDS planes - which the larger shrinks switch off as well (its planes no longer fit)
+        monkeypatch.setenv("MIFWI_AC_PML_OWN", "0" if shrink == "generic" else "1")
         if shrink is None:
             monkeypatch.setenv("MIFWI_AC_PML_LDS", "0")
         else:
             monkeypatch.setenv("MIFWI_AC_PML_LDS", "1")
-            monkeypatch.setenv("MIFWI_AC_PML_LDS_SHRINK_KB", str(shrink))
+            monkeypatch.setenv("MIFWI_AC_PML_LDS_SHRINK_KB", "0" if shrink == "generic" else str(shrink))
         r, f, rec = _run_cpml(c)
         if g is None:
             g = torch.sign(rec.detach()) + 0.25
