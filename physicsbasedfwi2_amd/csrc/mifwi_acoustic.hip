@@ -437,6 +437,7 @@ struct ClParams {
     AcPml pml;                           // second-order C-PML (PML = true variants): strip / region arrays in global memory
     int pml_lds_floats;                  // dynamic LDS of the launch in floats: what a slab may carve layer arrays from (pml_place)
     int pml_own;                         // edge slabs run the layer of axis 0 in the own-group form (pml_own_*) if its planes fit
+    int pml_late_e;                      // the groups of axis 1's region in slot 0, no barrier behind the layer's last phase
 #ifdef MIFWI_ABLATIONS
     long long *trace;                    // phase time stamps of one workgroup (MIFWI_AC_CL_TRACE), see CL_STAMP
 #endif
@@ -678,10 +679,22 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
     // of both.  Which thread updates a group does not change any result.  The permutation lives in
     // the (not yet staged) plane memory.
     int *perm = reinterpret_cast<int *>(lds);
-    __shared__ int perm_cnt[2];
+    __shared__ int perm_cnt[3];
+    // C-PML plans: the groups at the two ends of a row (the region of axis 1) go right behind the boundary rows, i.e. into
+    // slot 0 - the slot that is updated behind barrier A.  If all of them fit there (late_e), the layer's last phase (the
+    // term e of axis 1, read by exactly these groups) needs no barrier of its own: A orders it.
+    bool late_e = false;
     {
         const int nb = min(4 * p.ng, ngrp);
-        if (t < 2) perm_cnt[t] = 0;
+        int nin1 = 0;
+        if (PML) {
+            int per_row = 0;
+            for (int g = 0; g < p.ng; ++g) per_row += (4 * g < m.W + 2 || 4 * g + 3 >= m.n1 - (m.W + 2)) ? 1 : 0;
+            nin1 = per_row * max(R - 4, 0);
+            late_e = p.pml_late_e && nb + nin1 <= kClThreads;
+            if (!late_e) nin1 = 0;
+        }
+        if (t < 3) perm_cnt[t] = 0;
         __syncthreads();
         for (int gi = t; gi < ngrp; gi += kClThreads) {
             if (gi < nb) { perm[gi] = gi; continue; }
@@ -690,7 +703,8 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
             // (C-PML plans have no sponge: there the groups of the layer, whose update adds the layer's term, go last)
             const bool dmp = PML ? pml_layer_group(m, r0 + row_of(kr), g)
                                  : p.q0[r0 + row_of(kr)] != 0.f || q1.x != 0.f || q1.y != 0.f || q1.z != 0.f || q1.w != 0.f;
-            if (!dmp) perm[nb + atomicAdd(&perm_cnt[0], 1)] = gi;
+            if (PML && late_e && (4 * g < m.W + 2 || 4 * g + 3 >= m.n1 - (m.W + 2))) perm[nb + atomicAdd(&perm_cnt[2], 1)] = gi;
+            else if (!dmp) perm[nb + nin1 + atomicAdd(&perm_cnt[0], 1)] = gi;
             else perm[ngrp - 1 - atomicAdd(&perm_cnt[1], 1)] = gi;
         }
         __syncthreads();
@@ -969,7 +983,9 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
                 CL_STAMP(15);
                 cl_pml_cells(m, w, p.NW, r0, R, t, own, [&](const PmlCell &c, int ax) { ac_pml_adj_c_cell(m, s, ax, c, ul, PL); });
             }
-            cl_pml_sync();
+            // the last phase's e is read by the update: of every group on an edge slab in the generic form (barrier), of the
+            // groups at the ends of the rows otherwise - in slot 0, behind barrier A, when late_e
+            if (!(late_e && (own || !(w == 0 || w == p.NW - 1)))) cl_pml_sync();
             CL_STAMP(14);
         }
         // ---- stencil: new field overwrites prv in place (prv is only read at the own cell) --
@@ -1427,6 +1443,7 @@ ClParams cluster_params(const mifwi_acoustic_plan *pl, const float *r, const flo
     // partial placement must give the same bits)
     c.pml_lds_floats = std::max(0, c.pml_lds_floats - 256 * env_int("MIFWI_AC_PML_LDS_SHRINK_KB", 0));
     c.pml_own = env_int("MIFWI_AC_PML_OWN", 1);
+    c.pml_late_e = env_int("MIFWI_AC_PML_LATE_E", 1);
     return c;
 }
 
