@@ -424,15 +424,18 @@ def test_cpml_partial_lds_placements_give_the_same_bits(monkeypatch):
     c = _cpml_case(seed=29, n0=88, n1=150, w=12, nt=70, ns=2, nrec=30)
     g = None
     outs = {}
-    for shrink in (None, 0, "generic", 3, 6, 9, 12, 16, 20, 26, 32, 40, 60, 80):
+    for shrink in (None, 0, "generic", "barrier", 3, 6, 9, 12, 16, 20, 26, 32, 40, 60, 80):
         # "generic": the edge slabs' layer of axis 0 through the thread maps and compact arrays (MIFWI_AC_PML_OWN=0) instead
-        # of the own-group form with its LDS planes - which the larger shrinks switch off as well (its planes no longer fit)
+        # of the own-group form with its LDS planes - which the larger shrinks switch off as well (its planes no longer fit);
+        # "barrier": a barrier of its own behind the layer's last phase and the plain deal of the groups
+        # (MIFWI_AC_PML_LATE_E=0) instead of the readers of e in slot 0, behind barrier A
         monkeypatch.setenv("MIFWI_AC_PML_OWN", "0" if shrink == "generic" else "1")
+        monkeypatch.setenv("MIFWI_AC_PML_LATE_E", "0" if shrink == "barrier" else "1")
         if shrink is None:
             monkeypatch.setenv("MIFWI_AC_PML_LDS", "0")
         else:
             monkeypatch.setenv("MIFWI_AC_PML_LDS", "1")
-            monkeypatch.setenv("MIFWI_AC_PML_LDS_SHRINK_KB", "0" if shrink == "generic" else str(shrink))
+            monkeypatch.setenv("MIFWI_AC_PML_LDS_SHRINK_KB", "0" if shrink in ("generic", "barrier") else str(shrink))
         r, f, rec = _run_cpml(c)
         if g is None:
             g = torch.sign(rec.detach()) + 0.25
