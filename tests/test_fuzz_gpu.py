@@ -112,3 +112,53 @@ def test_random_acoustic_configuration(oracle32, monkeypatch, k, cfg, opt):
     gr_o, gf_o = o.acoustic_backward(case["r"], case["q0"], case["q1"], *geo, g, G, case["c0"], case["c1"])
     assert rel_l2(r.grad.cpu().numpy(), gr_o) <= 5e-5, (cfg, opt)
     assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 5e-5, (cfg, opt)
+
+
+def _cpml_configs():
+    rng = np.random.default_rng(2029)
+    out = []
+    for k in range(14):
+        w = int(rng.choice([4, 6, 7, 10, 12]))
+        cfg = dict(n0=int(rng.integers(40, 110)), n1=int(rng.integers(48, 170)), w=w, ns=int(rng.integers(1, 6)),
+                   nrec=int(rng.integers(1, 30)), nt=int(rng.integers(30, 90)), h=(10.0, float(rng.choice([10.0, 12.5]))))
+        cfg["nt"] += cfg["n1"]            # long enough for the wave to reach a receiver (the traces must not be all zero)
+        # the forms the single-launch kernels carry the layer in: edge slabs own-group / generic, the last
+        # phase with / without its own barrier, layer arrays in LDS as far as they fit / less LDS / all through L2; slab
+        # counts; the per-step family; time checkpointing
+        opt = dict(cluster=str(int(rng.integers(0, 4) > 0)), own=str(int(rng.integers(0, 3) > 0)),
+                   late=str(int(rng.integers(0, 3) > 0)), nw=str(int(rng.choice([0, 0, 3, 4, 5]))),
+                   shrink=str(int(rng.choice([0, 0, 8, 24, 60]))), lds=str(int(rng.integers(0, 4) > 0)),
+                   budget=(None if rng.integers(0, 3) else 1 << 20), gs=int(rng.integers(0, 3)))
+        out.append((k, cfg, opt))
+    return out
+
+
+@pytest.mark.parametrize("k,cfg,opt", _cpml_configs())
+def test_random_acoustic_cpml_configuration(oracle32, monkeypatch, k, cfg, opt):
+    """The second-order C-PML (the deepwave-shaped API's default layer) on random grids, widths and shot counts through
+    randomly drawn forms of the kernels, against oracle/acoustic_cpml.c: traces bit for bit, gradients <= 5e-5."""
+    from physicsbasedfwi2_amd import acoustic
+    from test_acoustic_gpu import _cpml_case
+    monkeypatch.setenv("MIFWI_AC_CLUSTER", opt["cluster"])
+    monkeypatch.setenv("MIFWI_AC_PML_OWN", opt["own"])
+    monkeypatch.setenv("MIFWI_AC_PML_LATE_E", opt["late"])
+    monkeypatch.setenv("MIFWI_AC_PML_LDS", opt["lds"])
+    monkeypatch.setenv("MIFWI_AC_PML_LDS_SHRINK_KB", opt["shrink"])
+    if opt["nw"] != "0":
+        monkeypatch.setenv("MIFWI_AC_NW", opt["nw"])
+    c = _cpml_case(seed=300 + k, **cfg)
+    o = oracle32
+    geo = (c["sc"], c["sw"], c["rc"], c["rw"])
+    rec_o, G_o = o.acoustic_cpml_forward(c["r"], c["ab0"], c["ab1"], c["f"], *geo, c["c0"], c["c1"], save=True)
+    r = torch.tensor(c["r"], dtype=torch.float32, device=DEV, requires_grad=True)
+    f = torch.tensor(c["f"], dtype=torch.float32, device=DEV, requires_grad=True)
+    kw = {} if opt["budget"] is None else {"snapshot_budget": opt["budget"]}
+    rec = acoustic.propagate(r, f, torch.tensor(c["ab0"]), torch.tensor(c["ab1"]), *[torch.tensor(a) for a in geo],
+                             c["c0"], c["c1"], cpml_width=c["w"], shots_per_group=opt["gs"], **kw)
+    scale = np.abs(rec_o).max()
+    assert scale > 0 and np.abs(rec.detach().cpu().numpy() - rec_o).max() == 0.0, (cfg, opt)
+    g = (np.random.default_rng(k).standard_normal(rec_o.shape) * scale).astype(np.float32)
+    rec.backward(torch.tensor(g, device=DEV))
+    gr_o, gf_o = o.acoustic_cpml_backward(c["r"], c["ab0"], c["ab1"], *geo, g, G_o, c["c0"], c["c1"])
+    assert rel_l2(r.grad.cpu().numpy(), gr_o) <= 5e-5, (cfg, opt)
+    assert rel_l2(f.grad.cpu().numpy(), gf_o) <= 5e-5, (cfg, opt)
