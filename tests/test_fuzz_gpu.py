@@ -1,6 +1,8 @@
 """Seeded sweep over small random configurations of the elastic path (grid sizes off the tile sizes, C-PML width,
 free surface, source type, pressure receivers, shots per accumulator group, forced shot passes, both kernel
 families): seismograms and every gradient against oracle/elastic.c."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -117,7 +119,7 @@ def test_random_acoustic_configuration(oracle32, monkeypatch, k, cfg, opt):
 def _cpml_configs():
     rng = np.random.default_rng(2029)
     out = []
-    for k in range(14):
+    for k in range(int(os.environ.get("MIFWI_FUZZ_CPML", "14"))):      # more draws: a one-off soak of the layer's kernel forms
         w = int(rng.choice([4, 6, 7, 10, 12]))
         cfg = dict(n0=int(rng.integers(40, 110)), n1=int(rng.integers(48, 170)), w=w, ns=int(rng.integers(1, 6)),
                    nrec=int(rng.integers(1, 30)), nt=int(rng.integers(30, 90)), h=(10.0, float(rng.choice([10.0, 12.5]))))
