@@ -627,7 +627,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         float *q = ldq0 + ((R + 3) & ~3);
         // edge slabs: the own-group form of the layer of axis 0 (mifwi_acoustic_cpml.h) if its planes fit behind the field planes
         own = edge && p.pml_own && R == m.W + 2 && base + pml_own_floats(adj, R, PL) <= (long long)p.pml_lds_floats;
-        if (own) {
+        if (own) {                           // planes start as zeros and only the strip's cells are ever written: zero elsewhere for good
             plP = q; plQ = q + (adj ? LR * PL : 0);
             q += pml_own_floats(adj, R, PL); base += pml_own_floats(adj, R, PL);
             for (int e = t; e < (int)pml_own_floats(adj, R, PL); e += kClThreads) plP[e] = 0.f;
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(kClThreads) void ac_cluster(const ClParams p)
         };
         copy(PML_A1, m.A1, p.pml.A1, m.f1s, 2 * W * R, m.s1); copy(PML_B1, m.B1, p.pml.B1, m.f1s, 2 * W * R, m.s1);
         if (edge) { copy(PML_A0, m.A0, p.pml.A0, m.f0s, W * m.gp, m.s0); copy(PML_B0, m.B0, p.pml.B0, m.f0s, W * m.gp, m.s0); }
-        if (own && !adj) {                   // Psi of the strip's rows into its plane (the zeroing above is by the same threads... not: barrier)
+        if (own && !adj) {                   // Psi of the strip's rows into its plane (zeroed above, by other threads: barrier first)
             __syncthreads();
             const float *src = p.pml.A0 + (long long)s * m.s0 + m.f0s;
             for (int e = t; e < (int)(W * m.gp); e += kClThreads) {
