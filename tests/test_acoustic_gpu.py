@@ -309,10 +309,10 @@ def test_deepwave_shim_substeps_when_dt_exceeds_the_stability_limit(oracle32):
     assert torch.isfinite(vp.grad).all() and float(vp.grad.abs().max()) > 0
 
 
-def _cpml_case(seed=5, n0=70, n1=90, w=10, nt=150, ns=3, nrec=24, ntap=1, h=(10.0, 10.0)):
+def _cpml_case(seed=5, n0=70, n1=90, w=10, nt=150, ns=3, nrec=24, ntap=1, h=(10.0, 10.0), nsrc=1):
     """acoustic_case with the sponge replaced by a W-cell C-PML: ab [2, n] = the a and b profiles of each axis."""
     from oracle import helpers as H
-    c = acoustic_case(seed=seed, n0=n0, n1=n1, nb=w, nt=nt, ns=ns, nrec=nrec, ntap=ntap, h=h)
+    c = acoustic_case(seed=seed, n0=n0, n1=n1, nb=w, nt=nt, ns=ns, nrec=nrec, ntap=ntap, h=h, nsrc=nsrc)
     N0, N1 = c["shape"]
     vmax = float(c["vp"].max())
     c["ab0"] = H.cpml_profiles(N0, w, h[0], c["s"], vmax, 0.02)[:2]
@@ -345,6 +345,7 @@ def _run_cpml(c, budget=None, need_f=True):
     dict(n0=60, n1=300, w=20, ns=2, nrec=40, nt=90),       # the reference's layer width, several tiles
     dict(ntap=4, nrec=9),                                  # bilinear taps
     dict(h=(10.0, 15.0)),                                  # anisotropic spacing: c0 != c1 in the layer's term
+    dict(nsrc=2, nrec=12, n0=80, n1=120),                  # two sources per shot: the rescanning variants of the single-launch kernels
 ])
 def test_cpml_forward_backward_parity(oracle32, kw):
     """Second-order C-PML (desc.cpml_width; what deepwave's pml_width is, networks.py:5408-5411) through the per-step
