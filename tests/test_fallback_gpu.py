@@ -116,6 +116,34 @@ def test_resumed_calls_fall_back_too(monkeypatch, mode):
     _same(ref_e[2:], got_e[2:])
 
 
+@pytest.mark.expects_fallback
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_cpml_calls_fall_back_too(monkeypatch, mode):
+    """The same with the second-order C-PML (the deepwave-shaped API's default layer): the state a rolled-back attempt
+    restores includes the layer's memory variables - which an edge slab in the own-group form keeps in an LDS plane during
+    the launch and writes back at its end - and the per-step kernels with their thin layer launches take over: resident
+    and time-checkpointed calls, traces bit for bit."""
+    from physicsbasedfwi2_amd import acoustic
+    from test_acoustic_gpu import _cpml_case
+
+    def run(c, **kw):
+        r = torch.tensor(c["r"], dtype=torch.float32, device=DEV, requires_grad=True)
+        f = torch.tensor(c["f"], dtype=torch.float32, device=DEV, requires_grad=True)
+        rec = acoustic.propagate(r, f, *_t(c, "ab0", "ab1", "sc", "sw", "rc", "rw"), c["c0"], c["c1"], cpml_width=c["w"], **kw)
+        rec.backward(torch.sign(rec.detach()))
+        return rec.detach(), r.grad, f.grad
+
+    c = _cpml_case(seed=97, n0=100, n1=150, w=10, nt=130, ns=3, nrec=30)
+    ref = run(c)
+    ref_ck = run(c, snapshot_budget=1 << 20)
+    _same(ref, ref_ck)
+    monkeypatch.setenv("MIFWI_TEST_FAKE_TIMEOUT", mode)
+    got, got_ck = run(c), run(c, snapshot_budget=1 << 20)
+    assert float(ref[0].abs().max()) > 0 and torch.equal(ref[0], got[0]) and torch.equal(ref[0], got_ck[0])
+    _same(ref[1:], got[1:])
+    _same(ref[1:], got_ck[1:])
+
+
 _CHILD = r"""
 import sys, json
 import numpy as np, torch
