@@ -157,6 +157,15 @@ r = torch.tensor(ca["r"], dtype=torch.float32, device=dev, requires_grad=True)
 f = torch.tensor(ca["f"], dtype=torch.float32, device=dev)
 rec = acoustic.propagate(r, f, *t(ca, "q0", "q1", "sc", "sw", "rc", "rw"), ca["c0"], ca["c1"])
 rec.backward(torch.sign(rec.detach()))
+# the same acoustic set-up with a 10-cell C-PML instead of the sponge (edge slabs in the own-group form)
+from oracle import helpers as H
+N0, N1 = ca["shape"]
+ab0 = H.cpml_profiles(N0, 10, 10.0, ca["s"], float(ca["vp"].max()), 0.02)[:2]
+ab1 = H.cpml_profiles(N1, 10, 10.0, ca["s"], float(ca["vp"].max()), 0.02)[:2]
+rc_ = torch.tensor(ca["r"], dtype=torch.float32, device=dev, requires_grad=True)
+recc = acoustic.propagate(rc_, f, torch.tensor(ab0), torch.tensor(ab1), *t(ca, "sc", "sw", "rc", "rw"), ca["c0"], ca["c1"],
+                          cpml_width=10)
+recc.backward(torch.sign(recc.detach()))
 ce = elastic_case(seed=79, nz=100, nx=300, fw=10, ns=6, nrec=100, nt=100)
 mat = torch.tensor(ce["mat"], dtype=torch.float32, device=dev, requires_grad=True)
 ef = torch.tensor(ce["f"], dtype=torch.float32, device=dev)
@@ -164,7 +173,8 @@ vx, vz = elastic.propagate(mat, ef, *t(ce, "pz", "px", "sc", "sw", "rc", "rw"), 
 torch.autograd.backward([vx, vz], [torch.sign(vx.detach()), torch.sign(vz.detach())])
 from physicsbasedfwi2_amd import _lib
 lib = _lib.load()
-np.savez(sys.argv[1], rec=rec.detach().cpu().numpy(), gr=r.grad.cpu().numpy(), vx=vx.detach().cpu().numpy(),
+np.savez(sys.argv[1], rec=rec.detach().cpu().numpy(), gr=r.grad.cpu().numpy(), recc=recc.detach().cpu().numpy(),
+         grc=rc_.grad.cpu().numpy(), vx=vx.detach().cpu().numpy(),
          vz=vz.detach().cpu().numpy(), gm=mat.grad.cpu().numpy(),
          counts=np.array([lib.mifwi_fallback_count(), lib.mifwi_agent_handoff_count(), lib.mifwi_slow_handoff_count()]))
 """
@@ -207,6 +217,7 @@ def test_a_workgroup_that_never_shows_up_times_out_on_the_device_and_the_call_fa
     else:
         assert fb == 0 and ag == 0 and slow >= 4
     assert np.abs(ref["rec"]).max() > 0 and np.array_equal(ref["rec"], abl["rec"])
+    assert np.abs(ref["recc"]).max() > 0 and np.array_equal(ref["recc"], abl["recc"]) and rel_l2(abl["grc"], ref["grc"]) <= 2e-5
     assert np.array_equal(ref["vx"], abl["vx"]) and np.array_equal(ref["vz"], abl["vz"])
     assert rel_l2(abl["gr"], ref["gr"]) <= 2e-5 and rel_l2(abl["gm"], ref["gm"]) <= 2e-5
 
